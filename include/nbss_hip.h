@@ -1,0 +1,95 @@
+/* nbss_hip.h — C ABI of the MI355X-native SpatialNet hot path (libnbss_hip.so).
+ *
+ * The reference (Audio-WestlakeU/NBSS) is pure Python; its "plugin API" for this path is the
+ * nn.Module contract `arch.forward([B,F,T,2C]) -> [B,F,T,2*Spk]` (SharedTrainer.py:117-122)
+ * plus models/io/{stft,norm,loss}.py.  Every implicit ATen/cuDNN/cuBLAS/cuFFT kernel that
+ * contract reaches is replaced by one entry point below; each comment cites the reference
+ * site it stands in for.  Conventions:
+ *   - plain pointers + sizes only, no torch types; all pointers are DEVICE pointers owned by
+ *     the caller (no ownership transfer, no hidden allocation);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); re-entrant, callable from any
+ *     host thread (PyTorch's autograd thread calls the *_bwd entry points);
+ *   - returns 0 on success, a negative NBSS_E* code otherwise; never throws or exits;
+ *   - `dtype` = element type of the [B,F,T,H] residual stream and of the packed weights:
+ *        NBSS_F32  fp32 stream, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)
+ *        NBSS_BF16 bf16 stream, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate/statistics
+ *     master parameters, gradients, STFT/iSTFT, loss and optimizer state are always fp32.
+ */
+#ifndef NBSS_HIP_H
+#define NBSS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBSS_F32 0
+#define NBSS_BF16 1
+
+#define NBSS_OK 0
+#define NBSS_EINVAL (-1)       /* bad argument */
+#define NBSS_EUNSUPPORTED (-2) /* shape/config this build has no kernel for */
+#define NBSS_ELAUNCH (-3)      /* HIP launch error */
+
+/* SpatialNet hyper-parameters: models/arch/SpatialNet.py:154-171 (ctor) + batch geometry. */
+typedef struct nbss_cfg {
+    int32_t B, F, T;         /* batch, frequencies (129), frames (251) */
+    int32_t C_in, C_out;     /* dim_input (2*channels), dim_output (2*speakers) */
+    int32_t H, FFN, SQ;      /* dim_hidden, dim_ffn, dim_squeeze */
+    int32_t L, heads;        /* num_layers, num_heads */
+    int32_t enc_ks;          /* encoder_kernel_size */
+    int32_t f_ks, t_ks;      /* kernel_size = (f, t) */
+    int32_t f_groups, t_groups; /* conv_groups = (f, t) */
+    int32_t full_share;      /* layers > full_share reuse layer full_share's LinearGroup */
+    int32_t dtype;           /* NBSS_F32 | NBSS_BF16 */
+} nbss_cfg;
+
+/* ---- parameter geometry ------------------------------------------------------------------
+ * Parameters (and their gradients) live in ONE flat fp32 buffer; tensors appear in the
+ * reference's state_dict order (SURVEY.md §8(b) checkpoint contract):
+ *   encoder.weight, encoder.bias,
+ *   per layer l: fconv1.0.{weight,bias} fconv1.1.{weight,bias} fconv1.2.weight
+ *                norm_full.{weight,bias} squeeze.0.{weight,bias} full.{weight,bias}
+ *                unsqueeze.0.{weight,bias} fconv2.0.* fconv2.1.* fconv2.2.weight
+ *                norm_mhsa.{weight,bias} mhsa.in_proj_{weight,bias} mhsa.out_proj.{weight,bias}
+ *                tconvffn.{0,1,3,5,6,8,10}.{weight,bias}
+ *   decoder.weight, decoder.bias
+ * A shared `full` keeps the owner's offset (numel still reported, so offsets may repeat).
+ * nbss_param_table fills offsets[i] / numels[i] (in floats) and returns the entry count
+ * (2 + 38*L + 2), or a negative error.  Pass NULL arrays to query the count only. */
+int nbss_param_table(const nbss_cfg* cfg, int64_t* offsets, int64_t* numels, int max_entries);
+int64_t nbss_param_count(const nbss_cfg* cfg);   /* floats in the flat buffer */
+
+/* Packed MFMA weight fragments (+transposes for backward), rebuilt from the fp32 master
+ * copy after every optimizer step.  bytes needed / repack. */
+int64_t nbss_packed_bytes(const nbss_cfg* cfg);
+int nbss_pack_params(const nbss_cfg* cfg, const float* params, void* packed, void* stream);
+
+/* ---- SpatialNet sub-blocks, forward --------------------------------------------------------
+ * x/y: residual stream [B,F,T,H] of cfg->dtype.  y may not alias x (x is what backward
+ * re-reads).  `layer` selects the parameter slice. */
+
+/* encoder nn.Conv1d(C_in,H,5,'same') along T (SpatialNet.py:175,205).  xin [B,F,T,C_in]. */
+int nbss_encoder_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* xin, void* y, void* stream);
+/* decoder nn.Linear(H,C_out) (SpatialNet.py:200,216).  out [B,F,T,C_out] fp32. */
+int nbss_decoder_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* x, float* out, void* stream);
+/* x + _fconv(fconv1|fconv2): LN -> grouped Conv1d along F -> PReLU (SpatialNet.py:85,87,116-127). which = 0|1 */
+int nbss_fconv_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, int which, const void* x, void* y, void* stream);
+/* x + _full: LN -> squeeze+SiLU -> LinearGroup over F -> unsqueeze+SiLU (SpatialNet.py:86,129-146). */
+int nbss_full_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
+/* x + _tsa: LN -> nn.MultiheadAttention over T per (b,f) (SpatialNet.py:88,93-100). */
+int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
+/* x + _tconvffn (SpatialNet.py:90,102-114,61-73). */
+int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
+
+/* ---- diagnostics ---------------------------------------------------------------------------*/
+/* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
+ * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */
+int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream);
+const char* nbss_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBSS_HIP_H */

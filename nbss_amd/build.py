@@ -1,0 +1,114 @@
+"""Build the gfx950 shared library (libnbss_hip.so) from nbss_amd/csrc/*.hip with hipcc.
+
+In-tree build so that the .so travels with the repo snapshot to the GPU box.  Also knows how to
+build the host *emulator* flavour of the same sources (tests/hipemu, -DNBSS_EMU) which the CPU
+test-suite uses to exercise the kernels' index math without a GPU — that library is test
+infrastructure and is never loaded by the product code.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "nbss_amd" / "csrc"
+LIBDIR = ROOT / "nbss_amd" / "lib"
+EMUDIR = ROOT / "tests" / "hipemu"
+HIP_LIB = LIBDIR / "libnbss_hip.so"
+EMU_LIB = EMUDIR / "libnbss_emu.so"
+
+
+def _sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _headers():
+    return sorted(CSRC.glob("*.h")) + [ROOT / "include" / "nbss_hip.h"]
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(map(str, cmd)) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError(f"build failed: {cmd[0]} {cmd[-1]}")
+    return r
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found")
+    return p
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every .hip for gfx950 and link libnbss_hip.so (no-op when up to date)."""
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    objdir = LIBDIR / "obj"
+    objdir.mkdir(exist_ok=True)
+    hipcc = hipcc_path()
+    hdrs = _headers()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+             "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-pass-failed"]
+    jobs = []
+    objs = []
+    for s in _sources():
+        o = objdir / (s.stem + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+    if jobs:
+        if verbose:
+            print(f"[nbss_amd.build] hipcc: compiling {len(jobs)} file(s) for gfx950", flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _newer(HIP_LIB, objs):
+        # do not record an rpath to /opt/rocm/lib: the process already has torch's HIP runtime loaded
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(HIP_LIB), *map(str, objs)])
+    return HIP_LIB
+
+
+def build_emu(force: bool = False, verbose: bool = False) -> Path:
+    """Host build of the same kernel sources on top of tests/hipemu (CPU tests only)."""
+    objdir = EMUDIR / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = shutil.which("clang++") or cxx
+    hdrs = _headers() + [EMUDIR / "hipemu.h"]
+    flags = ["-x", "c++", "-DNBSS_EMU", "-O2", "-std=c++17", "-fPIC", f"-I{EMUDIR}", "-Wno-unused-variable",
+             "-Wno-unused-but-set-variable", "-Wno-pass-failed", "-Wno-unknown-attributes"]
+    jobs = []
+    objs = []
+    for s in _sources() + [EMUDIR / "hipemu.cpp"]:
+        o = objdir / (s.stem + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([cxx, *flags, "-c", str(s), "-o", str(o)])
+    if jobs:
+        if verbose:
+            print(f"[nbss_amd.build] emulator: compiling {len(jobs)} file(s)", flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _newer(EMU_LIB, objs):
+        _run([cxx, "-shared", "-fPIC", "-o", str(EMU_LIB), *map(str, objs), "-lpthread"])
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "hip"
+    if which in ("hip", "all"):
+        print(build_hip(verbose=True))
+    if which in ("emu", "all"):
+        print(build_emu(verbose=True))

@@ -1,0 +1,193 @@
+// Device-side building blocks shared by every nbss_amd kernel (gfx950 / CDNA4).
+//
+// Everything on the SpatialNet hot path is written against ONE fragment scheme for the
+// 16x16x32 MFMA ("form 2": weights are the A operand, tokens are the N dimension):
+//
+//   A frag  lane l : A[m = l&15][k = kmap(l>>4, j)],  j = 0..7
+//   B frag  lane l : B[k = kmap(l>>4, j)][n = l&15]
+//   C/D     lane l : D[m = (l>>4)*4 + r][n = l&15],   r = 0..3
+//
+// with two K orders inside a 32-wide K block:
+//   natural ("N"):  kmap(g, j) = 8g + j                      (16-byte contiguous per lane)
+//   permuted ("P"): kmap(g, j) = j < 4 ? 4g + j : 16 + 4g + (j-4)
+// The P order is exactly what two stacked C tiles (rows 0..15 and 16..31) look like when
+// they are re-used as the B operand of the next product, so chains of per-token linear
+// maps never leave registers.  Weights are pre-packed per lane (pack.hip) in whichever
+// order the consuming kernel needs.
+//
+// The stream dtype T is bf16 (bf16-mixed training, v_mfma_f32_16x16x32_bf16) or float
+// (fp32 training / parity runs, 8x v_mfma_f32_16x16x4_f32 per 32-wide K block: lane group
+// g supplies k = kmap(g, j) at sub-step j, identical data placement).
+#pragma once
+#ifdef NBSS_EMU
+#include "hipemu.h"
+#define NBSS_LDS(name) char* name = hipemu::g_block->lds
+#else
+#include <hip/hip_runtime.h>
+#define NBSS_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+#include <stdint.h>
+
+typedef unsigned short bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define NBSS_DEV __device__ __forceinline__
+
+NBSS_DEV float bf2f(bf16_t h) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)h) << 16;
+    return c.f;
+}
+NBSS_DEV bf16_t f2bf(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+NBSS_DEV uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+NBSS_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
+NBSS_DEV float dsilu_f(float x) {
+    float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+
+NBSS_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+NBSS_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+
+NBSS_DEV float wave_sum16(float v) {  // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+NBSS_DEV float wave_max16(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+NBSS_DEV float wave_sum64(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// ---- element access helpers, generic over the stream dtype ------------------------------
+NBSS_DEV void load4(const float* p, float o[4]) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+NBSS_DEV void load4(const bf16_t* p, float o[4]) {
+    u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    o[0] = bf2f((bf16_t)(v[0] & 0xFFFF)); o[1] = bf2f((bf16_t)(v[0] >> 16));
+    o[2] = bf2f((bf16_t)(v[1] & 0xFFFF)); o[3] = bf2f((bf16_t)(v[1] >> 16));
+}
+NBSS_DEV void load8(const float* p, float o[8]) { load4(p, o); load4(p + 4, o + 4); }
+NBSS_DEV void load8(const bf16_t* p, float o[8]) {
+    u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = bf2f((bf16_t)(v[i] & 0xFFFF));
+        o[2 * i + 1] = bf2f((bf16_t)(v[i] >> 16));
+    }
+}
+NBSS_DEV void store4(float* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+NBSS_DEV void store4(bf16_t* p, float a, float b, float c, float d) {
+    u32x2 v = {pack2bf(a, b), pack2bf(c, d)};
+    *reinterpret_cast<u32x2*>(p) = v;
+}
+NBSS_DEV void store1(float* p, float a) { *p = a; }
+NBSS_DEV void store1(bf16_t* p, float a) { *p = f2bf(a); }
+NBSS_DEV float load1(const float* p) { return *p; }
+NBSS_DEV float load1(const bf16_t* p) { return bf2f(*p); }
+// rounding a value to the stream precision (identity for float)
+NBSS_DEV float round_to(float v, const float*) { return v; }
+NBSS_DEV float round_to(float v, const bf16_t*) { return bf2f(f2bf(v)); }
+
+// ---- MFMA fragments ---------------------------------------------------------------------
+template <class T> struct Frag;
+template <> struct Frag<bf16_t> { s16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+NBSS_DEV void frag_zero(Frag<bf16_t>& f) { f.v = (s16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+NBSS_DEV void frag_zero(Frag<float>& f) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
+}
+// 8 contiguous elements (natural K order)
+NBSS_DEV void frag_load(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const s16x8*>(p); }
+NBSS_DEV void frag_load(Frag<float>& f, const float* p) { load8(p, f.v); }
+// two 4-element pieces (permuted K order, or conv taps)
+NBSS_DEV void frag_load_lo(Frag<bf16_t>& f, const bf16_t* p) {
+    s16x4 a = *reinterpret_cast<const s16x4*>(p);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+}
+NBSS_DEV void frag_load_hi(Frag<bf16_t>& f, const bf16_t* p) {
+    s16x4 a = *reinterpret_cast<const s16x4*>(p);
+    f.v[4] = a[0]; f.v[5] = a[1]; f.v[6] = a[2]; f.v[7] = a[3];
+}
+NBSS_DEV void frag_load_lo(Frag<float>& f, const float* p) { load4(p, f.v); }
+NBSS_DEV void frag_load_hi(Frag<float>& f, const float* p) { load4(p, f.v + 4); }
+NBSS_DEV void frag_zero_lo(Frag<bf16_t>& f) { f.v[0] = 0; f.v[1] = 0; f.v[2] = 0; f.v[3] = 0; }
+NBSS_DEV void frag_zero_hi(Frag<bf16_t>& f) { f.v[4] = 0; f.v[5] = 0; f.v[6] = 0; f.v[7] = 0; }
+NBSS_DEV void frag_zero_lo(Frag<float>& f) { f.v[0] = 0; f.v[1] = 0; f.v[2] = 0; f.v[3] = 0; }
+NBSS_DEV void frag_zero_hi(Frag<float>& f) { f.v[4] = 0; f.v[5] = 0; f.v[6] = 0; f.v[7] = 0; }
+NBSS_DEV void frag_set(Frag<bf16_t>& f, int j, float x) { f.v[j] = (short)f2bf(x); }
+NBSS_DEV void frag_set(Frag<float>& f, int j, float x) { f.v[j] = x; }
+NBSS_DEV float frag_get(const Frag<bf16_t>& f, int j) { return bf2f((bf16_t)f.v[j]); }
+NBSS_DEV float frag_get(const Frag<float>& f, int j) { return f.v[j]; }
+// fragment from 8 floats
+template <class T>
+NBSS_DEV void frag_from(Frag<T>& f, const float x[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) frag_set(f, j, x[j]);
+}
+// two stacked C tiles -> permuted-order B (or A) fragment
+template <class T>
+NBSS_DEV void frag_from_c2(Frag<T>& f, const f32x4& lo, const f32x4& hi) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        frag_set(f, j, lo[j]);
+        frag_set(f, 4 + j, hi[j]);
+    }
+}
+
+NBSS_DEV f32x4 mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4 c) {
+#ifdef NBSS_EMU
+    return hipemu::mfma_16x16x32_bf16(a.v, b.v, c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+#endif
+}
+NBSS_DEV f32x4 mma(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#ifdef NBSS_EMU
+        c = hipemu::mfma_16x16x4_f32(a.v[j], b.v[j], c);
+#else
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+#endif
+    }
+    return c;
+}
+
+#define F32X4_ZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
+
+// packed weight fragments live in global memory as [tile][kstep][lane][8] of T
+template <class T>
+NBSS_DEV void wfrag_load(Frag<T>& f, const T* base, int tile, int ksteps, int ks) {
+    frag_load(f, base + ((size_t)(tile * ksteps + ks) * 64 + lane_id()) * 8);
+}

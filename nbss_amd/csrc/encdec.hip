@@ -1,0 +1,115 @@
+// encdec.hip — SpatialNet encoder (nn.Conv1d(C_in,H,5,'same') along T, SpatialNet.py:175,205)
+// and decoder (nn.Linear(H,C_out), SpatialNet.py:200,216), forward and backward.
+//
+// One wave owns a strip of 16 consecutive frames of one (b,f) sequence; the weights are the
+// MFMA A operand (form 2), so a lane ends up with 4 consecutive channels of one frame and the
+// [B,F,T,H] stream is written with 8/16-byte stores.
+#include "launch.h"
+#include "layout.h"
+
+#define ENC_H 96
+
+template <class T>
+__global__ __launch_bounds__(256) void encoder_fwd_kernel(nbss_cfg c, const float* __restrict__ P, const T* __restrict__ Wp,
+                                                          const T* __restrict__ xin, T* __restrict__ y) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int T_ = c.T, Cin = c.C_in, pc = Cin / 4, np = c.enc_ks * pc, half = c.enc_ks / 2;
+    const int nst = cdiv(T_, 16);
+    const int nstrips = c.B * c.F * nst;
+    constexpr int MT = ENC_H / 16;
+    const int KS = cdiv(np, 8);  // <= 3 for C_in <= 16 (checked by host)
+    const float* bias = P + param_off_enc_b(c);
+    const int wpb = blockDim.x >> 6;
+    for (int s = blockIdx.x * wpb + wave_id(); s < nstrips; s += gridDim.x * wpb) {
+        const int bf = s / nst, t0 = (s % nst) * 16;
+        const T* xb = xin + (size_t)bf * T_ * Cin;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = F32X4_ZERO;
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag<T> b;
+            frag_zero(b);
+            const int p0 = ks * 8 + g4 * 2, p1 = p0 + 1;
+            if (p0 < np) {
+                const int t = t0 + l15 + p0 / pc - half;
+                if (t >= 0 && t < T_) frag_load_lo(b, xb + (size_t)t * Cin + (p0 % pc) * 4);
+            }
+            if (p1 < np) {
+                const int t = t0 + l15 + p1 / pc - half;
+                if (t >= 0 && t < T_) frag_load_hi(b, xb + (size_t)t * Cin + (p1 % pc) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                Frag<T> a;
+                wfrag_load(a, Wp, i, KS, ks);
+                acc[i] = mma(a, b, acc[i]);
+            }
+        }
+        const int t = t0 + l15;
+        if (t < T_) {
+            T* yr = y + ((size_t)bf * T_ + t) * ENC_H;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int ch = 16 * i + 4 * g4;
+                store4(yr + ch, acc[i][0] + bias[ch], acc[i][1] + bias[ch + 1], acc[i][2] + bias[ch + 2], acc[i][3] + bias[ch + 3]);
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void decoder_fwd_kernel(nbss_cfg c, const float* __restrict__ P, const T* __restrict__ Wp,
+                                                          const T* __restrict__ x, float* __restrict__ out) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int T_ = c.T, Co = c.C_out;
+    const int nst = cdiv(T_, 16);
+    const int nstrips = c.B * c.F * nst;
+    constexpr int KS = ENC_H / 32;
+    const float* bias = P + param_off_dec_b(c);
+    Frag<T> a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wfrag_load(a[ks], Wp, 0, KS, ks);
+    const int wpb = blockDim.x >> 6;
+    for (int s = blockIdx.x * wpb + wave_id(); s < nstrips; s += gridDim.x * wpb) {
+        const int bf = s / nst, t = (s % nst) * 16 + l15;
+        f32x4 acc = F32X4_ZERO;
+        const T* xr = x + ((size_t)bf * T_ + t) * ENC_H;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag<T> b;
+            if (t < T_) frag_load(b, xr + ks * 32 + 8 * g4);
+            else frag_zero(b);
+            acc = mma(a[ks], b, acc);
+        }
+        if (t < T_) {
+            float* o = out + ((size_t)bf * T_ + t) * Co;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 4 * g4 + r;
+                if (ch < Co) o[ch] = acc[r] + bias[ch];
+            }
+        }
+    }
+}
+
+template <class T>
+static int encoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, const void* xin, void* y, hipStream_t st) {
+    const int nstrips = c.B * c.F * cdiv(c.T, 16);
+    dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
+    NBSS_LAUNCH((encoder_fwd_kernel<T>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_ENC), (const T*)xin, (T*)y);
+    return NBSS_CHECK_LAUNCH();
+}
+template <class T>
+static int decoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st) {
+    const int nstrips = c.B * c.F * cdiv(c.T, 16);
+    dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
+    NBSS_LAUNCH((decoder_fwd_kernel<T>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_DEC), (const T*)x, out);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int encoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* xin, void* y, hipStream_t st) {
+    return c.dtype == NBSS_BF16 ? encoder_fwd_t<bf16_t>(c, P, packed, xin, y, st) : encoder_fwd_t<float>(c, P, packed, xin, y, st);
+}
+int decoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st) {
+    return c.dtype == NBSS_BF16 ? decoder_fwd_t<bf16_t>(c, P, packed, x, out, st) : decoder_fwd_t<float>(c, P, packed, x, out, st);
+}

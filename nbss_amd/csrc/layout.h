@@ -1,0 +1,155 @@
+// Flat fp32 parameter layout (reference state_dict order) and the layout of
+// the packed MFMA weight-fragment buffer.  Pure arithmetic on nbss_cfg so that host code and
+// device code (pack.hip) agree by construction.
+#pragma once
+#include "../../include/nbss_hip.h"
+
+#ifdef NBSS_EMU
+#define NBSS_HD inline
+#else
+#define NBSS_HD __host__ __device__ inline
+#endif
+
+enum LayerParam {
+    P_FC1_LN_W, P_FC1_LN_B, P_FC1_W, P_FC1_B, P_FC1_PRELU,
+    P_FULL_LN_W, P_FULL_LN_B, P_SQ_W, P_SQ_B, P_FULL_W, P_FULL_B, P_USQ_W, P_USQ_B,
+    P_FC2_LN_W, P_FC2_LN_B, P_FC2_W, P_FC2_B, P_FC2_PRELU,
+    P_MH_LN_W, P_MH_LN_B, P_INP_W, P_INP_B, P_OUTP_W, P_OUTP_B,
+    P_TF_LN_W, P_TF_LN_B, P_TF_W1, P_TF_B1, P_TF_C1W, P_TF_C1B, P_TF_C2W, P_TF_C2B,
+    P_TF_GN_W, P_TF_GN_B, P_TF_C3W, P_TF_C3B, P_TF_W2, P_TF_B2,
+    NUM_LAYER_PARAMS
+};
+
+NBSS_HD int64_t layer_param_numel(const nbss_cfg& c, int p) {
+    const int64_t H = c.H, FFN = c.FFN, SQ = c.SQ, F = c.F;
+    switch (p) {
+        case P_FC1_LN_W: case P_FC1_LN_B: case P_FC2_LN_W: case P_FC2_LN_B:
+        case P_FULL_LN_W: case P_FULL_LN_B: case P_MH_LN_W: case P_MH_LN_B:
+        case P_TF_LN_W: case P_TF_LN_B:
+        case P_FC1_B: case P_FC2_B: case P_FC1_PRELU: case P_FC2_PRELU:
+        case P_USQ_B: case P_OUTP_B: case P_TF_B2:
+            return H;
+        case P_FC1_W: case P_FC2_W: return H * (H / c.f_groups) * c.f_ks;
+        case P_SQ_W: return SQ * H;
+        case P_SQ_B: return SQ;
+        case P_FULL_W: return SQ * F * F;
+        case P_FULL_B: return SQ * F;
+        case P_USQ_W: return H * SQ;
+        case P_INP_W: return 3 * H * H;
+        case P_INP_B: return 3 * H;
+        case P_OUTP_W: return H * H;
+        case P_TF_W1: return FFN * H;
+        case P_TF_B1: case P_TF_C1B: case P_TF_C2B: case P_TF_C3B: case P_TF_GN_W: case P_TF_GN_B: return FFN;
+        case P_TF_C1W: case P_TF_C2W: case P_TF_C3W: return FFN * (FFN / c.t_groups) * c.t_ks;
+        case P_TF_W2: return H * FFN;
+    }
+    return 0;
+}
+
+NBSS_HD int64_t enc_w_numel(const nbss_cfg& c) { return (int64_t)c.H * c.C_in * c.enc_ks; }
+NBSS_HD int64_t param_off_enc_w(const nbss_cfg&) { return 0; }
+NBSS_HD int64_t param_off_enc_b(const nbss_cfg& c) { return enc_w_numel(c); }
+
+NBSS_HD int64_t layer_numel(const nbss_cfg& c, int l) {
+    int64_t s = 0;
+    for (int p = 0; p < NUM_LAYER_PARAMS; ++p) {
+        if ((p == P_FULL_W || p == P_FULL_B) && l > c.full_share) continue;
+        s += layer_param_numel(c, p);
+    }
+    return s;
+}
+NBSS_HD int64_t layer_base(const nbss_cfg& c, int l) {
+    int64_t o = enc_w_numel(c) + c.H;
+    for (int i = 0; i < l; ++i) o += layer_numel(c, i);
+    return o;
+}
+NBSS_HD int64_t param_off(const nbss_cfg& c, int l, int p) {
+    if ((p == P_FULL_W || p == P_FULL_B) && l > c.full_share) l = c.full_share;
+    int64_t o = layer_base(c, l);
+    for (int q = 0; q < p; ++q) {
+        if ((q == P_FULL_W || q == P_FULL_B) && l > c.full_share) continue;
+        o += layer_param_numel(c, q);
+    }
+    return o;
+}
+NBSS_HD int64_t param_off_dec_w(const nbss_cfg& c) { return layer_base(c, c.L); }
+NBSS_HD int64_t param_off_dec_b(const nbss_cfg& c) { return param_off_dec_w(c) + (int64_t)c.C_out * c.H; }
+NBSS_HD int64_t param_total(const nbss_cfg& c) { return param_off_dec_b(c) + c.C_out; }
+
+// ---- packed fragment buffer ------------------------------------------------------------------
+// Every entry is [MT tiles][KS ksteps][64 lanes][8] elements of the stream dtype.
+enum PackKind {
+    // forward operands
+    K_ENC = 0,   // encoder conv: rows = out ch, K = (tap, 4-ch piece)
+    K_DEC,       // decoder linear, natural K
+    K_FC1, K_FC2,  // f-conv, per group: rows = 12(+4 pad) out ch, K = (tap, 4-ch piece)
+    K_SQ,        // squeeze 1x1, natural K
+    K_FULL,      // LinearGroup, per squeeze channel: rows = k (out freq), K = h natural
+    K_USQ,       // unsqueeze 1x1, K = SQ natural
+    K_INP,       // in_proj: rows = [q|k|v] x heads x (dh + pad to 32), natural K
+    K_OUTP,      // out_proj: K = heads x 32, permuted order inside each head
+    K_TF_W1,     // 1x1 H->FFN, rows = groups x (cg + pad to 32), natural K
+    K_TF_C1, K_TF_C2, K_TF_C3,  // t-conv, per group: rows = cg (+pad), K = (tap, 4-ch piece)
+    K_TF_W2,     // 1x1 FFN->H, K = groups x 32 permuted
+    NUM_PACK_KINDS
+};
+
+struct PackGeom {
+    int MT, KS, NB;  // tiles, ksteps, number of independent blocks (groups) in this entry
+};
+
+NBSS_HD int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+NBSS_HD PackGeom pack_geom(const nbss_cfg& c, int kind) {
+    PackGeom g = {0, 0, 1};
+    const int dh = c.H / c.heads, cg = c.FFN / c.t_groups, fg = c.H / c.f_groups;
+    switch (kind) {
+        case K_ENC: g.MT = c.H / 16; g.KS = cdiv(c.enc_ks * (c.C_in / 4), 8); break;
+        case K_DEC: g.MT = cdiv(c.C_out, 16); g.KS = c.H / 32; break;
+        case K_FC1: case K_FC2: g.MT = cdiv(fg, 16); g.KS = cdiv(c.f_ks * (fg / 4), 8); g.NB = c.f_groups; break;
+        case K_SQ: g.MT = cdiv(c.SQ, 16); g.KS = c.H / 32; break;
+        case K_FULL: g.MT = cdiv(c.F, 16); g.KS = cdiv(c.F, 32); g.NB = c.SQ; break;
+        case K_USQ: g.MT = c.H / 16; g.KS = cdiv(c.SQ, 32); break;
+        case K_INP: g.MT = 3 * c.heads * cdiv(dh, 32) * 2; g.KS = c.H / 32; break;
+        case K_OUTP: g.MT = c.H / 16; g.KS = c.heads * cdiv(dh, 32); break;
+        case K_TF_W1: g.MT = c.t_groups * cdiv(cg, 32) * 2; g.KS = c.H / 32; break;
+        case K_TF_C1: case K_TF_C2: case K_TF_C3: g.MT = cdiv(cg, 32) * 2; g.KS = cdiv(c.t_ks * (cg / 4), 8); g.NB = c.t_groups; break;
+        case K_TF_W2: g.MT = c.H / 16; g.KS = c.t_groups * cdiv(cg, 32); break;
+    }
+    return g;
+}
+NBSS_HD int64_t pack_numel(const nbss_cfg& c, int kind) {
+    PackGeom g = pack_geom(c, kind);
+    return (int64_t)g.NB * g.MT * g.KS * 512;
+}
+NBSS_HD bool pack_is_global(int kind) { return kind == K_ENC || kind == K_DEC; }
+// offset (in elements) of entry `kind` for `layer` inside the packed buffer
+NBSS_HD int64_t pack_layer_numel(const nbss_cfg& c) {
+    int64_t s = 0;
+    for (int k = 0; k < NUM_PACK_KINDS; ++k)
+        if (!pack_is_global(k)) s += pack_numel(c, k);
+    return s;
+}
+NBSS_HD int64_t pack_off(const nbss_cfg& c, int layer, int kind) {
+    if (kind == K_ENC) return 0;
+    if (kind == K_DEC) return pack_numel(c, K_ENC);
+    int64_t o = pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + (int64_t)layer * pack_layer_numel(c);
+    for (int k = 0; k < kind; ++k)
+        if (!pack_is_global(k)) o += pack_numel(c, k);
+    return o;
+}
+NBSS_HD int64_t pack_total(const nbss_cfg& c) {
+    return pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + (int64_t)c.L * pack_layer_numel(c);
+}
+
+NBSS_HD int check_cfg(const nbss_cfg& c) {
+    if (c.B <= 0 || c.F <= 0 || c.T <= 0 || c.L <= 0) return NBSS_EINVAL;
+    if (c.dtype != NBSS_F32 && c.dtype != NBSS_BF16) return NBSS_EINVAL;
+    // this build ships kernels for the SpatialNet-small geometry (configs/SpatialNet.yaml)
+    if (c.H != 96 || c.FFN != 192 || c.SQ != 8 || c.heads != 4) return NBSS_EUNSUPPORTED;
+    if (c.f_groups != 8 || c.t_groups != 8 || c.f_ks != 5 || c.t_ks != 3 || c.enc_ks != 5) return NBSS_EUNSUPPORTED;
+    if (c.C_in % 4 != 0 || c.C_in > 16 || c.C_out > 16 || c.C_out <= 0) return NBSS_EUNSUPPORTED;
+    if (c.F > 160 || c.T > 256) return NBSS_EUNSUPPORTED;
+    if (c.full_share < 0 || c.full_share >= c.L) return NBSS_EINVAL;
+    return NBSS_OK;
+}

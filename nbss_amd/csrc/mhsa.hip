@@ -1,0 +1,269 @@
+// mhsa.hip — narrow-band multi-head self-attention module of SpatialNetLayer:
+//   y = x + out_proj(softmax(q k^T / sqrt(dh)) v),  [q,k,v] = in_proj(LayerNorm_H(x))
+// over the T frames of every (b,f) sequence (SpatialNet.py:88,93-100; nn.MultiheadAttention,
+// 4 heads, dh = 24, no mask, no dropout, need_weights always False).
+//
+// One workgroup = one (b,f) sequence (T <= 256 frames, 48 KB of bf16 stream).  K (row-major)
+// and V^T of every head are LDS resident; Q, the probabilities and the per-head outputs never
+// leave registers:
+//   * all projections are "form 2" GEMMs (weights = MFMA A operand, frames = N), so a C tile
+//     holds 4 consecutive channels of one frame per lane;
+//   * S^T = K Q^T is computed (not S), which makes the C tiles of S^T directly the B operand of
+//     O^T = V^T P^T and keeps the softmax row (all keys of one query) inside 4 lanes:
+//     row max / sum = in-lane reduce + two xor-shuffles (16, 32);
+//   * two stacked C tiles are re-used as the next B operand in the permuted K order
+//     (common.h), which is how Q^T feeds S^T and O^T feeds the output projection.
+// T = 251 is padded to 16 tiles of 16 keys; padded keys are masked to -inf.
+#include "launch.h"
+#include "layout.h"
+
+#define MH_H 96
+#define MH_HEADS 4
+#define MH_DH 24
+#define MH_TP 256
+#define MH_NT 16       // key/query tiles of 16 frames
+#define MH_NSW 4       // strips per wave (4 waves x 4 strips = 16 strips)
+#define MH_KS (MH_H / 32)
+
+// LN of a 16-frame strip held as natural-order B fragments (lane: frame l&15, channels 32ks+8g+j)
+template <class T>
+NBSS_DEV void ln_strip(const T* __restrict__ xr, bool valid, const float (&gam)[MH_KS][8], const float (&bet)[MH_KS][8], Frag<T> (&u)[MH_KS]) {
+    const int g4 = lane_id() >> 4;
+    float v[MH_KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < MH_KS; ++ks) {
+        if (valid) load8(xr + ks * 32 + 8 * g4, v[ks]);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[ks][j];
+    }
+    const float mean = wave_sum16(sum) * (1.0f / MH_H);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < MH_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[ks][j] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum16(q) * (1.0f / MH_H) + 1e-5f);
+#pragma unroll
+    for (int ks = 0; ks < MH_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frag_set(u[ks], j, (v[ks][j] - mean) * rstd * gam[ks][j] + bet[ks][j]);
+}
+
+template <class T, int HPP>
+__global__ __launch_bounds__(256) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                       const float* __restrict__ bin, const float* __restrict__ bout,
+                                                       const T* __restrict__ Win, const T* __restrict__ Wout,
+                                                       const T* __restrict__ x, T* __restrict__ y) {
+    NBSS_LDS(smem);
+    T* Ks = reinterpret_cast<T*>(smem);              // [HPP][TP][DH]
+    T* Vt = Ks + HPP * MH_TP * MH_DH;                // [HPP][DH][TP]
+    const int T_ = c.T, nst = cdiv(T_, 16);
+    const int bf = blockIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const T* xb = x + (size_t)bf * T_ * MH_H;
+    T* yb = y + (size_t)bf * T_ * MH_H;
+    const float qscale = 1.4426950408889634f * rsqrtf((float)MH_DH);
+
+    float gam[MH_KS][8], bet[MH_KS][8];
+#pragma unroll
+    for (int ks = 0; ks < MH_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gam[ks][j] = lnw[ks * 32 + 8 * g4 + j];
+            bet[ks][j] = lnb[ks * 32 + 8 * g4 + j];
+        }
+
+    for (int pass = 0; pass < MH_HEADS / HPP; ++pass) {
+        // (all 16 strips are always projected, so every K / V^T entry is (re)written each pass and
+        //  padded frames hold finite values: their keys are masked and their probabilities are 0)
+        if (pass > 0) __syncthreads();
+
+        // ---- stage A: LN, then Q (registers), K and V^T (LDS) for this pass's heads --------
+        Frag<T> qf[MH_NSW][HPP];
+        {
+            Frag<T> u[MH_NSW][MH_KS];
+#pragma unroll
+            for (int si = 0; si < MH_NSW; ++si) {
+                const int t = (w * MH_NSW + si) * 16 + l15;
+                ln_strip<T>(xb + (size_t)t * MH_H, t < T_, gam, bet, u[si]);
+            }
+#pragma unroll
+            for (int which = 0; which < 3; ++which) {
+#pragma unroll
+                for (int hh = 0; hh < HPP; ++hh) {
+                    const int head = pass * HPP + hh;
+                    f32x4 ct[MH_NSW][2];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        Frag<T> a[MH_KS];
+#pragma unroll
+                        for (int ks = 0; ks < MH_KS; ++ks) wfrag_load(a[ks], Win, (which * MH_HEADS + head) * 2 + half, MH_KS, ks);
+#pragma unroll
+                        for (int si = 0; si < MH_NSW; ++si) {
+                            f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                            for (int ks = 0; ks < MH_KS; ++ks) acc = mma(a[ks], u[si][ks], acc);
+                            ct[si][half] = acc;
+                        }
+                    }
+                    // bias (rows d >= DH are padding: weight rows are zero, keep the bias zero too)
+                    float b0[4], b1[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        b0[r] = bin[which * MH_H + head * MH_DH + 4 * g4 + r];
+                        b1[r] = (16 + 4 * g4 + r < MH_DH) ? bin[which * MH_H + head * MH_DH + 16 + 4 * g4 + r] : 0.f;
+                    }
+#pragma unroll
+                    for (int si = 0; si < MH_NSW; ++si) {
+                        const int t = (w * MH_NSW + si) * 16 + l15;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ct[si][0][r] += b0[r];
+                            ct[si][1][r] += b1[r];
+                        }
+                        if (which == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                ct[si][0][r] *= qscale;
+                                ct[si][1][r] *= qscale;
+                            }
+                            frag_from_c2(qf[si][hh], ct[si][0], ct[si][1]);
+                        } else if (which == 1) {
+                            T* kr = Ks + ((size_t)hh * MH_TP + t) * MH_DH;
+                            store4(kr + 4 * g4, ct[si][0][0], ct[si][0][1], ct[si][0][2], ct[si][0][3]);
+                            if (g4 < 2) store4(kr + 16 + 4 * g4, ct[si][1][0], ct[si][1][1], ct[si][1][2], ct[si][1][3]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                store1(Vt + ((size_t)hh * MH_DH + 4 * g4 + r) * MH_TP + t, ct[si][0][r]);
+                                if (g4 < 2) store1(Vt + ((size_t)hh * MH_DH + 16 + 4 * g4 + r) * MH_TP + t, ct[si][1][r]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- stage B: attention per (strip, head); outputs stay in registers as B fragments ---
+        Frag<T> of[MH_NSW][HPP];
+#pragma unroll
+        for (int si = 0; si < MH_NSW; ++si) {
+#pragma unroll
+            for (int hh = 0; hh < HPP; ++hh) {
+                const T* kh = Ks + (size_t)hh * MH_TP * MH_DH;
+                const T* vh = Vt + (size_t)hh * MH_DH * MH_TP;
+                f32x4 sc[MH_NT];
+                float mx = -1e30f;
+#pragma unroll
+                for (int j = 0; j < MH_NT; ++j) {
+                    if (j < nst) {
+                        Frag<T> a;
+                        const T* kr = kh + (size_t)(j * 16 + l15) * MH_DH;
+                        frag_load_lo(a, kr + 4 * g4);
+                        if (g4 < 2) frag_load_hi(a, kr + 16 + 4 * g4);
+                        else frag_zero_hi(a);
+                        sc[j] = mma(a, qf[si][hh], F32X4_ZERO);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
+                            mx = fmaxf(mx, sc[j][r]);
+                        }
+                    } else {
+                        sc[j] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
+                    }
+                }
+                mx = wave_max16(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < MH_NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = (j < nst) ? exp2f(sc[j][r] - mx) : 0.f;
+                        sc[j][r] = p;
+                        sum += p;
+                    }
+                sum = wave_sum16(sum);
+                const float inv = 1.0f / sum;
+                f32x4 o0 = F32X4_ZERO, o1 = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < MH_NT / 2; ++ks) {
+                    if (2 * ks < nst) {
+                        Frag<T> pf, a0, a1;
+                        frag_from_c2(pf, sc[2 * ks], sc[2 * ks + 1]);
+                        const T* v0 = vh + (size_t)l15 * MH_TP + ks * 32 + 4 * g4;
+                        frag_load_lo(a0, v0);
+                        frag_load_hi(a0, v0 + 16);
+                        o0 = mma(a0, pf, o0);
+                        if (l15 < MH_DH - 16) {
+                            const T* v1 = vh + (size_t)(16 + l15) * MH_TP + ks * 32 + 4 * g4;
+                            frag_load_lo(a1, v1);
+                            frag_load_hi(a1, v1 + 16);
+                        } else {
+                            frag_zero(a1);
+                        }
+                        o1 = mma(a1, pf, o1);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0[r] *= inv;
+                    o1[r] *= inv;
+                }
+                frag_from_c2(of[si][hh], o0, o1);
+            }
+        }
+
+        // ---- stage C: output projection (+bias, +residual) --------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < MH_H / 16; ++mt) {
+            Frag<T> a[HPP];
+#pragma unroll
+            for (int hh = 0; hh < HPP; ++hh) wfrag_load(a[hh], Wout, mt, MH_HEADS, pass * HPP + hh);
+            const int ch = 16 * mt + 4 * g4;
+#pragma unroll
+            for (int si = 0; si < MH_NSW; ++si) {
+                const int t = (w * MH_NSW + si) * 16 + l15;
+                f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                for (int hh = 0; hh < HPP; ++hh) acc = mma(a[hh], of[si][hh], acc);
+                if (t < T_) {
+                    float rv[4];
+                    if (pass == 0) {
+                        load4(xb + (size_t)t * MH_H + ch, rv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rv[r] += bout[ch + r];
+                    } else {
+                        load4(yb + (size_t)t * MH_H + ch, rv);
+                    }
+                    store4(yb + (size_t)t * MH_H + ch, rv[0] + acc[0], rv[1] + acc[1], rv[2] + acc[2], rv[3] + acc[3]);
+                }
+            }
+        }
+    }
+}
+
+template <class T, int HPP>
+static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T);
+    const T* pk = (const T*)packed;
+    int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP>), lds);
+    if (e) return e;
+    dim3 grid(c.B * c.F), block(256);
+    NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
+                P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
+                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    return c.dtype == NBSS_BF16 ? mhsa_fwd_t<bf16_t, 4>(c, P, packed, layer, x, y, st) : mhsa_fwd_t<float, 2>(c, P, packed, layer, x, y, st);
+}

@@ -1,0 +1,116 @@
+// pack.hip — re-layout of the fp32 master parameters into per-lane MFMA A-operand fragments.
+// One thread per packed element; grid = (chunks, kind, layer).  Runs once per optimizer step
+// (1.2 M parameters: a few microseconds), so every GEMM in the hot kernels fetches its weight
+// fragment with a single 16-byte (bf16) load per lane and no index arithmetic.
+#include "launch.h"
+#include "layout.h"
+
+NBSS_DEV int perm_k(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
+
+// value of A[m-tile mt, row i=lane&15][kstep ks, lane group g4, slot j] for (kind, layer, block nb)
+NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P, int kind, int layer, int nb, int mt, int ks, int lane, int j) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int m = mt * 16 + l15;
+    const int knat = ks * 32 + 8 * g4 + j;
+    const int H = c.H;
+    switch (kind) {
+        case K_ENC: {
+            const int pc = c.C_in / 4, p = ks * 8 + g4 * 2 + (j >> 2);
+            if (p >= c.enc_ks * pc) return 0.f;
+            const int tap = p / pc, i = (p % pc) * 4 + (j & 3);
+            return P[param_off_enc_w(c) + ((int64_t)m * c.C_in + i) * c.enc_ks + tap];
+        }
+        case K_DEC:
+            return m < c.C_out ? P[param_off_dec_w(c) + (int64_t)m * H + knat] : 0.f;
+        case K_FC1: case K_FC2: {
+            const int fg = H / c.f_groups, pc = fg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
+            if (m >= fg || p >= c.f_ks * pc) return 0.f;
+            const int tap = p / pc, i = (p % pc) * 4 + (j & 3);
+            const int64_t w = param_off(c, layer, kind == K_FC1 ? P_FC1_W : P_FC2_W);
+            return P[w + ((int64_t)(nb * fg + m) * fg + i) * c.f_ks + tap];
+        }
+        case K_SQ:
+            return m < c.SQ ? P[param_off(c, layer, P_SQ_W) + (int64_t)m * H + knat] : 0.f;
+        case K_FULL:
+            return (m < c.F && knat < c.F) ? P[param_off(c, layer, P_FULL_W) + ((int64_t)nb * c.F + m) * c.F + knat] : 0.f;
+        case K_USQ:
+            return knat < c.SQ ? P[param_off(c, layer, P_USQ_W) + (int64_t)m * c.SQ + knat] : 0.f;
+        case K_INP: {
+            const int dh = H / c.heads;
+            const int which = mt / (c.heads * 2), rem = mt % (c.heads * 2), head = rem >> 1, d = (rem & 1) * 16 + l15;
+            if (d >= dh) return 0.f;
+            return P[param_off(c, layer, P_INP_W) + (int64_t)(which * H + head * dh + d) * H + knat];
+        }
+        case K_OUTP: {
+            const int dh = H / c.heads, d = perm_k(g4, j);
+            if (d >= dh) return 0.f;
+            return P[param_off(c, layer, P_OUTP_W) + (int64_t)m * H + ks * dh + d];
+        }
+        case K_TF_W1: {
+            const int cg = c.FFN / c.t_groups, grp = mt >> 1, ci = (mt & 1) * 16 + l15;
+            if (ci >= cg) return 0.f;
+            return P[param_off(c, layer, P_TF_W1) + (int64_t)(grp * cg + ci) * H + knat];
+        }
+        case K_TF_C1: case K_TF_C2: case K_TF_C3: {
+            const int cg = c.FFN / c.t_groups, pc = cg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
+            if (m >= cg || p >= c.t_ks * pc) return 0.f;
+            const int tap = p / pc, i = (p % pc) * 4 + (j & 3);
+            const int pk = kind == K_TF_C1 ? P_TF_C1W : (kind == K_TF_C2 ? P_TF_C2W : P_TF_C3W);
+            return P[param_off(c, layer, pk) + ((int64_t)(nb * cg + m) * cg + i) * c.t_ks + tap];
+        }
+        case K_TF_W2: {
+            const int cg = c.FFN / c.t_groups, d = perm_k(g4, j);
+            if (d >= cg) return 0.f;
+            return P[param_off(c, layer, P_TF_W2) + (int64_t)m * c.FFN + ks * cg + d];
+        }
+    }
+    return 0.f;
+}
+
+template <class T>
+__global__ void pack_kernel(nbss_cfg c, const float* __restrict__ P, T* __restrict__ out) {
+    const int kind = blockIdx.y, layer = blockIdx.z;
+    if (pack_is_global(kind) && layer != 0) return;
+    const PackGeom g = pack_geom(c, kind);
+    const int64_t n = (int64_t)g.NB * g.MT * g.KS * 512;
+    T* dst = out + pack_off(c, layer, kind);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t r = e >> 9;
+        const int ks = (int)(r % g.KS);
+        r /= g.KS;
+        const int mt = (int)(r % g.MT), nb = (int)(r / g.MT);
+        store1(dst + e, pack_value(c, P, kind, layer, nb, mt, ks, lane, j));
+    }
+}
+
+int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipStream_t stream) {
+    dim3 grid(32, NUM_PACK_KINDS, c.L), block(256);
+    if (c.dtype == NBSS_BF16)
+        NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, params, (bf16_t*)packed);
+    else
+        NBSS_LAUNCH((pack_kernel<float>), grid, block, 0, stream, c, params, (float*)packed);
+    return NBSS_CHECK_LAUNCH();
+}
+
+// ---- MFMA fragment self-test -------------------------------------------------------------
+template <class T>
+__global__ void selftest_mma_kernel(int kperm, const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ D) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    Frag<T> a, b;
+    for (int j = 0; j < 8; ++j) {
+        const int k = kperm ? perm_k(g4, j) : 8 * g4 + j;
+        frag_set(a, j, A[l15 * 32 + k]);  // A is 16x32 row-major
+        frag_set(b, j, B[k * 16 + l15]);  // B is 32x16 row-major
+    }
+    f32x4 acc = mma(a, b, F32X4_ZERO);
+    for (int r = 0; r < 4; ++r) D[(g4 * 4 + r) * 16 + l15] = acc[r];
+}
+
+int selftest_mma_impl(int dtype, int kperm, const float* A, const float* B, float* D, hipStream_t stream) {
+    if (dtype == NBSS_BF16)
+        NBSS_LAUNCH((selftest_mma_kernel<bf16_t>), dim3(1), dim3(64), 0, stream, kperm, A, B, D);
+    else
+        NBSS_LAUNCH((selftest_mma_kernel<float>), dim3(1), dim3(64), 0, stream, kperm, A, B, D);
+    return NBSS_CHECK_LAUNCH();
+}

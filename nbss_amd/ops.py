@@ -1,0 +1,110 @@
+"""Tensor-level wrappers of the C ABI (include/nbss_hip.h): torch is used for device memory
+and streams only.  Every function takes the library handle explicitly (`lib`); the product
+passes `nbss_amd._lib.hip()`; tests may pass the host-emulator build to run the same kernel
+sources on CPU tensors.  There is no other code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+
+from ._lib import NBSS_BF16, NBSS_F32, Cfg, Lib, NbssError
+from .params import param_table
+
+
+def _is_emu(lib: Lib) -> bool:
+    if not hasattr(lib, "_is_emu"):
+        lib._is_emu = "emulator" in lib.build_info()
+    return lib._is_emu
+
+
+def stream_dtype(cfg: Cfg) -> torch.dtype:
+    return torch.bfloat16 if cfg.dtype == NBSS_BF16 else torch.float32
+
+
+def _ptr(lib: Lib, t: Optional[Tensor], dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise NbssError("nbss_amd ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise NbssError(f"expected {dtype}, got {t.dtype}")
+    if _is_emu(lib):
+        if t.device.type != "cpu":
+            raise NbssError("the emulator library only takes CPU tensors")
+    elif t.device.type != "cuda":
+        raise NbssError("libnbss_hip.so needs tensors on a HIP device (no CPU fallback exists)")
+    return t.data_ptr()
+
+
+def _stream(lib: Lib, t: Tensor) -> Optional[int]:
+    if _is_emu(lib):
+        return None
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def flatten_params(lib: Lib, cfg: Cfg, p: Dict[str, Tensor], device) -> Tensor:
+    """state_dict-style dict -> flat fp32 buffer in nbss_param_table order."""
+    n = lib.nbss_param_count(C.byref(cfg))
+    if n <= 0:
+        raise NbssError("unsupported configuration")
+    flat = torch.zeros(n, dtype=torch.float32)
+    for name, (off, shape) in param_table(lib, cfg).items():
+        t = p[name]
+        if tuple(t.shape) != tuple(shape):
+            raise NbssError(f"{name}: shape {tuple(t.shape)} != {shape}")
+        flat[off:off + t.numel()] = t.detach().reshape(-1).to(torch.float32).cpu()
+    return flat.to(device)
+
+
+def pack_params(lib: Lib, cfg: Cfg, flat: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    nbytes = lib.nbss_packed_bytes(C.byref(cfg))
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=flat.device)
+    lib.call("nbss_pack_params", C.byref(cfg), _ptr(lib, flat, torch.float32), _ptr(lib, out), _stream(lib, flat))
+    return out
+
+
+def encoder_fwd(lib, cfg, flat, packed, xin):
+    y = torch.empty(cfg.B, cfg.F, cfg.T, cfg.H, dtype=stream_dtype(cfg), device=xin.device)
+    lib.call("nbss_encoder_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), _ptr(lib, xin, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, xin))
+    return y
+
+
+def decoder_fwd(lib, cfg, flat, packed, x):
+    out = torch.empty(cfg.B, cfg.F, cfg.T, cfg.C_out, dtype=torch.float32, device=x.device)
+    lib.call("nbss_decoder_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, out), _stream(lib, x))
+    return out
+
+
+def fconv_fwd(lib, cfg, flat, packed, layer, which, x):
+    y = torch.empty_like(x)
+    lib.call("nbss_fconv_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, which, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
+    return y
+
+
+def full_fwd(lib, cfg, flat, packed, layer, x):
+    y = torch.empty_like(x)
+    lib.call("nbss_full_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
+    return y
+
+
+def mhsa_fwd(lib, cfg, flat, packed, layer, x):
+    y = torch.empty_like(x)
+    lib.call("nbss_mhsa_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
+    return y
+
+
+def tconvffn_fwd(lib, cfg, flat, packed, layer, x):
+    y = torch.empty_like(x)
+    lib.call("nbss_tconvffn_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
+    return y
+
+
+def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:
+    D = torch.empty(16, 16, dtype=torch.float32, device=A.device)
+    lib.call("nbss_selftest_mma", dtype, kperm, _ptr(lib, A, torch.float32), _ptr(lib, B, torch.float32), _ptr(lib, D), _stream(lib, A))
+    return D

@@ -1,0 +1,177 @@
+"""ORACLE — test infrastructure only (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+
+A CPU restatement, in plain functional PyTorch (fp32 or fp64), of the reference's SpatialNet
+forward.  The reference (/root/reference, pure Python on torch.nn) is importable in the build
+container but NOT on the GPU box, so parity is pinned in two steps:
+  1. tests/test_oracle_vs_reference.py checks these functions against the reference's own
+     modules (models.arch.SpatialNet.SpatialNet, models.io.stft.STFT, models.io.norm.Norm)
+     whenever /root/reference exists, and tests/golden/make_golden.py stores outputs of the
+     reference itself as fixtures;
+  2. the HIP kernels are checked against these functions (and the fixtures) everywhere.
+Backward parity uses torch.autograd through these same functions.
+
+Parameters are passed as a dict keyed by the reference's state_dict names
+(`layers.N.fconv1.1.weight`, ...), every function cites the reference lines it restates.
+Nothing under nbss_amd/, models/ or the timed part of bench.py imports this module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as Fn
+from torch import Tensor
+
+
+def layer_norm_h(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """LayerNorm over the last (H) dim, eps=1e-5 (models/arch/base/norm.py:11-27)."""
+    return Fn.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def encoder(x: Tensor, p: Dict[str, Tensor]) -> Tensor:
+    """nn.Conv1d(dim_input, H, k=5, padding='same') along T per (b,f): SpatialNet.py:175,205.
+    x [B,F,T,Cin] -> [B,F,T,H]"""
+    B, F, T, C = x.shape
+    y = Fn.conv1d(x.reshape(B * F, T, C).permute(0, 2, 1), p["encoder.weight"], p["encoder.bias"], padding="same")
+    return y.permute(0, 2, 1).reshape(B, F, T, -1)
+
+
+def fconv(x: Tensor, p: Dict[str, Tensor], pre: str, groups: int = 8) -> Tensor:
+    """x + _fconv: LN(H) -> Conv1d(H,H,k=5,groups=8,'same',zeros) ALONG F -> PReLU(H)
+    (SpatialNet.py:85,87,116-127,36-40,49-53).  pre = 'layers.N.fconv1' | 'layers.N.fconv2'."""
+    B, F, T, H = x.shape
+    u = layer_norm_h(x, p[pre + ".0.weight"], p[pre + ".0.bias"])
+    u = u.permute(0, 2, 3, 1).reshape(B * T, H, F)
+    v = Fn.conv1d(u, p[pre + ".1.weight"], p[pre + ".1.bias"], padding="same", groups=groups)
+    v = Fn.prelu(v, p[pre + ".2.weight"])
+    return x + v.reshape(B, T, H, F).permute(0, 3, 1, 2)
+
+
+def full(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    """x + _full: LN -> Conv1d(H,SQ,1)+SiLU -> LinearGroup over F -> Conv1d(SQ,H,1)+SiLU
+    (SpatialNet.py:86,129-146,42-47; LinearGroup linear_group.py:29-34).  pre = 'layers.N'."""
+    B, F, T, H = x.shape
+    u = layer_norm_h(x, p[pre + ".norm_full.weight"], p[pre + ".norm_full.bias"])
+    u = u.permute(0, 2, 3, 1).reshape(B * T, H, F)
+    s = Fn.silu(Fn.conv1d(u, p[pre + ".squeeze.0.weight"], p[pre + ".squeeze.0.bias"]))  # [B*T,SQ,F]
+    z = torch.einsum("...gh,gkh->...gk", s, p[pre + ".full.weight"]) + p[pre + ".full.bias"]
+    v = Fn.silu(Fn.conv1d(z, p[pre + ".unsqueeze.0.weight"], p[pre + ".unsqueeze.0.bias"]))  # [B*T,H,F]
+    return x + v.reshape(B, T, H, F).permute(0, 3, 1, 2)
+
+
+def mhsa(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int = 4) -> Tensor:
+    """x + _tsa: LN -> nn.MultiheadAttention(H, heads, batch_first) self-attention over T for
+    every (b,f); no mask, no dropout (SpatialNet.py:88,93-100,57-58)."""
+    B, F, T, H = x.shape
+    dh = H // heads
+    u = layer_norm_h(x, p[pre + ".norm_mhsa.weight"], p[pre + ".norm_mhsa.bias"]).reshape(B * F, T, H)
+    qkv = u @ p[pre + ".mhsa.in_proj_weight"].t() + p[pre + ".mhsa.in_proj_bias"]
+    q, k, v = qkv.split(H, dim=-1)
+    q = q.reshape(B * F, T, heads, dh).transpose(1, 2)
+    k = k.reshape(B * F, T, heads, dh).transpose(1, 2)
+    v = v.reshape(B * F, T, heads, dh).transpose(1, 2)
+    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B * F, T, H)
+    o = o @ p[pre + ".mhsa.out_proj.weight"].t() + p[pre + ".mhsa.out_proj.bias"]
+    return x + o.reshape(B, F, T, H)
+
+
+def tconvffn(x: Tensor, p: Dict[str, Tensor], pre: str, groups: int = 8) -> Tensor:
+    """x + _tconvffn (SpatialNet.py:90,102-114,61-73): on [B*F,H,T]:
+    LN(H) -> 1x1 H->FFN -> SiLU -> gconv(k=3) -> SiLU -> gconv -> GroupNorm(groups,FFN) -> SiLU -> gconv -> SiLU -> 1x1 FFN->H."""
+    B, F, T, H = x.shape
+    q = pre + ".tconvffn"
+    u = layer_norm_h(x, p[q + ".0.weight"], p[q + ".0.bias"])
+    h = u.reshape(B * F, T, H).transpose(1, 2)
+    h = Fn.silu(Fn.conv1d(h, p[q + ".1.weight"], p[q + ".1.bias"]))
+    h = Fn.silu(Fn.conv1d(h, p[q + ".3.weight"], p[q + ".3.bias"], padding="same", groups=groups))
+    h = Fn.conv1d(h, p[q + ".5.weight"], p[q + ".5.bias"], padding="same", groups=groups)
+    h = Fn.silu(Fn.group_norm(h, groups, p[q + ".6.weight"], p[q + ".6.bias"], 1e-5))
+    h = Fn.silu(Fn.conv1d(h, p[q + ".8.weight"], p[q + ".8.bias"], padding="same", groups=groups))
+    h = Fn.conv1d(h, p[q + ".10.weight"], p[q + ".10.bias"])
+    return x + h.transpose(1, 2).reshape(B, F, T, H)
+
+
+def decoder(x: Tensor, p: Dict[str, Tensor]) -> Tensor:
+    """nn.Linear(H, dim_output): SpatialNet.py:200,216."""
+    return x @ p["decoder.weight"].t() + p["decoder.bias"]
+
+
+def layer(x: Tensor, p: Dict[str, Tensor], l: int, heads: int = 4) -> Tensor:
+    """SpatialNetLayer.forward: fconv1, full, fconv2, MHSA, T-ConvFFN (SpatialNet.py:76-91)."""
+    pre = f"layers.{l}"
+    x = fconv(x, p, pre + ".fconv1")
+    x = full(x, p, pre)
+    x = fconv(x, p, pre + ".fconv2")
+    x = mhsa(x, p, pre, heads)
+    x = tconvffn(x, p, pre)
+    return x
+
+
+def spatialnet(x: Tensor, p: Dict[str, Tensor], num_layers: int, heads: int = 4) -> Tensor:
+    """SpatialNet.forward (SpatialNet.py:202-220): [B,F,T,2C] -> [B,F,T,2*Spk]."""
+    h = encoder(x, p)
+    for l in range(num_layers):
+        h = layer(h, p, l, heads)
+    return decoder(h, p)
+
+
+# ---------------------------------------------------------------------------------------------
+def init_params(num_layers: int = 8, num_freqs: int = 129, dim_input: int = 12, dim_output: int = 4, dim_hidden: int = 96,
+                dim_ffn: int = 192, dim_squeeze: int = 8, full_share: int = 0, seed: int = 0, scale: float = 1.0,
+                dtype=torch.float32) -> Dict[str, Tensor]:
+    """Random parameters with the reference's names/shapes; NOT the reference's
+    init distribution — plain scaled normals, plus non-trivial LN/GN/PReLU values so that every
+    affine term is exercised.  Shared `full` tensors are the same object under each layer key."""
+    g = torch.Generator().manual_seed(seed)
+    H, FFN, SQ, F = dim_hidden, dim_ffn, dim_squeeze, num_freqs
+
+    def rn(*shape, fan_in=None):
+        t = torch.randn(*shape, generator=g, dtype=torch.float64)
+        if fan_in:
+            t = t * (scale / math.sqrt(fan_in))
+        return t.to(dtype)
+
+    def affine(n):
+        return (1.0 + 0.2 * torch.randn(n, generator=g, dtype=torch.float64)).to(dtype), (0.1 * torch.randn(n, generator=g, dtype=torch.float64)).to(dtype)
+
+    p: Dict[str, Tensor] = {}
+    p["encoder.weight"] = rn(H, dim_input, 5, fan_in=dim_input * 5)
+    p["encoder.bias"] = rn(H) * 0.1
+    for l in range(num_layers):
+        pre = f"layers.{l}"
+        for fc in ("fconv1", "fconv2"):
+            p[f"{pre}.{fc}.0.weight"], p[f"{pre}.{fc}.0.bias"] = affine(H)
+            p[f"{pre}.{fc}.1.weight"] = rn(H, H // 8, 5, fan_in=H // 8 * 5)
+            p[f"{pre}.{fc}.1.bias"] = rn(H) * 0.1
+            p[f"{pre}.{fc}.2.weight"] = (0.25 + 0.1 * torch.randn(H, generator=g, dtype=torch.float64)).to(dtype)
+        p[f"{pre}.norm_full.weight"], p[f"{pre}.norm_full.bias"] = affine(H)
+        p[f"{pre}.squeeze.0.weight"] = rn(SQ, H, 1, fan_in=H)
+        p[f"{pre}.squeeze.0.bias"] = rn(SQ) * 0.1
+        if l <= full_share:
+            p[f"{pre}.full.weight"] = rn(SQ, F, F, fan_in=F)
+            p[f"{pre}.full.bias"] = rn(SQ, F) * 0.1
+        else:
+            p[f"{pre}.full.weight"] = p[f"layers.{full_share}.full.weight"]
+            p[f"{pre}.full.bias"] = p[f"layers.{full_share}.full.bias"]
+        p[f"{pre}.unsqueeze.0.weight"] = rn(H, SQ, 1, fan_in=SQ)
+        p[f"{pre}.unsqueeze.0.bias"] = rn(H) * 0.1
+        p[f"{pre}.norm_mhsa.weight"], p[f"{pre}.norm_mhsa.bias"] = affine(H)
+        p[f"{pre}.mhsa.in_proj_weight"] = rn(3 * H, H, fan_in=H)
+        p[f"{pre}.mhsa.in_proj_bias"] = rn(3 * H) * 0.1
+        p[f"{pre}.mhsa.out_proj.weight"] = rn(H, H, fan_in=H)
+        p[f"{pre}.mhsa.out_proj.bias"] = rn(H) * 0.1
+        q = f"{pre}.tconvffn"
+        p[q + ".0.weight"], p[q + ".0.bias"] = affine(H)
+        p[q + ".1.weight"] = rn(FFN, H, 1, fan_in=H)
+        p[q + ".1.bias"] = rn(FFN) * 0.1
+        for i in (3, 5, 8):
+            p[f"{q}.{i}.weight"] = rn(FFN, FFN // 8, 3, fan_in=FFN // 8 * 3)
+            p[f"{q}.{i}.bias"] = rn(FFN) * 0.1
+        p[q + ".6.weight"], p[q + ".6.bias"] = affine(FFN)
+        p[q + ".10.weight"] = rn(H, FFN, 1, fan_in=FFN)
+        p[q + ".10.bias"] = rn(H) * 0.1
+    p["decoder.weight"] = rn(dim_output, H, fan_in=H)
+    p["decoder.bias"] = rn(dim_output) * 0.1
+    return p

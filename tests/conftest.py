@@ -1,0 +1,59 @@
+"""pytest configuration: `gpu` marker, backends.
+
+Two backends run the SAME kernel sources through the SAME C ABI:
+  * "emu" — host-emulator build (tests/hipemu), CPU tensors, no GPU needed;  -m "not gpu"
+  * "hip" — libnbss_hip.so on a real MI355X;                                   -m gpu
+"""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+REFERENCE = Path("/root/reference")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running emulator case")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    from nbss_amd.build import build_emu
+    from nbss_amd._lib import Lib
+    return Lib(build_emu())
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from nbss_amd._lib import hip
+    return hip()
+
+
+class Backend:
+    def __init__(self, name, lib, device):
+        self.name, self.lib, self.device = name, lib, device
+
+
+def _backend_params():
+    return [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=_backend_params())
+def backend(request):
+    if request.param == "emu":
+        return Backend("emu", request.getfixturevalue("emu_lib"), torch.device("cpu"))
+    return Backend("hip", request.getfixturevalue("hip_lib"), torch.device("cuda:0"))
+
+
+@pytest.fixture(scope="session")
+def reference_available():
+    return (REFERENCE / "models" / "arch" / "SpatialNet.py").exists()

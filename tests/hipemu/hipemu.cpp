@@ -1,0 +1,173 @@
+// hipemu runtime: fiber scheduler.  TEST INFRASTRUCTURE ONLY (see hipemu.h).
+#include "hipemu.h"
+
+#include <algorithm>
+#include <random>
+#include <thread>
+
+namespace hipemu {
+
+thread_local Block* g_block = nullptr;
+thread_local Fiber* g_fiber = nullptr;
+
+static const size_t kStackBytes = 256 * 1024;
+
+void yield_to_sched() {
+    Fiber* f = g_fiber;
+    swapcontext(&f->ctx, &g_block->sched);
+}
+
+void block_barrier() {
+    Block* b = g_block;
+    Fiber* f = g_fiber;
+    unsigned long gen = b->bar_gen;
+    if (++b->bar_arrived >= b->alive) {
+        b->bar_arrived = 0;
+        b->bar_gen++;
+        return;
+    }
+    f->wait = 1;
+    f->wait_gen = gen;
+    yield_to_sched();
+}
+
+void wave_sync() {
+    Block* b = g_block;
+    Fiber* f = g_fiber;
+    Wave& w = b->waves[f->wave];
+    unsigned long gen = w.gen;
+    if (++w.arrived >= w.alive) {
+        w.arrived = 0;
+        w.gen++;
+        return;
+    }
+    f->wait = 2;
+    f->wait_gen = gen;
+    yield_to_sched();
+}
+
+static void fiber_main() {
+    Block* b = g_block;
+    Fiber* f = g_fiber;
+    b->entry(b->entry_arg);
+    f->done = true;
+    // exited threads no longer take part in barriers / collectives
+    b->alive--;
+    Wave& w = b->waves[f->wave];
+    w.alive--;
+    if (b->alive > 0 && b->bar_arrived >= b->alive && b->bar_arrived > 0) {
+        b->bar_arrived = 0;
+        b->bar_gen++;
+    }
+    if (w.alive > 0 && w.arrived >= w.alive && w.arrived > 0) {
+        w.arrived = 0;
+        w.gen++;
+    }
+    swapcontext(&f->ctx, &b->sched);
+}
+
+struct Worker {
+    std::vector<char*> stacks;
+    std::vector<char> lds;
+    ~Worker() {
+        for (char* s : stacks) free(s);
+    }
+};
+
+static int order_mode() {
+    static int mode = [] {
+        const char* e = getenv("HIPEMU_ORDER");
+        if (!e) return 0;
+        if (!strcmp(e, "rev")) return 1;
+        if (!strcmp(e, "rand")) return 2;
+        return 0;
+    }();
+    return mode;
+}
+
+static void run_block(Worker& wk, dim3 bid, dim3 grid, dim3 bdim, size_t lds_bytes, void (*entry)(void*), void* arg) {
+    int nthreads = (int)(bdim.x * bdim.y * bdim.z);
+    int nwaves = (nthreads + 63) / 64;
+    Block blk;
+    blk.bid = bid;
+    blk.bdim = bdim;
+    blk.gdim = grid;
+    blk.fibers.resize(nthreads);
+    blk.waves.resize(nwaves);
+    blk.alive = nthreads;
+    blk.entry = entry;
+    blk.entry_arg = arg;
+    if (wk.lds.size() < lds_bytes + 64) wk.lds.resize(lds_bytes + 64);
+    // poison LDS so that reads of never-written LDS are visible as NaNs / garbage
+    memset(wk.lds.data(), 0xFF, wk.lds.size());
+    uintptr_t base = (reinterpret_cast<uintptr_t>(wk.lds.data()) + 15) & ~uintptr_t(15);
+    blk.lds = reinterpret_cast<char*>(base);
+    blk.lds_bytes = lds_bytes;
+    while ((int)wk.stacks.size() < nthreads) wk.stacks.push_back((char*)malloc(kStackBytes));
+    g_block = &blk;
+    for (int i = 0; i < nthreads; ++i) {
+        Fiber& f = blk.fibers[i];
+        f.linear = i;
+        f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
+        f.lane = i & 63;
+        f.wave = i >> 6;
+        blk.waves[f.wave].alive++;
+        f.stack = wk.stacks[i];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStackBytes;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+    }
+    std::vector<int> order(nthreads);
+    for (int i = 0; i < nthreads; ++i) order[i] = i;
+    int mode = order_mode();
+    if (mode == 1) std::reverse(order.begin(), order.end());
+    std::mt19937 rng(1234 + bid.x * 7919 + bid.y * 104729);
+    int remaining = nthreads;
+    while (remaining > 0) {
+        if (mode == 2) std::shuffle(order.begin(), order.end(), rng);
+        bool progress = false;
+        for (int idx : order) {
+            Fiber& f = blk.fibers[idx];
+            if (f.done) continue;
+            if (f.wait == 1 && blk.bar_gen == f.wait_gen) continue;
+            if (f.wait == 2 && blk.waves[f.wave].gen == f.wait_gen) continue;
+            f.wait = 0;
+            progress = true;
+            g_fiber = &f;
+            swapcontext(&blk.sched, &f.ctx);
+            if (f.done) remaining--;
+        }
+        if (!progress) {
+            fprintf(stderr, "hipemu: DEADLOCK in block (%u,%u,%u): %d threads stuck (divergent barrier / collective?)\n", bid.x, bid.y,
+                    bid.z, remaining);
+            abort();
+        }
+    }
+    g_block = nullptr;
+    g_fiber = nullptr;
+}
+
+void run_grid(dim3 grid, dim3 block, size_t lds_bytes, void (*entry)(void*), void* arg) {
+    size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    int nthr = 8;
+    if (const char* e = getenv("HIPEMU_THREADS")) nthr = std::max(1, atoi(e));
+    nthr = (int)std::min<size_t>(nthr, nblocks);
+    auto work = [&](int w) {
+        Worker wk;
+        for (size_t b = w; b < nblocks; b += nthr) {
+            dim3 bid((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y)));
+            run_block(wk, bid, grid, block, lds_bytes, entry, arg);
+        }
+    };
+    if (nthr <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> ts;
+    for (int w = 0; w < nthr; ++w) ts.emplace_back(work, w);
+    for (auto& t : ts) t.join();
+}
+
+}  // namespace hipemu
