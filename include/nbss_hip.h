@@ -78,10 +78,24 @@ int nbss_decoder_fwd(const nbss_cfg* cfg, const float* params, const void* packe
 int nbss_fconv_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, int which, const void* x, void* y, void* stream);
 /* x + _full: LN -> squeeze+SiLU -> LinearGroup over F -> unsqueeze+SiLU (SpatialNet.py:86,129-146). */
 int nbss_full_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
-/* x + _tsa: LN -> nn.MultiheadAttention over T per (b,f) (SpatialNet.py:88,93-100). */
-int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
+/* x + _tsa: LN -> nn.MultiheadAttention over T per (b,f) (SpatialNet.py:88,93-100).
+ * o_save (optional, [B,F,T,H] of cfg->dtype): attention output before out_proj, kept for backward. */
+int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* o_save, void* stream);
 /* x + _tconvffn (SpatialNet.py:90,102-114,61-73). */
 int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
+
+/* ---- SpatialNet sub-blocks, backward (autograd of the forward entry points) ------------------
+ * x: the forward INPUT of the block (the only saved activation; everything else is recomputed
+ * on chip), dy: gradient w.r.t. the block output, dx: gradient w.r.t. x (may not alias dy).
+ * Parameter gradients are ACCUMULATED (+=) into `grads`, a flat fp32 buffer with the layout of
+ * `params`; zero it at the start of a step.  `ws` is caller-provided scratch of at least
+ * nbss_workspace_bytes(cfg) bytes (per-token LayerNorm statistics and the operands of the
+ * weight-gradient contractions). */
+int64_t nbss_workspace_bytes(const nbss_cfg* cfg);
+int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
+                      void* dx, void* ws, void* stream);
+int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
+                  const void* o_save, void* dx, void* ws, void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use

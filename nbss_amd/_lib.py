@@ -48,8 +48,11 @@ SIGNATURES = {
     "nbss_decoder_fwd": (_I, [_CP, _P, _P, _P, _P, _P]),
     "nbss_fconv_fwd": (_I, [_CP, _P, _P, _I, _I, _P, _P, _P]),
     "nbss_full_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
-    "nbss_mhsa_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
+    "nbss_mhsa_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P, _P]),
     "nbss_tconvffn_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
+    "nbss_workspace_bytes": (C.c_int64, [_CP]),
+    "nbss_tconvffn_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "nbss_mhsa_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),
     "nbss_build_info": (C.c_char_p, []),
 }

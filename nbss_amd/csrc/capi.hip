@@ -9,8 +9,13 @@ int encoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, cons
 int decoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st);
 int fconv_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st);
 int full_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
-int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
+int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st);
+int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
+                  void* dx, void* ws, hipStream_t st);
 int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
+
+int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                      void* ws, hipStream_t st);
 
 #define CHECK_CFG(cfg)                         \
     if (!(cfg)) return NBSS_EINVAL;            \
@@ -84,11 +89,19 @@ int nbss_full_fwd(const nbss_cfg* cfg, const float* params, const void* packed, 
     return full_fwd_impl(*cfg, params, packed, layer, x, y, (hipStream_t)stream);
 }
 
-int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream) {
+int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* o_save, void* stream) {
     CHECK_CFG(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !packed || !x || !y || x == y) return NBSS_EINVAL;
-    return mhsa_fwd_impl(*cfg, params, packed, layer, x, y, (hipStream_t)stream);
+    return mhsa_fwd_impl(*cfg, params, packed, layer, x, y, o_save, (hipStream_t)stream);
+}
+
+int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
+                  const void* o_save, void* dx, void* ws, void* stream) {
+    CHECK_CFG(cfg);
+    CHECK_LAYER(cfg, layer);
+    if (!params || !grads || !packed || !x || !dy || !o_save || !dx || !ws) return NBSS_EINVAL;
+    return mhsa_bwd_impl(*cfg, params, grads, packed, layer, x, dy, o_save, dx, ws, (hipStream_t)stream);
 }
 
 int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream) {
@@ -96,6 +109,19 @@ int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* pack
     CHECK_LAYER(cfg, layer);
     if (!params || !packed || !x || !y || x == y) return NBSS_EINVAL;
     return tconvffn_fwd_impl(*cfg, params, packed, layer, x, y, (hipStream_t)stream);
+}
+
+int64_t nbss_workspace_bytes(const nbss_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
+    return (int64_t)workspace_bytes(*cfg);
+}
+
+int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
+                      void* dx, void* ws, void* stream) {
+    CHECK_CFG(cfg);
+    CHECK_LAYER(cfg, layer);
+    if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
+    return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

@@ -91,6 +91,17 @@ enum PackKind {
     K_TF_W1,     // 1x1 H->FFN, rows = groups x (cg + pad to 32), natural K
     K_TF_C1, K_TF_C2, K_TF_C3,  // t-conv, per group: rows = cg (+pad), K = (tap, 4-ch piece)
     K_TF_W2,     // 1x1 FFN->H, K = groups x 32 permuted
+    // backward (data-gradient) operands: transposed weights
+    K_DEC_T,     // dx = W^T dout: rows = H, K = C_out natural
+    K_FC1_T, K_FC2_T,  // f-conv^T per group: rows = 12(+4) in ch, K = (flipped tap, 4-out-ch piece)
+    K_SQ_T,      // du = Ws^T ds: rows = H, K = SQ natural
+    K_FULL_T,    // per squeeze channel: rows = h (in freq), K = k natural
+    K_USQ_T,     // dz = Wu^T dy: rows = SQ (+pad), K = H permuted
+    K_INP_T,     // du = Win^T dqkv: rows = H, K = [q|k|v] x heads x 32 permuted
+    K_OUTP_T,    // dO = Wo^T dy: rows = heads x (dh + pad to 32), K = H natural
+    K_TF_W1_T,   // du = W1^T da1: rows = H, K = groups x 32 permuted
+    K_TF_C1_T, K_TF_C2_T, K_TF_C3_T,  // t-conv^T per group: rows = cg in ch, K = (flipped tap, 4-out-ch piece)
+    K_TF_W2_T,   // dh5 = W2^T dy: rows = groups x (cg + pad to 32), K = H natural
     NUM_PACK_KINDS
 };
 
@@ -115,6 +126,16 @@ NBSS_HD PackGeom pack_geom(const nbss_cfg& c, int kind) {
         case K_TF_W1: g.MT = c.t_groups * cdiv(cg, 32) * 2; g.KS = c.H / 32; break;
         case K_TF_C1: case K_TF_C2: case K_TF_C3: g.MT = cdiv(cg, 32) * 2; g.KS = cdiv(c.t_ks * (cg / 4), 8); g.NB = c.t_groups; break;
         case K_TF_W2: g.MT = c.H / 16; g.KS = c.t_groups * cdiv(cg, 32); break;
+        case K_DEC_T: g.MT = c.H / 16; g.KS = cdiv(c.C_out, 32); break;
+        case K_FC1_T: case K_FC2_T: g.MT = cdiv(fg, 16); g.KS = cdiv(c.f_ks * (fg / 4), 8); g.NB = c.f_groups; break;
+        case K_SQ_T: g.MT = c.H / 16; g.KS = cdiv(c.SQ, 32); break;
+        case K_FULL_T: g.MT = cdiv(c.F, 16); g.KS = cdiv(c.F, 32); g.NB = c.SQ; break;
+        case K_USQ_T: g.MT = cdiv(c.SQ, 16); g.KS = c.H / 32; break;
+        case K_INP_T: g.MT = c.H / 16; g.KS = 3 * c.heads * cdiv(dh, 32); break;
+        case K_OUTP_T: g.MT = c.heads * cdiv(dh, 32) * 2; g.KS = c.H / 32; break;
+        case K_TF_W1_T: g.MT = c.H / 16; g.KS = c.t_groups * cdiv(cg, 32); break;
+        case K_TF_C1_T: case K_TF_C2_T: case K_TF_C3_T: g.MT = cdiv(cg, 32) * 2; g.KS = cdiv(c.t_ks * (cg / 4), 8); g.NB = c.t_groups; break;
+        case K_TF_W2_T: g.MT = c.t_groups * cdiv(cg, 32) * 2; g.KS = c.H / 32; break;
     }
     return g;
 }
@@ -122,7 +143,7 @@ NBSS_HD int64_t pack_numel(const nbss_cfg& c, int kind) {
     PackGeom g = pack_geom(c, kind);
     return (int64_t)g.NB * g.MT * g.KS * 512;
 }
-NBSS_HD bool pack_is_global(int kind) { return kind == K_ENC || kind == K_DEC; }
+NBSS_HD bool pack_is_global(int kind) { return kind == K_ENC || kind == K_DEC || kind == K_DEC_T; }
 // offset (in elements) of entry `kind` for `layer` inside the packed buffer
 NBSS_HD int64_t pack_layer_numel(const nbss_cfg& c) {
     int64_t s = 0;
@@ -133,13 +154,21 @@ NBSS_HD int64_t pack_layer_numel(const nbss_cfg& c) {
 NBSS_HD int64_t pack_off(const nbss_cfg& c, int layer, int kind) {
     if (kind == K_ENC) return 0;
     if (kind == K_DEC) return pack_numel(c, K_ENC);
-    int64_t o = pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + (int64_t)layer * pack_layer_numel(c);
+    if (kind == K_DEC_T) return pack_numel(c, K_ENC) + pack_numel(c, K_DEC);
+    int64_t o = pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + pack_numel(c, K_DEC_T) + (int64_t)layer * pack_layer_numel(c);
     for (int k = 0; k < kind; ++k)
         if (!pack_is_global(k)) o += pack_numel(c, k);
     return o;
 }
 NBSS_HD int64_t pack_total(const nbss_cfg& c) {
-    return pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + (int64_t)c.L * pack_layer_numel(c);
+    return pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + pack_numel(c, K_DEC_T) + (int64_t)c.L * pack_layer_numel(c);
+}
+
+// backward workspace (caller-provided): per-token LN statistics + the widest set of wgrad operands
+NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
+NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
+    const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + 256;
 }
 
 NBSS_HD int check_cfg(const nbss_cfg& c) {

@@ -60,7 +60,7 @@ template <class T, int HPP>
 __global__ __launch_bounds__(256) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
-                                                       const T* __restrict__ x, T* __restrict__ y) {
+                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave) {
     NBSS_LDS(smem);
     T* Ks = reinterpret_cast<T*>(smem);              // [HPP][TP][DH]
     T* Vt = Ks + HPP * MH_TP * MH_DH;                // [HPP][DH][TP]
@@ -218,6 +218,14 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                     o1[r] *= inv;
                 }
                 frag_from_c2(of[si][hh], o0, o1);
+                if (osave) {  // attention output before out_proj: the only extra activation backward needs
+                    const int t = (w * MH_NSW + si) * 16 + l15;
+                    if (t < T_) {
+                        T* orow = osave + ((size_t)bf * T_ + t) * MH_H + (pass * HPP + hh) * MH_DH;
+                        store4(orow + 4 * g4, o0[0], o0[1], o0[2], o0[3]);
+                        if (g4 < 2) store4(orow + 16 + 4 * g4, o1[0], o1[1], o1[2], o1[3]);
+                    }
+                }
             }
         }
 
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(nbss_cfg c, const float* 
 }
 
 template <class T, int HPP>
-static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
     if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
     const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T);
     const T* pk = (const T*)packed;
@@ -260,10 +268,10 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     dim3 grid(c.B * c.F), block(256);
     NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
-                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y);
+                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave);
     return NBSS_CHECK_LAUNCH();
 }
 
-int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? mhsa_fwd_t<bf16_t, 4>(c, P, packed, layer, x, y, st) : mhsa_fwd_t<float, 2>(c, P, packed, layer, x, y, st);
+int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
+    return c.dtype == NBSS_BF16 ? mhsa_fwd_t<bf16_t, 4>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<float, 2>(c, P, packed, layer, x, y, osave, st);
 }

@@ -1,0 +1,394 @@
+// mhsa_bwd.hip — data gradient of the narrow-band self-attention module (forward: mhsa.hip).
+//
+// One workgroup (8 waves, two 16-frame strips each) = one (b,f) sequence, one head at a time.
+// Recomputed per head: Q' = q * log2(e)/sqrt(dh), K, V (from LN(x)) and dO = Wo_h^T dy.  LDS holds
+// Q', K, V, dO row-major [T][24] and Q', K, dO transposed [24][T]; nothing else is staged.
+//   pass 1 (wave owns QUERY strips):  S^T = K Q'^T, P, D = rowsum(dO * O), dS^T = P (dP^T - D),
+//                                     dQ^T = K^T dS^T              (O = saved forward attention output)
+//   pass 2 (wave owns KEY strips):    S = Q' K^T, P = exp2(S - m)/l from the stored row statistics,
+//                                     dS = P (dP - D),  dV^T += dO^T P,  dK^T += Q'^T dS
+// Both passes keep their S / dS tiles in the C layout that is directly the next MFMA's B operand
+// (permuted K order), so there is no register transpose and no atomics.  dQ/dK/dV tiles go (a) to
+// global [N][3H] for the in_proj weight gradient (wgrad.hip) and (b) straight into
+// du += Win^T dqkv, followed by the in-register LayerNorm backward.
+#include "launch.h"
+#include "layout.h"
+#include "blocks.h"
+#include "wgrad.h"
+
+#define MB_H 96
+#define MB_HEADS 4
+#define MB_DH 24
+#define MB_NT 16
+#define MB_NSW 2
+#define MB_KS 3
+
+template <class T>
+NBSS_DEV void row_pieces(Frag<T>& f, const T* __restrict__ row) {  // [.. 24] row -> permuted-K fragment (d = 4g+j | 16+4g+j)
+    const int g4 = lane_id() >> 4;
+    frag_load_lo(f, row + 4 * g4);
+    if (g4 < 2) frag_load_hi(f, row + 16 + 4 * g4);
+    else frag_zero_hi(f);
+}
+
+template <class T>
+NBSS_DEV void store_row24(T* __restrict__ row, const f32x4& lo, const f32x4& hi) {
+    const int g4 = lane_id() >> 4;
+    store4(row + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
+    if (g4 < 2) store4(row + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
+}
+
+template <class T>
+NBSS_DEV void store_col24(T* __restrict__ base, int tp, int t, const f32x4& lo, const f32x4& hi) {  // transposed [24][tp]
+    const int g4 = lane_id() >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        store1(base + (size_t)(4 * g4 + r) * tp + t, lo[r]);
+        if (g4 < 2) store1(base + (size_t)(16 + 4 * g4 + r) * tp + t, hi[r]);
+    }
+}
+
+// A fragment of a transposed [24][tp] array: rows d = half*16 + l15, K = 32 frames of k-step ks (permuted order)
+template <class T>
+NBSS_DEV void col_frag(Frag<T>& f, const T* __restrict__ base, int tp, int half, int ks, bool hi_valid) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int d = half * 16 + l15;
+    if (d < MB_DH) {
+        const T* p = base + (size_t)d * tp + ks * 32 + 4 * g4;
+        frag_load_lo(f, p);
+        if (hi_valid) frag_load_hi(f, p + 16);
+        else frag_zero_hi(f);
+    } else {
+        frag_zero(f);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, const float* __restrict__ P, float* __restrict__ G, int layer,
+                                                       const T* __restrict__ Win, const T* __restrict__ WinT, const T* __restrict__ WoutT,
+                                                       const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ osave,
+                                                       T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dqkv) {
+    NBSS_LDS(smem);
+    const int T_ = c.T, nst = cdiv(T_, 16), tp = nst * 16, nkp = cdiv(nst, 2);
+    T* Qr = reinterpret_cast<T*>(smem);
+    T* Kr = Qr + (size_t)tp * MB_DH;
+    T* Vr = Kr + (size_t)tp * MB_DH;
+    T* dOr = Vr + (size_t)tp * MB_DH;
+    T* Qt = dOr + (size_t)tp * MB_DH;
+    T* Kt = Qt + (size_t)tp * MB_DH;
+    T* dOt = Kt + (size_t)tp * MB_DH;
+    float* m2s = reinterpret_cast<float*>(dOt + (size_t)tp * MB_DH);
+    float* lis = m2s + tp;
+    float* Dds = lis + tp;
+    const int bf = blockIdx.x;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)bf * T_;
+    const T* xb = x + n0 * MB_H;
+    const T* dyb = dy + n0 * MB_H;
+    const T* ob = osave + n0 * MB_H;
+    const float* bin = P + param_off(c, layer, P_INP_B);
+    const float rs_dh = rsqrtf((float)MB_DH);
+    const float qscale = 1.4426950408889634f * rs_dh;
+
+    int tt[MB_NSW];
+    bool tv[MB_NSW], sact[MB_NSW];
+#pragma unroll
+    for (int si = 0; si < MB_NSW; ++si) {
+        tt[si] = (w * MB_NSW + si) * 16 + l15;
+        tv[si] = tt[si] < T_;
+        sact[si] = (w * MB_NSW + si) < nst;  // wave-uniform
+    }
+
+    Frag<T> u[MB_NSW][MB_KS], dyf[MB_NSW][MB_KS];
+    {
+        float gam[BK_KS][8], bet[BK_KS][8];
+        load_ln_affine(P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B), gam, bet);
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+            ln_strip96<T>(xb + (size_t)tt[si] * MB_H, tv[si], gam, bet, u[si]);
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                if (tv[si]) frag_load(dyf[si][ks], dyb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
+                else frag_zero(dyf[si][ks]);
+            }
+        }
+    }
+    f32x4 du[MB_NSW][BK_MT];
+#pragma unroll
+    for (int si = 0; si < MB_NSW; ++si)
+#pragma unroll
+        for (int mt = 0; mt < BK_MT; ++mt) du[si][mt] = F32X4_ZERO;
+
+    for (int head = 0; head < MB_HEADS; ++head) {
+        Frag<T> qf[MB_NSW], dof[MB_NSW];
+        float Dv[MB_NSW];
+        // ---------------- stage A: Q', K, V, dO of this head ----------------
+#pragma unroll
+        for (int which = 0; which < 4; ++which) {  // 0 q, 1 k, 2 v, 3 dO
+            f32x4 ct[MB_NSW][2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                Frag<T> a[MB_KS];
+#pragma unroll
+                for (int ks = 0; ks < MB_KS; ++ks) {
+                    if (which < 3) wfrag_load(a[ks], Win, (which * MB_HEADS + head) * 2 + half, MB_KS, ks);
+                    else wfrag_load(a[ks], WoutT, head * 2 + half, MB_KS, ks);
+                }
+#pragma unroll
+                for (int si = 0; si < MB_NSW; ++si) {
+                    f32x4 acc = F32X4_ZERO;
+                    if (sact[si]) {
+#pragma unroll
+                        for (int ks = 0; ks < MB_KS; ++ks) acc = mma(a[ks], which < 3 ? u[si][ks] : dyf[si][ks], acc);
+                    }
+                    ct[si][half] = acc;
+                }
+            }
+            float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (which < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    b0[r] = bin[which * MB_H + head * MB_DH + 4 * g4 + r];
+                    b1[r] = (16 + 4 * g4 + r < MB_DH) ? bin[which * MB_H + head * MB_DH + 16 + 4 * g4 + r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int si = 0; si < MB_NSW; ++si) {
+                if (!sact[si]) continue;
+                const int t = tt[si];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ct[si][0][r] += b0[r];
+                    ct[si][1][r] += b1[r];
+                    if (which == 0) {
+                        ct[si][0][r] *= qscale;
+                        ct[si][1][r] *= qscale;
+                    }
+                }
+                if (which == 0) {
+                    frag_from_c2(qf[si], ct[si][0], ct[si][1]);
+                    store_row24<T>(Qr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
+                    store_col24<T>(Qt, tp, t, ct[si][0], ct[si][1]);
+                } else if (which == 1) {
+                    store_row24<T>(Kr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
+                    store_col24<T>(Kt, tp, t, ct[si][0], ct[si][1]);
+                } else if (which == 2) {
+                    store_row24<T>(Vr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
+                } else {
+                    frag_from_c2(dof[si], ct[si][0], ct[si][1]);
+                    store_row24<T>(dOr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
+                    store_col24<T>(dOt, tp, t, ct[si][0], ct[si][1]);
+                    // D = rowsum(dO * O) with the saved forward attention output
+                    float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (tv[si]) {
+                        load4(ob + (size_t)t * MB_H + head * MB_DH + 4 * g4, o0);
+                        if (g4 < 2) load4(ob + (size_t)t * MB_H + head * MB_DH + 16 + 4 * g4, o1);
+                    }
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dsum += round_to(ct[si][0][r], x) * o0[r] + round_to(ct[si][1][r], x) * o1[r];
+                    Dv[si] = wave_sum16(dsum);
+                    if (g4 == 0) Dds[t] = Dv[si];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---------------- pass 1: query strips -> dQ ----------------
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+            if (!sact[si]) continue;
+            f32x4 sc[MB_NT];
+            float mx = -1e30f;
+#pragma unroll
+            for (int j = 0; j < MB_NT; ++j) {
+                if (j < nst) {
+                    Frag<T> a;
+                    row_pieces<T>(a, Kr + (size_t)(j * 16 + l15) * MB_DH);
+                    sc[j] = mma(a, qf[si], F32X4_ZERO);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
+                        mx = fmaxf(mx, sc[j][r]);
+                    }
+                } else {
+                    sc[j] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
+                }
+            }
+            mx = wave_max16(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < MB_NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (j < nst) ? exp2f(sc[j][r] - mx) : 0.f;
+                    sc[j][r] = p;
+                    sum += p;
+                }
+            sum = wave_sum16(sum);
+            const float inv = 1.0f / sum;
+            if (g4 == 0) {
+                m2s[tt[si]] = mx;
+                lis[tt[si]] = inv;
+            }
+#pragma unroll
+            for (int j = 0; j < MB_NT; ++j) {
+                if (j < nst) {
+                    Frag<T> a;
+                    row_pieces<T>(a, Vr + (size_t)(j * 16 + l15) * MB_DH);
+                    const f32x4 dp = mma(a, dof[si], F32X4_ZERO);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[j][r] = sc[j][r] * inv * (dp[r] - Dv[si]);  // dS^T (natural-log domain)
+                } else {
+                    sc[j] = F32X4_ZERO;
+                }
+            }
+            f32x4 dq[2] = {F32X4_ZERO, F32X4_ZERO};
+#pragma unroll
+            for (int ks = 0; ks < MB_NT / 2; ++ks) {
+                if (ks < nkp) {
+                    Frag<T> dsf;
+                    frag_from_c2(dsf, sc[2 * ks], sc[2 * ks + 1]);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        Frag<T> a;
+                        col_frag<T>(a, Kt, tp, half, ks, 2 * ks + 1 < nst);
+                        dq[half] = mma(a, dsf, dq[half]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dq[0][r] *= rs_dh;
+                dq[1][r] *= rs_dh;
+            }
+            if (tv[si]) store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + head * MB_DH, dq[0], dq[1]);
+            Frag<T> dqf;
+            frag_from_c2(dqf, dq[0], dq[1]);
+#pragma unroll
+            for (int mt = 0; mt < BK_MT; ++mt) {
+                Frag<T> a;
+                wfrag_load(a, WinT, mt, 3 * MB_HEADS, head);
+                du[si][mt] = mma(a, dqf, du[si][mt]);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- pass 2: key strips -> dK, dV ----------------
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+            if (!sact[si]) continue;
+            Frag<T> kf, vf;
+            row_pieces<T>(kf, Kr + (size_t)tt[si] * MB_DH);
+            row_pieces<T>(vf, Vr + (size_t)tt[si] * MB_DH);
+            f32x4 dk[2] = {F32X4_ZERO, F32X4_ZERO}, dv[2] = {F32X4_ZERO, F32X4_ZERO};
+            for (int jp = 0; jp < nkp; ++jp) {
+                f32x4 pt[2], dst[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int jj = 2 * jp + e;
+                    if (jj < nst) {
+                        Frag<T> qa, doa;
+                        row_pieces<T>(qa, Qr + (size_t)(jj * 16 + l15) * MB_DH);
+                        row_pieces<T>(doa, dOr + (size_t)(jj * 16 + l15) * MB_DH);
+                        const f32x4 s = mma(qa, kf, F32X4_ZERO);
+                        const f32x4 dp = mma(doa, vf, F32X4_ZERO);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int tq = jj * 16 + 4 * g4 + r;
+                            const float p = (tq < T_ && tv[si]) ? exp2f(s[r] - m2s[tq]) * lis[tq] : 0.f;
+                            pt[e][r] = p;
+                            dst[e][r] = p * (dp[r] - Dds[tq]);
+                        }
+                    } else {
+                        pt[e] = F32X4_ZERO;
+                        dst[e] = F32X4_ZERO;
+                    }
+                }
+                Frag<T> pf, dsf;
+                frag_from_c2(pf, pt[0], pt[1]);
+                frag_from_c2(dsf, dst[0], dst[1]);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    Frag<T> a;
+                    col_frag<T>(a, dOt, tp, half, jp, 2 * jp + 1 < nst);
+                    dv[half] = mma(a, pf, dv[half]);
+                    col_frag<T>(a, Qt, tp, half, jp, 2 * jp + 1 < nst);
+                    dk[half] = mma(a, dsf, dk[half]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dk[0][r] *= 0.6931471805599453f;  // Q' carries log2(e)/sqrt(dh): dk = dS^T q / sqrt(dh) = dS^T Q' ln2
+                dk[1][r] *= 0.6931471805599453f;
+            }
+            if (tv[si]) {
+                store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + MB_H + head * MB_DH, dk[0], dk[1]);
+                store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + 2 * MB_H + head * MB_DH, dv[0], dv[1]);
+            }
+            Frag<T> dkf, dvf;
+            frag_from_c2(dkf, dk[0], dk[1]);
+            frag_from_c2(dvf, dv[0], dv[1]);
+#pragma unroll
+            for (int mt = 0; mt < BK_MT; ++mt) {
+                Frag<T> a;
+                wfrag_load(a, WinT, mt, 3 * MB_HEADS, MB_HEADS + head);
+                du[si][mt] = mma(a, dkf, du[si][mt]);
+                wfrag_load(a, WinT, mt, 3 * MB_HEADS, 2 * MB_HEADS + head);
+                du[si][mt] = mma(a, dvf, du[si][mt]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- LayerNorm backward + residual ----------------
+    float dlw[BK_MT][4], dlb[BK_MT][4];
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dlw[mt][r] = dlb[mt][r] = 0.f;
+#pragma unroll
+    for (int si = 0; si < MB_NSW; ++si) {
+        const size_t n = n0 + tt[si];
+        ln_bwd_row96<T>(du[si], x + n * MB_H, dy + n * MB_H, dx + n * MB_H, stats + n * 2, tv[si], P + param_off(c, layer, P_MH_LN_W), dlw, dlb);
+    }
+    ln_affine_flush(dlw, dlb, G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B));
+}
+
+template <class T>
+static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
+                      void* dx, float* stats, void* dqkv, hipStream_t st) {
+    const int tp = cdiv(c.T, 16) * 16;
+    if (tp > 256) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)7 * tp * MB_DH * sizeof(T) + (size_t)3 * tp * sizeof(float);
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
+    const T* pk = (const T*)packed;
+    int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
+    if (e) return e;
+    dim3 grid(c.B * c.F), block(512);
+    NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_T),
+                pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (T*)dx, stats, (T*)dqkv);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
+                  void* dx, void* ws, hipStream_t st) {
+    const size_t N = (size_t)c.B * c.F * c.T;
+    float* stats = (float*)ws;
+    void* dqkv = (char*)ws + ws_align(N * 2 * sizeof(float));
+    int e = c.dtype == NBSS_BF16 ? mhsa_bwd_t<bf16_t>(c, P, G, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+                                 : mhsa_bwd_t<float>(c, P, G, packed, layer, x, dy, osave, dx, stats, dqkv, st);
+    if (e) return e;
+    WgradArgs a;
+    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
+    // out_proj: dWo[H][H] = dy^T O ; dbo = colsum(dy)
+    a.A = dy; a.lda = MB_H; a.MA = MB_H; a.B = osave; a.ldb = MB_H; a.NB = MB_H;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    a.dW = G + param_off(c, layer, P_OUTP_W); a.dbias = G + param_off(c, layer, P_OUTP_B);
+    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    // in_proj: dWin[3H][H] = dqkv^T LN(x) ; dbin = colsum(dqkv)
+    a.A = dqkv; a.lda = 3 * MB_H; a.MA = 3 * MB_H; a.B = x; a.ldb = MB_H; a.NB = MB_H;
+    a.stats = stats; a.gamma = P + param_off(c, layer, P_MH_LN_W); a.beta = P + param_off(c, layer, P_MH_LN_B);
+    a.dW = G + param_off(c, layer, P_INP_W); a.dbias = G + param_off(c, layer, P_INP_B);
+    return wgrad_launch(a, c.dtype, st);
+}

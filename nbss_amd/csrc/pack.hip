@@ -63,6 +63,52 @@ NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P, int ki
             if (d >= cg) return 0.f;
             return P[param_off(c, layer, P_TF_W2) + (int64_t)m * c.FFN + ks * cg + d];
         }
+        // ---- transposed (data-gradient) operands ----
+        case K_DEC_T:
+            return knat < c.C_out ? P[param_off_dec_w(c) + (int64_t)knat * H + m] : 0.f;
+        case K_FC1_T: case K_FC2_T: {
+            // du[f][i] = sum_{tap',o} W[o][i][ks-1-tap'] dv[f + tap' - half][o]
+            const int fg = H / c.f_groups, pc = fg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
+            if (m >= fg || p >= c.f_ks * pc) return 0.f;
+            const int tapp = p / pc, o = (p % pc) * 4 + (j & 3);
+            const int64_t w = param_off(c, layer, kind == K_FC1_T ? P_FC1_W : P_FC2_W);
+            return P[w + ((int64_t)(nb * fg + o) * fg + m) * c.f_ks + (c.f_ks - 1 - tapp)];
+        }
+        case K_SQ_T:
+            return knat < c.SQ ? P[param_off(c, layer, P_SQ_W) + (int64_t)knat * H + m] : 0.f;
+        case K_FULL_T:
+            return (m < c.F && knat < c.F) ? P[param_off(c, layer, P_FULL_W) + ((int64_t)nb * c.F + knat) * c.F + m] : 0.f;
+        case K_USQ_T: {
+            const int ch = ks * 32 + perm_k(g4, j);
+            return m < c.SQ ? P[param_off(c, layer, P_USQ_W) + (int64_t)ch * c.SQ + m] : 0.f;
+        }
+        case K_INP_T: {
+            const int dh = H / c.heads, which = ks / c.heads, head = ks % c.heads, d = perm_k(g4, j);
+            if (d >= dh) return 0.f;
+            return P[param_off(c, layer, P_INP_W) + (int64_t)(which * H + head * dh + d) * H + m];
+        }
+        case K_OUTP_T: {
+            const int dh = H / c.heads, head = mt >> 1, d = (mt & 1) * 16 + l15;
+            if (d >= dh) return 0.f;
+            return P[param_off(c, layer, P_OUTP_W) + (int64_t)knat * H + head * dh + d];
+        }
+        case K_TF_W1_T: {
+            const int cg = c.FFN / c.t_groups, d = perm_k(g4, j);
+            if (d >= cg) return 0.f;
+            return P[param_off(c, layer, P_TF_W1) + (int64_t)(ks * cg + d) * H + m];
+        }
+        case K_TF_C1_T: case K_TF_C2_T: case K_TF_C3_T: {
+            const int cg = c.FFN / c.t_groups, pc = cg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
+            if (m >= cg || p >= c.t_ks * pc) return 0.f;
+            const int tapp = p / pc, o = (p % pc) * 4 + (j & 3);
+            const int pk = kind == K_TF_C1_T ? P_TF_C1W : (kind == K_TF_C2_T ? P_TF_C2W : P_TF_C3W);
+            return P[param_off(c, layer, pk) + ((int64_t)(nb * cg + o) * cg + m) * c.t_ks + (c.t_ks - 1 - tapp)];
+        }
+        case K_TF_W2_T: {
+            const int cg = c.FFN / c.t_groups, grp = mt >> 1, ci = (mt & 1) * 16 + l15;
+            if (ci >= cg) return 0.f;
+            return P[param_off(c, layer, P_TF_W2) + (int64_t)knat * c.FFN + grp * cg + ci];
+        }
     }
     return 0.f;
 }

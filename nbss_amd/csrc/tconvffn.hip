@@ -11,6 +11,7 @@
 // intermediates of the reference never exist in memory.
 #include "launch.h"
 #include "layout.h"
+#include "wgrad.h"
 
 #define TF_H 96
 #define TF_FFN 192
@@ -281,6 +282,466 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_kernel(nbss_cfg c, const flo
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Backward (data gradient).  Same decomposition as forward; the group chain is recomputed and then
+// walked backwards.  Pre-activations stay in registers (they are only needed by the owning wave),
+// activations / gradients that neighbouring frames need go through 4 LDS buffers.  Weight
+// gradients are NOT formed here: the kernel emits the (activation, pre-activation-gradient) pairs of
+// the five linear maps as [B,F,T,FFN] tensors and wgrad.hip contracts them over all tokens.
+// LayerNorm / GroupNorm affine gradients are reduced in-kernel (shuffle + atomicAdd).
+template <class T>
+struct TfOps {  // wgrad operands, each [B*F*T][FFN]
+    T *h1, *h2, *h4, *h5, *da1, *da2, *da3, *da5;
+};
+
+template <class T>
+NBSS_DEV void store_op(T* __restrict__ op, size_t n, bool valid, int cbase, const f32x4& lo, const f32x4& hi) {
+    if (!valid) return;
+    const int g4 = lane_id() >> 4;
+    T* r = op + n * TF_FFN + cbase;
+    store4(r + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
+    if (g4 < 2) store4(r + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
+}
+
+// sum over the 16 lanes that share (lane>>4): per-channel reduction over the frames of a strip
+NBSS_DEV float sum_l15(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+template <class T>
+__global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, const float* __restrict__ P, float* __restrict__ G, int layer,
+                                                           const T* __restrict__ W1, const T* __restrict__ Wc1, const T* __restrict__ Wc2,
+                                                           const T* __restrict__ Wc3, const T* __restrict__ W1t, const T* __restrict__ Wc1t,
+                                                           const T* __restrict__ Wc2t, const T* __restrict__ Wc3t, const T* __restrict__ W2t,
+                                                           const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                           float* __restrict__ stats, TfOps<T> ops) {
+    NBSS_LDS(smem);
+    const int T_ = c.T;
+    constexpr int tp = TF_TP;  // buffers always hold 16 strips so that no strip ever indexes out of bounds
+    T* buf0 = reinterpret_cast<T*>(smem);
+    T* buf1 = buf0 + (size_t)(tp + 2) * TF_CG;
+    T* buf2 = buf1 + (size_t)(tp + 2) * TF_CG;
+    T* buf3 = buf2 + (size_t)(tp + 2) * TF_CG;
+    float* red = reinterpret_cast<float*>(buf3 + (size_t)(tp + 2) * TF_CG);  // [8 waves][2]
+    const int bf = blockIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)bf * T_;
+    const T* xb = x + n0 * TF_H;
+    const T* dyb = dy + n0 * TF_H;
+    T* dxb = dx + n0 * TF_H;
+    const float* lnw = P + param_off(c, layer, P_TF_LN_W);
+    const float* lnb = P + param_off(c, layer, P_TF_LN_B);
+    const float* b1 = P + param_off(c, layer, P_TF_B1);
+    const float* cb1 = P + param_off(c, layer, P_TF_C1B);
+    const float* cb2 = P + param_off(c, layer, P_TF_C2B);
+    const float* cb3 = P + param_off(c, layer, P_TF_C3B);
+    const float* gnw = P + param_off(c, layer, P_TF_GN_W);
+    const float* gnb = P + param_off(c, layer, P_TF_GN_B);
+
+    if (tid < TF_CG) {
+        T* bs[4] = {buf0, buf1, buf2, buf3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            store1(bs[i] + tid, 0.f);
+            store1(bs[i] + (size_t)(tp + 1) * TF_CG + tid, 0.f);
+        }
+    }
+
+    int tt[TF_NSW];
+    bool tv[TF_NSW];
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si) {
+        tt[si] = (w * TF_NSW + si) * 16 + l15;
+        tv[si] = tt[si] < T_;
+    }
+    // strips beyond the padded length do nothing but must still hit every barrier
+    const bool wact = (w * TF_NSW) * 16 < tp;
+
+    Frag<T> u[TF_NSW][TF_KS], dyf[TF_NSW][TF_KS];
+    {
+        float gam[TF_KS][8], bet[TF_KS][8];
+#pragma unroll
+        for (int ks = 0; ks < TF_KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gam[ks][j] = lnw[ks * 32 + 8 * g4 + j];
+                bet[ks][j] = lnb[ks * 32 + 8 * g4 + j];
+            }
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+            ln_strip_tf<T>(xb + (size_t)tt[si] * TF_H, tv[si], gam, bet, u[si]);
+#pragma unroll
+            for (int ks = 0; ks < TF_KS; ++ks) {
+                if (tv[si]) frag_load(dyf[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                else frag_zero(dyf[si][ks]);
+            }
+        }
+    }
+    f32x4 du[TF_NSW][TF_H / 16];
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si)
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) du[si][mt] = F32X4_ZERO;
+
+    const int d0 = 4 * g4, d1 = 16 + 4 * g4;
+    const bool v1 = g4 < 2;
+    const float cnt = (float)(TF_CG * T_);
+
+    for (int gr = 0; gr < TF_G; ++gr) {
+        const int cbase = gr * TF_CG;
+        f32x4 a1[TF_NSW][2], a2[TF_NSW][2], a3h[TF_NSW][2], a5[TF_NSW][2], ct[TF_NSW][2];
+        // ---------------- forward recompute ----------------
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            Frag<T> a[TF_KS];
+#pragma unroll
+            for (int ks = 0; ks < TF_KS; ++ks) wfrag_load(a[ks], W1, gr * 2 + half, TF_KS, ks);
+#pragma unroll
+            for (int si = 0; si < TF_NSW; ++si) {
+                f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < TF_KS; ++ks) acc = mma(a[ks], u[si][ks], acc);
+                a1[si][half] = acc;
+            }
+        }
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a1[si][0][r] += b1[cbase + d0 + r];
+                a1[si][1][r] = v1 ? a1[si][1][r] + b1[cbase + d1 + r] : 0.f;
+                ct[si][0][r] = silu_f(a1[si][0][r]);
+                ct[si][1][r] = v1 ? silu_f(a1[si][1][r]) : 0.f;
+            }
+            store_rows<T>(buf0, tt[si], tv[si], ct[si][0], ct[si][1]);
+            store_op<T>(ops.h1, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        __syncthreads();
+        conv_group<T>(Wc1 + (size_t)gr * 2 * TF_CKS * 512, buf0, w, a2);
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a2[si][0][r] += cb1[cbase + d0 + r];
+                a2[si][1][r] = v1 ? a2[si][1][r] + cb1[cbase + d1 + r] : 0.f;
+                ct[si][0][r] = silu_f(a2[si][0][r]);
+                ct[si][1][r] = v1 ? silu_f(a2[si][1][r]) : 0.f;
+            }
+            store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
+            store_op<T>(ops.h2, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        __syncthreads();
+        conv_group<T>(Wc2 + (size_t)gr * 2 * TF_CKS * 512, buf1, w, a3h);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a3h[si][0][r] = round_to(a3h[si][0][r] + cb2[cbase + d0 + r], x);
+                a3h[si][1][r] = v1 ? round_to(a3h[si][1][r] + cb2[cbase + d1 + r], x) : 0.f;
+                if (tv[si]) {
+                    s1 += a3h[si][0][r] + a3h[si][1][r];
+                    s2 += a3h[si][0][r] * a3h[si][0][r] + a3h[si][1][r] * a3h[si][1][r];
+                }
+            }
+        s1 = wave_sum64(s1);
+        s2 = wave_sum64(s2);
+        if (lane == 0) {
+            red[2 * w] = s1;
+            red[2 * w + 1] = s2;
+        }
+        __syncthreads();
+        float ts1 = 0.f, ts2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ts1 += red[2 * i];
+            ts2 += red[2 * i + 1];
+        }
+        const float mean = ts1 / cnt;
+        const float rstd = rsqrtf(fmaxf(ts2 / cnt - mean * mean, 0.f) + 1e-5f);
+        float gw0[4], gw1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gw0[r] = gnw[cbase + d0 + r];
+            gw1[r] = v1 ? gnw[cbase + d1 + r] : 0.f;
+        }
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a3h[si][0][r] = (a3h[si][0][r] - mean) * rstd;                   // \hat a3
+                a3h[si][1][r] = v1 ? (a3h[si][1][r] - mean) * rstd : 0.f;
+                ct[si][0][r] = silu_f(a3h[si][0][r] * gw0[r] + gnb[cbase + d0 + r]);
+                ct[si][1][r] = v1 ? silu_f(a3h[si][1][r] * gw1[r] + gnb[cbase + d1 + r]) : 0.f;
+            }
+            store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
+            store_op<T>(ops.h4, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        __syncthreads();
+        conv_group<T>(Wc3 + (size_t)gr * 2 * TF_CKS * 512, buf2, w, a5);
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a5[si][0][r] += cb3[cbase + d0 + r];
+                a5[si][1][r] = v1 ? a5[si][1][r] + cb3[cbase + d1 + r] : 0.f;
+                ct[si][0][r] = silu_f(a5[si][0][r]);
+                ct[si][1][r] = v1 ? silu_f(a5[si][1][r]) : 0.f;
+            }
+            store_op<T>(ops.h5, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        // ---------------- backward ----------------
+        // dh5 = W2[:, group]^T dy ; da5 = dh5 * silu'(a5) -> buf3
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            Frag<T> a[TF_KS];
+#pragma unroll
+            for (int ks = 0; ks < TF_KS; ++ks) wfrag_load(a[ks], W2t, gr * 2 + half, TF_KS, ks);
+#pragma unroll
+            for (int si = 0; si < TF_NSW; ++si) {
+                f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < TF_KS; ++ks) acc = mma(a[ks], dyf[si][ks], acc);
+                ct[si][half] = acc;
+            }
+        }
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ct[si][0][r] *= dsilu_f(a5[si][0][r]);
+                ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a5[si][1][r]) : 0.f;
+            }
+            store_rows<T>(buf3, tt[si], tv[si], ct[si][0], ct[si][1]);
+            store_op<T>(ops.da5, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        __syncthreads();
+        // dh4 = conv3^T(da5) ; dn3 = dh4 * silu'(n3) ; GroupNorm backward -> da3 -> buf2
+        conv_group<T>(Wc3t + (size_t)gr * 2 * TF_CKS * 512, buf3, w, ct);
+        float sa = 0.f, sb = 0.f;
+        float dgw[2][4], dgb[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dgw[0][r] = dgw[1][r] = dgb[0][r] = dgb[1][r] = 0.f;
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float n30 = a3h[si][0][r] * gw0[r] + gnb[cbase + d0 + r];
+                const float n31 = v1 ? a3h[si][1][r] * gw1[r] + gnb[cbase + d1 + r] : 0.f;
+                ct[si][0][r] = tv[si] ? ct[si][0][r] * dsilu_f(n30) : 0.f;            // dn3
+                ct[si][1][r] = (tv[si] && v1) ? ct[si][1][r] * dsilu_f(n31) : 0.f;
+                dgw[0][r] += ct[si][0][r] * a3h[si][0][r];
+                dgw[1][r] += ct[si][1][r] * a3h[si][1][r];
+                dgb[0][r] += ct[si][0][r];
+                dgb[1][r] += ct[si][1][r];
+                sa += gw0[r] * ct[si][0][r] + gw1[r] * ct[si][1][r];
+                sb += gw0[r] * ct[si][0][r] * a3h[si][0][r] + gw1[r] * ct[si][1][r] * a3h[si][1][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float w0 = sum_l15(dgw[0][r]), w1 = sum_l15(dgw[1][r]), q0 = sum_l15(dgb[0][r]), q1 = sum_l15(dgb[1][r]);
+            if (l15 == 0 && wact) {
+                atomicAdd(G + param_off(c, layer, P_TF_GN_W) + cbase + d0 + r, w0);
+                atomicAdd(G + param_off(c, layer, P_TF_GN_B) + cbase + d0 + r, q0);
+                if (v1) {
+                    atomicAdd(G + param_off(c, layer, P_TF_GN_W) + cbase + d1 + r, w1);
+                    atomicAdd(G + param_off(c, layer, P_TF_GN_B) + cbase + d1 + r, q1);
+                }
+            }
+        }
+        sa = wave_sum64(sa);
+        sb = wave_sum64(sb);
+        __syncthreads();  // red is free again (everyone has read the forward statistics)
+        if (lane == 0) {
+            red[2 * w] = sa;
+            red[2 * w + 1] = sb;
+        }
+        __syncthreads();
+        float tsa = 0.f, tsb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            tsa += red[2 * i];
+            tsb += red[2 * i + 1];
+        }
+        tsa /= cnt;
+        tsb /= cnt;
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ct[si][0][r] = rstd * (gw0[r] * ct[si][0][r] - tsa - a3h[si][0][r] * tsb);
+                ct[si][1][r] = v1 ? rstd * (gw1[r] * ct[si][1][r] - tsa - a3h[si][1][r] * tsb) : 0.f;
+            }
+            store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
+            store_op<T>(ops.da3, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        __syncthreads();
+        // dh2 = conv2^T(da3) ; da2 = dh2 * silu'(a2) -> buf1
+        conv_group<T>(Wc2t + (size_t)gr * 2 * TF_CKS * 512, buf2, w, ct);
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ct[si][0][r] *= dsilu_f(a2[si][0][r]);
+                ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a2[si][1][r]) : 0.f;
+            }
+            store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
+            store_op<T>(ops.da2, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+        }
+        __syncthreads();
+        // dh1 = conv1^T(da2) ; da1 = dh1 * silu'(a1) ; du += W1[group]^T da1
+        conv_group<T>(Wc1t + (size_t)gr * 2 * TF_CKS * 512, buf1, w, ct);
+        Frag<T> da1f[TF_NSW];
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ct[si][0][r] *= dsilu_f(a1[si][0][r]);
+                ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a1[si][1][r]) : 0.f;
+            }
+            store_op<T>(ops.da1, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            frag_from_c2(da1f[si], ct[si][0], ct[si][1]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) {
+            Frag<T> a;
+            wfrag_load(a, W1t, mt, TF_G, gr);
+#pragma unroll
+            for (int si = 0; si < TF_NSW; ++si) du[si][mt] = mma(a, da1f[si], du[si][mt]);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- LayerNorm backward + residual, in registers ----------------
+    float dlw[TF_H / 16][4], dlb[TF_H / 16][4];
+#pragma unroll
+    for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dlw[mt][r] = dlb[mt][r] = 0.f;
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si) {
+        float xv[TF_H / 16][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) {
+            if (tv[si]) load4(xb + (size_t)tt[si] * TF_H + 16 * mt + 4 * g4, xv[mt]);
+            else xv[mt][0] = xv[mt][1] = xv[mt][2] = xv[mt][3] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += xv[mt][r];
+        }
+        const float mean = wave_sum16(sum) * (1.0f / TF_H);
+        float q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xv[mt][r] -= mean;
+                q += xv[mt][r] * xv[mt][r];
+            }
+        const float rstd = rsqrtf(wave_sum16(q) * (1.0f / TF_H) + 1e-5f);
+        if (tv[si] && g4 == 0) {
+            stats[(n0 + tt[si]) * 2] = mean;
+            stats[(n0 + tt[si]) * 2 + 1] = rstd;
+        }
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * mt + 4 * g4 + r;
+                xv[mt][r] *= rstd;  // \hat x
+                const float dv = tv[si] ? du[si][mt][r] : 0.f;
+                dlw[mt][r] += dv * xv[mt][r];
+                dlb[mt][r] += dv;
+                du[si][mt][r] = dv * lnw[ch];
+                m1 += du[si][mt][r];
+                m2 += du[si][mt][r] * xv[mt][r];
+            }
+        m1 = wave_sum16(m1) * (1.0f / TF_H);
+        m2 = wave_sum16(m2) * (1.0f / TF_H);
+        if (tv[si]) {
+#pragma unroll
+            for (int mt = 0; mt < TF_H / 16; ++mt) {
+                const int ch = 16 * mt + 4 * g4;
+                float dv[4], o[4];
+                load4(dyb + (size_t)tt[si] * TF_H + ch, dv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = dv[r] + rstd * (du[si][mt][r] - m1 - xv[mt][r] * m2);
+                store4(dxb + (size_t)tt[si] * TF_H + ch, o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = sum_l15(dlw[mt][r]), b = sum_l15(dlb[mt][r]);
+            if (l15 == 0 && wact) {
+                atomicAdd(G + param_off(c, layer, P_TF_LN_W) + 16 * mt + 4 * g4 + r, a);
+                atomicAdd(G + param_off(c, layer, P_TF_LN_B) + 16 * mt + 4 * g4 + r, b);
+            }
+        }
+}
+
+template <class T>
+static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                          float* stats, void* const* opsv, hipStream_t st) {
+    if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float);
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    const T* pk = (const T*)packed;
+    TfOps<T> ops;
+    ops.h1 = (T*)opsv[0]; ops.h2 = (T*)opsv[1]; ops.h4 = (T*)opsv[2]; ops.h5 = (T*)opsv[3];
+    ops.da1 = (T*)opsv[4]; ops.da2 = (T*)opsv[5]; ops.da3 = (T*)opsv[6]; ops.da5 = (T*)opsv[7];
+    int e = NBSS_SET_MAX_LDS((tconvffn_bwd_kernel<T>), lds);
+    if (e) return e;
+    dim3 grid(c.B * c.F), block(512);
+    NBSS_LAUNCH((tconvffn_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
+                pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W1_T),
+                pk + pack_off(c, layer, K_TF_C1_T), pk + pack_off(c, layer, K_TF_C2_T), pk + pack_off(c, layer, K_TF_C3_T),
+                pk + pack_off(c, layer, K_TF_W2_T), (const T*)x, (const T*)dy, (T*)dx, stats, ops);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                      void* ws, hipStream_t st) {
+    // workspace: stats [N][2] f32 | h1 h2 h4 h5 da1 da2 da3 da5, each [N][FFN] of the stream dtype
+    const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    float* stats = (float*)ws;
+    char* base = (char*)ws + ws_align(N * 2 * sizeof(float));
+    void* ops[8];
+    for (int i = 0; i < 8; ++i) ops[i] = base + (size_t)i * ws_align(N * TF_FFN * esz);
+    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_t<bf16_t>(c, P, G, packed, layer, x, dy, dx, stats, ops, st)
+                                 : tconvffn_bwd_t<float>(c, P, G, packed, layer, x, dy, dx, stats, ops, st);
+    if (e) return e;
+    WgradArgs a;
+    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
+    a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = ops[3]; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
+    a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
+    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    // the three grouped k=3 convs
+    const int convA[3] = {5, 6, 7}, convB[3] = {0, 1, 2};
+    const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convBias[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
+    for (int k = 0; k < 3; ++k) {
+        a.A = ops[convA[k]]; a.lda = TF_FFN; a.MA = TF_FFN; a.B = ops[convB[k]]; a.ldb = TF_FFN; a.NB = TF_FFN;
+        a.groups = c.t_groups; a.taps = c.t_ks;
+        a.dW = G + param_off(c, layer, convW[k]); a.dbias = G + param_off(c, layer, convBias[k]);
+        if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    }
+    // W1: dW1[FFN][H] = da1^T LN(x) ; db1 = colsum(da1)
+    a.A = ops[4]; a.lda = TF_FFN; a.MA = TF_FFN; a.B = x; a.ldb = TF_H; a.NB = TF_H; a.groups = 1; a.taps = 1;
+    a.stats = stats; a.gamma = P + param_off(c, layer, P_TF_LN_W); a.beta = P + param_off(c, layer, P_TF_LN_B);
+    a.dW = G + param_off(c, layer, P_TF_W1); a.dbias = G + param_off(c, layer, P_TF_B1);
+    return wgrad_launch(a, c.dtype, st);
 }
 
 template <class T>

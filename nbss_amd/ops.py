@@ -92,16 +92,36 @@ def full_fwd(lib, cfg, flat, packed, layer, x):
     return y
 
 
-def mhsa_fwd(lib, cfg, flat, packed, layer, x):
+def mhsa_fwd(lib, cfg, flat, packed, layer, x, o_save=None):
     y = torch.empty_like(x)
-    lib.call("nbss_mhsa_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
+    lib.call("nbss_mhsa_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y),
+             _ptr(lib, o_save), _stream(lib, x))
     return y
+
+
+def mhsa_bwd(lib, cfg, flat, grads, packed, layer, x, dy, o_save, ws):
+    dx = torch.empty_like(x)
+    lib.call("nbss_mhsa_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed), layer,
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, o_save, stream_dtype(cfg)), _ptr(lib, dx), _ptr(lib, ws),
+             _stream(lib, x))
+    return dx
 
 
 def tconvffn_fwd(lib, cfg, flat, packed, layer, x):
     y = torch.empty_like(x)
     lib.call("nbss_tconvffn_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
     return y
+
+
+def workspace(lib, cfg, device) -> Tensor:
+    return torch.empty(lib.nbss_workspace_bytes(C.byref(cfg)), dtype=torch.uint8, device=device)
+
+
+def tconvffn_bwd(lib, cfg, flat, grads, packed, layer, x, dy, ws):
+    dx = torch.empty_like(x)
+    lib.call("nbss_tconvffn_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed), layer,
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, dx), _ptr(lib, ws), _stream(lib, x))
+    return dx
 
 
 def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:
