@@ -96,6 +96,15 @@ int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, co
                       void* dx, void* ws, void* stream);
 int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
                   const void* o_save, void* dx, void* ws, void* stream);
+int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, int which, const void* x,
+                   const void* dy, void* dx, void* ws, void* stream);
+int nbss_full_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
+                  void* dx, void* ws, void* stream);
+/* decoder: x = decoder input stream, dout = fp32 gradient of the [B,F,T,C_out] output */
+int nbss_decoder_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* x, const float* dout, void* dx,
+                     void* ws, void* stream);
+/* encoder: weight/bias gradient only (the network input needs none); dy = gradient of the encoder output */
+int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const void* dy, void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use

@@ -53,6 +53,10 @@ SIGNATURES = {
     "nbss_workspace_bytes": (C.c_int64, [_CP]),
     "nbss_tconvffn_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "nbss_mhsa_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "nbss_fconv_bwd": (_I, [_CP, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "nbss_full_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "nbss_decoder_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_encoder_bwd": (_I, [_CP, _P, _P, _P, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),
     "nbss_build_info": (C.c_char_p, []),
 }

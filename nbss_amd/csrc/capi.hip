@@ -17,6 +17,14 @@ int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
                       void* ws, hipStream_t st);
 
+int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
+                   void* ws, hipStream_t st);
+int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx, void* ws,
+                  hipStream_t st);
+int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, const void* x, const float* dout, void* dx, void* ws,
+                     hipStream_t st);
+int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, hipStream_t st);
+
 #define CHECK_CFG(cfg)                         \
     if (!(cfg)) return NBSS_EINVAL;            \
     {                                          \
@@ -122,6 +130,35 @@ int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, co
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
     return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
+}
+
+int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, int which, const void* x,
+                   const void* dy, void* dx, void* ws, void* stream) {
+    CHECK_CFG(cfg);
+    CHECK_LAYER(cfg, layer);
+    if (!params || !grads || !packed || !x || !dy || !dx || !ws || (which != 0 && which != 1)) return NBSS_EINVAL;
+    return fconv_bwd_impl(*cfg, params, grads, packed, layer, which, x, dy, dx, ws, (hipStream_t)stream);
+}
+
+int nbss_full_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
+                  void* dx, void* ws, void* stream) {
+    CHECK_CFG(cfg);
+    CHECK_LAYER(cfg, layer);
+    if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
+    return full_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
+}
+
+int nbss_decoder_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* x, const float* dout, void* dx,
+                     void* ws, void* stream) {
+    CHECK_CFG(cfg);
+    if (!params || !grads || !packed || !x || !dout || !dx || !ws) return NBSS_EINVAL;
+    return decoder_bwd_impl(*cfg, params, grads, packed, x, dout, dx, ws, (hipStream_t)stream);
+}
+
+int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const void* dy, void* stream) {
+    CHECK_CFG(cfg);
+    if (!grads || !xin || !dy) return NBSS_EINVAL;
+    return encoder_bwd_impl(*cfg, grads, xin, dy, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

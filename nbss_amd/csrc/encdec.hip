@@ -6,6 +6,7 @@
 // [B,F,T,H] stream is written with 8/16-byte stores.
 #include "launch.h"
 #include "layout.h"
+#include "wgrad.h"
 
 #define ENC_H 96
 
@@ -112,4 +113,74 @@ int encoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, cons
 }
 int decoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st) {
     return c.dtype == NBSS_BF16 ? decoder_fwd_t<bf16_t>(c, P, packed, x, out, st) : decoder_fwd_t<float>(c, P, packed, x, out, st);
+}
+
+// ---- backward -------------------------------------------------------------------------------
+// decoder: dx = W^T dout (form 2, K = C_out) and a stream-dtype copy of dout for the weight gradient
+template <class T>
+__global__ __launch_bounds__(256) void decoder_bwd_kernel(nbss_cfg c, const T* __restrict__ WpT, const float* __restrict__ dout,
+                                                          T* __restrict__ dx, T* __restrict__ dout_t, int CP) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int T_ = c.T, Co = c.C_out;
+    const int nst = cdiv(T_, 16);
+    const int nstrips = c.B * c.F * nst;
+    constexpr int MT = ENC_H / 16;
+    Frag<T> a[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) wfrag_load(a[i], WpT, i, 1, 0);
+    const int wpb = blockDim.x >> 6;
+    for (int s = blockIdx.x * wpb + wave_id(); s < nstrips; s += gridDim.x * wpb) {
+        const int bf = s / nst, t = (s % nst) * 16 + l15;
+        const size_t n = (size_t)bf * T_ + t;
+        Frag<T> b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g4 + j;
+            const float v = (t < T_ && k < Co) ? dout[n * Co + k] : 0.f;
+            frag_set(b, j, v);
+            if (t < T_ && k < CP) store1(dout_t + n * CP + k, v);
+        }
+        if (t < T_) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const f32x4 acc = mma(a[i], b, F32X4_ZERO);
+                store4(dx + n * ENC_H + 16 * i + 4 * g4, acc[0], acc[1], acc[2], acc[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) (void)mma(a[i], b, F32X4_ZERO);
+        }
+    }
+}
+
+int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, const void* x, const float* dout, void* dx, void* ws,
+                     hipStream_t st) {
+    const size_t N = (size_t)c.B * c.F * c.T;
+    const int CP = (c.C_out + 3) & ~3;
+    const int nstrips = c.B * c.F * cdiv(c.T, 16);
+    dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
+    if (c.dtype == NBSS_BF16)
+        NBSS_LAUNCH((decoder_bwd_kernel<bf16_t>), grid, block, 0, st, c, (const bf16_t*)packed + pack_off(c, 0, K_DEC_T), dout, (bf16_t*)dx, (bf16_t*)ws, CP);
+    else
+        NBSS_LAUNCH((decoder_bwd_kernel<float>), grid, block, 0, st, c, (const float*)packed + pack_off(c, 0, K_DEC_T), dout, (float*)dx, (float*)ws, CP);
+    int e = NBSS_CHECK_LAUNCH();
+    if (e) return e;
+    WgradArgs a;
+    a.mvalid = c.C_out; a.nvalid = 0;
+    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    a.A = ws; a.lda = CP; a.MA = CP; a.B = x; a.ldb = ENC_H; a.NB = ENC_H;
+    a.dW = G + param_off_dec_w(c); a.dbias = G + param_off_dec_b(c);
+    return wgrad_launch(a, c.dtype, st);
+}
+
+// encoder: the network input needs no gradient; only dW[o][i][tap] = sum_n dy[n][o] xin[n+tap-2][i] and db
+int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, hipStream_t st) {
+    WgradArgs a;
+    a.mvalid = 0; a.nvalid = 0;
+    a.Ntok = c.B * c.F * c.T; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = c.enc_ks;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    a.A = dy; a.lda = ENC_H; a.MA = ENC_H; a.B = xin; a.ldb = c.C_in; a.NB = c.C_in;
+    a.dW = G + param_off_enc_w(c); a.dbias = G + param_off_enc_b(c);
+    return wgrad_launch(a, c.dtype, st);
 }

@@ -10,6 +10,8 @@
 // residual add + store are full 16-byte coalesced accesses.
 #include "launch.h"
 #include "layout.h"
+#include "blocks.h"
+#include "wgrad.h"
 
 #define FC_H 96
 #define FC_G 8
@@ -167,6 +169,211 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
             store4(y + go, xv[0] + yv[0], xv[1] + yv[1], xv[2] + yv[2], xv[3] + yv[3]);
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Backward (data gradient): one workgroup = one (b,t) frame with the whole F axis in LDS.  Here a
+// wave owns frequency tiles (16 rows of F) and walks all 8 groups, so a lane ends up holding all 96
+// channels of "its" frequency (12g + 4(l>>4) + r, lanes 48..63 idle in the epilogues) and PReLU',
+// the transposed conv and the LayerNorm backward run without leaving registers.  The conv weight
+// gradient is contracted by wgrad.hip from dv (emitted here) and LN(x).
+template <class T>
+NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int f, int ch0, int ks) {
+    const int g4 = lane_id() >> 4;
+    const int p0 = ks * 8 + 2 * g4, p1 = p0 + 1;
+    frag_load_lo(bq, u + (size_t)(f + p0 / 3) * FC_H + ch0 + (p0 % 3) * 4);
+    if (p1 < 15) frag_load_hi(bq, u + (size_t)(f + p1 / 3) * FC_H + ch0 + (p1 % 3) * 4);
+    else frag_zero_hi(bq);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                        const float* __restrict__ cb, const float* __restrict__ slope, float* __restrict__ g_lnw,
+                                                        float* __restrict__ g_lnb, float* __restrict__ g_slope, const T* __restrict__ Wp,
+                                                        const T* __restrict__ WpT, const T* __restrict__ x, const T* __restrict__ dy,
+                                                        T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout) {
+    NBSS_LDS(smem);
+    const int F = c.F, T_ = c.T;
+    const int b = blockIdx.x / T_, t = blockIdx.x % T_;
+    const int mtf = cdiv(F, 16), FP = mtf * 16 + 4;
+    T* u = reinterpret_cast<T*>(smem);       // [FP][H]  LN(x), rows f+2
+    T* dvb = u + (size_t)FP * FC_H;          // [FP][H]  dv, rows f+2
+    constexpr int VN = VecOf<T>::N;
+    constexpr int VPR = FC_H / VN;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
+    const bool cvalid = g4 < 3;  // lanes 48..63 hold the 4 padding rows of every 12-channel group
+
+    for (int i = tid; i < FP * VPR; i += nthr) {
+        const int rr = i / VPR, off = (i % VPR) * VN, f = rr - 2;
+        if (f >= 0 && f < F) vec_copy(u + (size_t)rr * FC_H + off, x + (((size_t)b * F + f) * T_ + t) * FC_H + off);
+        else vec_zero(u + (size_t)rr * FC_H + off);
+        vec_zero(dvb + (size_t)rr * FC_H + off);
+    }
+    __syncthreads();
+    for (int f = tid; f < F; f += nthr) ln_row_inplace(u + (size_t)(f + 2) * FC_H, lnw, lnb);
+    __syncthreads();
+
+    float dsl[FC_G][4];
+#pragma unroll
+    for (int g = 0; g < FC_G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dsl[g][r] = 0.f;
+
+    // ---- conv forward recompute, PReLU', dv ----
+    for (int ft = w; ft < mtf; ft += nw) {
+        const int f = ft * 16 + l15;
+        const bool fvalid = f < F;
+        const size_t n = ((size_t)b * F + f) * T_ + t;
+#pragma unroll
+        for (int g = 0; g < FC_G; ++g) {
+            f32x4 acc = F32X4_ZERO;
+#pragma unroll
+            for (int ks = 0; ks < FC_KS; ++ks) {
+                Frag<T> a, bq;
+                wfrag_load(a, Wp, g, FC_KS, ks);
+                fconv_bfrag<T>(bq, u, f, g * FC_CG, ks);
+                acc = mma(a, bq, acc);
+            }
+            if (fvalid && cvalid) {
+                const int ch = g * FC_CG + 4 * g4;
+                float dyv[4], dv[4];
+                load4(dy + n * FC_H + ch, dyv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[r] + cb[ch + r];
+                    dv[r] = v > 0.f ? dyv[r] : slope[ch + r] * dyv[r];
+                    if (v <= 0.f) dsl[g][r] += dyv[r] * v;
+                }
+                store4(dvb + (size_t)(f + 2) * FC_H + ch, dv[0], dv[1], dv[2], dv[3]);
+                store4(dvout + n * FC_H + ch, dv[0], dv[1], dv[2], dv[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- transposed conv -> du, LayerNorm backward, residual ----
+    float dlw[FC_G][4], dlb[FC_G][4];
+#pragma unroll
+    for (int g = 0; g < FC_G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dlw[g][r] = dlb[g][r] = 0.f;
+    for (int ft = w; ft < mtf; ft += nw) {
+        const int f = ft * 16 + l15;
+        const bool valid = f < F && cvalid;
+        const size_t n = ((size_t)b * F + f) * T_ + t;
+        f32x4 du[FC_G];
+#pragma unroll
+        for (int g = 0; g < FC_G; ++g) {
+            f32x4 acc = F32X4_ZERO;
+#pragma unroll
+            for (int ks = 0; ks < FC_KS; ++ks) {
+                Frag<T> a, bq;
+                wfrag_load(a, WpT, g, FC_KS, ks);
+                fconv_bfrag<T>(bq, dvb, f, g * FC_CG, ks);
+                acc = mma(a, bq, acc);
+            }
+            du[g] = acc;
+        }
+        float xv[FC_G][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < FC_G; ++g) {
+            if (valid) load4(x + n * FC_H + g * FC_CG + 4 * g4, xv[g]);
+            else xv[g][0] = xv[g][1] = xv[g][2] = xv[g][3] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += xv[g][r];
+        }
+        const float mean = wave_sum16(sum) * (1.0f / FC_H);
+        float q = 0.f;
+#pragma unroll
+        for (int g = 0; g < FC_G; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xv[g][r] = valid ? xv[g][r] - mean : 0.f;
+                q += xv[g][r] * xv[g][r];
+            }
+        const float rstd = rsqrtf(wave_sum16(q) * (1.0f / FC_H) + 1e-5f);
+        if (f < F && g4 == 0) {
+            stats[n * 2] = mean;
+            stats[n * 2 + 1] = rstd;
+        }
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < FC_G; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xv[g][r] *= rstd;
+                const float dv = valid ? du[g][r] : 0.f;
+                dlw[g][r] += dv * xv[g][r];
+                dlb[g][r] += dv;
+                du[g][r] = valid ? dv * lnw[g * FC_CG + 4 * g4 + r] : 0.f;
+                m1 += du[g][r];
+                m2 += du[g][r] * xv[g][r];
+            }
+        m1 = wave_sum16(m1) * (1.0f / FC_H);
+        m2 = wave_sum16(m2) * (1.0f / FC_H);
+        if (valid) {
+#pragma unroll
+            for (int g = 0; g < FC_G; ++g) {
+                const int ch = g * FC_CG + 4 * g4;
+                float dyv[4], o[4];
+                load4(dy + n * FC_H + ch, dyv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = dyv[r] + rstd * (du[g][r] - m1 - xv[g][r] * m2);
+                store4(dx + n * FC_H + ch, o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < FC_G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = sum_l15_(dlw[g][r]), bb = sum_l15_(dlb[g][r]), s2 = sum_l15_(dsl[g][r]);
+            if (l15 == 0 && cvalid) {
+                const int ch = g * FC_CG + 4 * g4 + r;
+                atomicAdd(g_lnw + ch, a);
+                atomicAdd(g_lnb + ch, bb);
+                atomicAdd(g_slope + ch, s2);
+            }
+        }
+}
+
+template <class T>
+static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
+                       float* stats, void* dv, hipStream_t st) {
+    const int mtf = cdiv(c.F, 16);
+    if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)2 * (mtf * 16 + 4) * FC_H * sizeof(T);
+    const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
+    const T* pk = (const T*)packed;
+    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T>), lds);
+    if (e) return e;
+    dim3 grid(c.B * c.T), block(256);
+    NBSS_LAUNCH((fconv_bwd_kernel<T>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
+                P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), G + param_off(c, layer, lw),
+                G + param_off(c, layer, lb), G + param_off(c, layer, sl), pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
+                pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
+                   void* ws, hipStream_t st) {
+    const size_t N = (size_t)c.B * c.F * c.T;
+    float* stats = (float*)ws;
+    void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));
+    int e = c.dtype == NBSS_BF16 ? fconv_bwd_t<bf16_t>(c, P, G, packed, layer, which, x, dy, dx, stats, dv, st)
+                                 : fconv_bwd_t<float>(c, P, G, packed, layer, which, x, dy, dx, stats, dv, st);
+    if (e) return e;
+    // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
+    WgradArgs a;
+    a.mvalid = 0; a.nvalid = 0;
+    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = c.T; a.shift_dim = 1; a.groups = c.f_groups; a.taps = c.f_ks;
+    a.A = dv; a.lda = FC_H; a.MA = FC_H; a.B = x; a.ldb = FC_H; a.NB = FC_H;
+    a.stats = stats; a.gamma = P + param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); a.beta = P + param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B);
+    a.dW = G + param_off(c, layer, which ? P_FC2_W : P_FC1_W); a.dbias = G + param_off(c, layer, which ? P_FC2_B : P_FC1_B);
+    return wgrad_launch(a, c.dtype, st);
 }
 
 template <class T, int TT>

@@ -11,6 +11,8 @@
 //   pass 3  y = x + SiLU(Wu z + bu)
 #include "launch.h"
 #include "layout.h"
+#include "blocks.h"
+#include "wgrad.h"
 
 #define FL_H 96
 #define FL_SQ 8
@@ -143,6 +145,264 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward (data gradient).  Same slab decomposition; the squeezed tensors are recomputed in LDS
+// and walked backwards:
+//   p1  s_pre = Ws LN(x) + bs, s = SiLU(s_pre)                      -> LDS + global s (wgrad operand)
+//   p2  z = Wf s + bf                                               -> LDS + global z
+//   p3  y_pre = Wu z + bu ; dy_pre = dy SiLU'(y_pre) ; dz = Wu^T dy_pre   -> LDS dz, global dy_pre, dz
+//   p4  ds = Wf^T dz ; ds_pre = ds SiLU'(s_pre)                     -> LDS, global ds_pre
+//   p5  du = Ws^T ds_pre ; LayerNorm backward + residual in registers -> dx, (mean, rstd)
+// The three weight gradients (squeeze, LinearGroup, unsqueeze) are contracted by wgrad.hip.
+#define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
+
+template <class T>
+__global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, const float* __restrict__ P, float* __restrict__ G, int layer,
+                                                       const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
+                                                       const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
+                                                       const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                       float* __restrict__ stats, T* __restrict__ s_out, T* __restrict__ dz_out,
+                                                       T* __restrict__ z_out, T* __restrict__ dyp_out, T* __restrict__ dsp_out) {
+    NBSS_LDS(smem);
+    const int F = c.F, T_ = c.T;
+    const int mtf = cdiv(F, 16), ksf = cdiv(F, 32), FK = ksf * 32, FM = mtf * 16, FKP = FL_FKP(F);
+    T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]   s, later dz
+    T* sp = s + FL_SQ * FL_TT * FK;                // [FM][TT][SQ]   s_pre
+    T* z = sp + FM * FL_TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
+    const int ntt = cdiv(T_, FL_TT);
+    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
+    const int ntile = cdiv(F, 2);
+    const float* lnw = P + param_off(c, layer, P_FULL_LN_W);
+    const float* lnb = P + param_off(c, layer, P_FULL_LN_B);
+    const float* bs = P + param_off(c, layer, P_SQ_B);
+    const float* bfull = P + param_off(c, layer, P_FULL_B);
+    const float* bu = P + param_off(c, layer, P_USQ_B);
+
+    for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
+    __syncthreads();
+
+    // ---- p1: LN + squeeze ----
+    {
+        Frag<T> a[FL_KS];
+#pragma unroll
+        for (int ks = 0; ks < FL_KS; ++ks) wfrag_load(a[ks], Wsq, 0, FL_KS, ks);
+        float gam[BK_KS][8], bet[BK_KS][8];
+        load_ln_affine(lnw, lnb, gam, bet);
+        for (int nt = w; nt < ntile; nt += nw) {
+            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const bool valid = f < F && t0 + tt < T_;
+            Frag<T> u[BK_KS];
+            ln_strip96<T>(x + (((size_t)b * F + f) * T_ + t0 + tt) * FL_H, valid, gam, bet, u);
+            f32x4 acc = F32X4_ZERO;
+#pragma unroll
+            for (int ks = 0; ks < FL_KS; ++ks) acc = mma(a[ks], u[ks], acc);
+            if (valid && g4 < 2) {
+                float pre[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 4 * g4 + r;
+                    pre[r] = acc[r] + bs[ch];
+                    const float sv = silu_f(pre[r]);
+                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, sv);
+                    store1(s_out + (((size_t)b * T_ + t0 + tt) * FL_SQ + ch) * FKP + f, sv);
+                }
+                store4(sp + ((size_t)f * FL_TT + tt) * FL_SQ + 4 * g4, pre[0], pre[1], pre[2], pre[3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- p2: z = Wf s + bf ----
+    for (int task = w; task < FL_SQ * mtf; task += nw) {
+        const int ch = task / mtf, mt = task % mtf;
+        f32x4 acc = F32X4_ZERO;
+        for (int ks = 0; ks < ksf; ++ks) {
+            Frag<T> a, bq;
+            wfrag_load(a, Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
+            if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+            else frag_zero(bq);
+            acc = mma(a, bq, acc);
+        }
+        if (l15 < FL_TT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = mt * 16 + 4 * g4 + r;
+                if (k < F) store1(z + ((size_t)k * FL_TT + l15) * FL_SQ + ch, acc[r] + bfull[ch * F + k]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- p3: recompute y_pre, dy_pre, dz = Wu^T dy_pre (dz overwrites s) ----
+    {
+        Frag<T> a[FL_MT], at[FL_KS];
+#pragma unroll
+        for (int mt = 0; mt < FL_MT; ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
+#pragma unroll
+        for (int ks = 0; ks < FL_KS; ++ks) wfrag_load(at[ks], WusqT, 0, FL_KS, ks);
+        for (int nt = w; nt < ntile; nt += nw) {
+            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const bool valid = f < F && t0 + tt < T_;
+            const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
+            Frag<T> bq;
+            if (g4 == 0 && f < F) {
+                frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
+                if (valid) {
+                    float zv[8];
+                    load8(z + ((size_t)f * FL_TT + tt) * FL_SQ, zv);
+                    store4(z_out + n * FL_SQ, zv[0], zv[1], zv[2], zv[3]);
+                    store4(z_out + n * FL_SQ + 4, zv[4], zv[5], zv[6], zv[7]);
+                }
+            } else {
+                frag_zero(bq);
+            }
+            f32x4 dyp[FL_MT];
+#pragma unroll
+            for (int mt = 0; mt < FL_MT; ++mt) {
+                const f32x4 acc = mma(a[mt], bq, F32X4_ZERO);
+                const int ch = 16 * mt + 4 * g4;
+                float dv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (valid) load4(dy + n * FL_H + ch, dv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dyp[mt][r] = valid ? dv[r] * dsilu_f(acc[r] + bu[ch + r]) : 0.f;
+                if (valid) store4(dyp_out + n * FL_H + ch, dyp[mt][0], dyp[mt][1], dyp[mt][2], dyp[mt][3]);
+            }
+            f32x4 dzt = F32X4_ZERO;
+#pragma unroll
+            for (int ks = 0; ks < FL_KS; ++ks) {
+                Frag<T> df;
+                frag_from_c2(df, dyp[2 * ks], dyp[2 * ks + 1]);
+                dzt = mma(at[ks], df, dzt);
+            }
+            if (valid && g4 < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = 4 * g4 + r;
+                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, dzt[r]);
+                    store1(dz_out + (((size_t)b * T_ + t0 + tt) * FL_SQ + ch) * FKP + f, dzt[r]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- p4: ds = Wf^T dz ; ds_pre = ds * SiLU'(s_pre)  (ds_pre overwrites z) ----
+    for (int task = w; task < FL_SQ * mtf; task += nw) {
+        const int ch = task / mtf, mt = task % mtf;
+        f32x4 acc = F32X4_ZERO;
+        for (int ks = 0; ks < ksf; ++ks) {
+            Frag<T> a, bq;
+            wfrag_load(a, WfullT + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
+            if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+            else frag_zero(bq);
+            acc = mma(a, bq, acc);
+        }
+        if (l15 < FL_TT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = mt * 16 + 4 * g4 + r;
+                if (h < F) {
+                    const float pre = load1(sp + ((size_t)h * FL_TT + l15) * FL_SQ + ch);
+                    store1(z + ((size_t)h * FL_TT + l15) * FL_SQ + ch, acc[r] * dsilu_f(pre));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- p5: du = Ws^T ds_pre, LayerNorm backward + residual ----
+    {
+        Frag<T> a[FL_MT];
+#pragma unroll
+        for (int mt = 0; mt < FL_MT; ++mt) wfrag_load(a[mt], WsqT, mt, 1, 0);
+        float dlw[BK_MT][4], dlb[BK_MT][4];
+#pragma unroll
+        for (int mt = 0; mt < BK_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dlw[mt][r] = dlb[mt][r] = 0.f;
+        for (int nt = w; nt < ntile; nt += nw) {
+            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const bool valid = f < F && t0 + tt < T_;
+            const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
+            Frag<T> bq;
+            if (g4 == 0 && valid) {
+                frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
+                float dv[8];
+                load8(z + ((size_t)f * FL_TT + tt) * FL_SQ, dv);
+                store4(dsp_out + n * FL_SQ, dv[0], dv[1], dv[2], dv[3]);
+                store4(dsp_out + n * FL_SQ + 4, dv[4], dv[5], dv[6], dv[7]);
+            } else {
+                frag_zero(bq);
+            }
+            f32x4 du[BK_MT];
+#pragma unroll
+            for (int mt = 0; mt < FL_MT; ++mt) du[mt] = mma(a[mt], bq, F32X4_ZERO);
+            ln_bwd_row96<T>(du, x + n * FL_H, dy + n * FL_H, dx + n * FL_H, stats + n * 2, valid, lnw, dlw, dlb);
+        }
+        ln_affine_flush(dlw, dlb, G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B));
+    }
+}
+
+template <class T>
+static int full_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                      float* stats, void* const* o, hipStream_t st) {
+    const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
+    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T);
+    const T* pk = (const T*)packed;
+    int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T>), lds);
+    if (e) return e;
+    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
+    NBSS_LAUNCH((full_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
+                pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
+                (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4]);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int memset_async_impl(void* p, size_t bytes, hipStream_t st);
+
+int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx, void* ws,
+                  hipStream_t st) {
+    // workspace: stats | s [B*T][SQ][FKP] | dz [B*T][SQ][FKP] | z [N][SQ] | dy_pre [N][H] | ds_pre [N][SQ]
+    const size_t N = (size_t)c.B * c.F * c.T, BT = (size_t)c.B * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    const int FKP = FL_FKP(c.F);
+    float* stats = (float*)ws;
+    char* p = (char*)ws + ws_align(N * 2 * sizeof(float));
+    void* o[5];
+    o[0] = p; p += ws_align(BT * FL_SQ * FKP * esz);
+    o[1] = p; p += ws_align(BT * FL_SQ * FKP * esz);
+    o[2] = p; p += ws_align(N * FL_SQ * esz);
+    o[3] = p; p += ws_align(N * FL_H * esz);
+    o[4] = p;
+    // the F..FKP padding columns of s / dz are read by the wgrad staging: keep them zero
+    int e = memset_async_impl(o[0], 2 * ws_align(BT * FL_SQ * FKP * esz), st);
+    if (e) return e;
+    e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t>(c, P, G, packed, layer, x, dy, dx, stats, o, st)
+                             : full_bwd_t<float>(c, P, G, packed, layer, x, dy, dx, stats, o, st);
+    if (e) return e;
+    WgradArgs a;
+    a.mvalid = 0; a.nvalid = 0;
+    a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.taps = 1;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    // unsqueeze: dWu[H][SQ] = dy_pre^T z ; dbu = colsum(dy_pre)
+    a.Ntok = (int)N; a.groups = 1;
+    a.A = o[3]; a.lda = FL_H; a.MA = FL_H; a.B = o[2]; a.ldb = FL_SQ; a.NB = FL_SQ;
+    a.dW = G + param_off(c, layer, P_USQ_W); a.dbias = G + param_off(c, layer, P_USQ_B);
+    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    // LinearGroup: dWf[c][k][h] = sum_{b,t} dz[b,t,c,k] s[b,t,c,h] ; dbf = colsum(dz)   (rows = (b,t))
+    a.Ntok = (int)BT; a.groups = FL_SQ; a.mvalid = c.F; a.nvalid = c.F;
+    a.A = o[1]; a.lda = FL_SQ * FKP; a.MA = FL_SQ * FKP; a.B = o[0]; a.ldb = FL_SQ * FKP; a.NB = FL_SQ * FKP;
+    a.dW = G + param_off(c, layer, P_FULL_W); a.dbias = G + param_off(c, layer, P_FULL_B);
+    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    // squeeze: dWs[SQ][H] = ds_pre^T LN(x) ; dbs = colsum(ds_pre)
+    a.Ntok = (int)N; a.groups = 1; a.mvalid = 0; a.nvalid = 0;
+    a.A = o[4]; a.lda = FL_SQ; a.MA = FL_SQ; a.B = x; a.ldb = FL_H; a.NB = FL_H;
+    a.stats = stats; a.gamma = P + param_off(c, layer, P_FULL_LN_W); a.beta = P + param_off(c, layer, P_FULL_LN_B);
+    a.dW = G + param_off(c, layer, P_SQ_W); a.dbias = G + param_off(c, layer, P_SQ_B);
+    return wgrad_launch(a, c.dtype, st);
 }
 
 template <class T>

@@ -380,6 +380,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
                                  : mhsa_bwd_t<float>(c, P, G, packed, layer, x, dy, osave, dx, stats, dqkv, st);
     if (e) return e;
     WgradArgs a;
+    a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
     // out_proj: dWo[H][H] = dy^T O ; dbo = colsum(dy)
     a.A = dy; a.lda = MB_H; a.MA = MB_H; a.B = osave; a.ldb = MB_H; a.NB = MB_H;

@@ -722,6 +722,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
                                  : tconvffn_bwd_t<float>(c, P, G, packed, layer, x, dy, dx, stats, ops, st);
     if (e) return e;
     WgradArgs a;
+    a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     NBSS_LDS(smem);
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
+    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
     const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
     const int tiles_per_group = mtiles * ntiles;
     const int TPB = WG_WAVES * WG_TPW;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mt * 16 + 4 * g4 + r;
-                    if (m < mg) atomicAdd(a.dW + ((size_t)(grp * mg + m) * ng + i) * a.taps + tap, acc[s][r]);
+                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(grp * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
                 }
             }
         }
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int col = tid + q * 256;
-            if (col < ncolsA) atomicAdd(a.dbias + acols0 + col, bsum[q]);
+            if (col < ncolsA && (col % mg) < mv) atomicAdd(a.dbias + (size_t)((acols0 + col) / mg) * mv + (col % mg), bsum[q]);
         }
     }
 }

@@ -124,6 +124,32 @@ def tconvffn_bwd(lib, cfg, flat, grads, packed, layer, x, dy, ws):
     return dx
 
 
+def fconv_bwd(lib, cfg, flat, grads, packed, layer, which, x, dy, ws):
+    dx = torch.empty_like(x)
+    lib.call("nbss_fconv_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed), layer, which,
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, dx), _ptr(lib, ws), _stream(lib, x))
+    return dx
+
+
+def full_bwd(lib, cfg, flat, grads, packed, layer, x, dy, ws):
+    dx = torch.empty_like(x)
+    lib.call("nbss_full_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed), layer,
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, dx), _ptr(lib, ws), _stream(lib, x))
+    return dx
+
+
+def decoder_bwd(lib, cfg, flat, grads, packed, x, dout, ws):
+    dx = torch.empty_like(x)
+    lib.call("nbss_decoder_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed),
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dout, torch.float32), _ptr(lib, dx), _ptr(lib, ws), _stream(lib, x))
+    return dx
+
+
+def encoder_bwd(lib, cfg, grads, xin, dy):
+    lib.call("nbss_encoder_bwd", C.byref(cfg), _ptr(lib, grads, torch.float32), _ptr(lib, xin, stream_dtype(cfg)),
+             _ptr(lib, dy, stream_dtype(cfg)), _stream(lib, xin))
+
+
 def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:
     D = torch.empty(16, 16, dtype=torch.float32, device=A.device)
     lib.call("nbss_selftest_mma", dtype, kperm, _ptr(lib, A, torch.float32), _ptr(lib, B, torch.float32), _ptr(lib, D), _stream(lib, A))

@@ -48,7 +48,7 @@ def check_param_grads(cs, G, want, tol):
     assert not bad, bad
 
 
-def run_block_bwd(backend, dtype, B, F, T, fwd_ref, bwd_op, names, seed):
+def run_block_bwd(backend, dtype, B, F, T, fwd_ref, bwd_op, names, seed, bf16_tol=3e-2):
     cs = Case(backend, B, F, T, dtype)
     x, x64 = cs.stream(seed=seed)
     dy, dy64 = cs.stream(seed=seed + 100, scale=0.5)
@@ -56,7 +56,7 @@ def run_block_bwd(backend, dtype, B, F, T, fwd_ref, bwd_op, names, seed):
     ws = ops.workspace(cs.lib, cs.cfg, backend.device)
     dx = bwd_op(cs, G, x, dy, ws)
     want_dx, want_g = oracle_grads(lambda xx, pp: fwd_ref(xx, pp), x64, cs.p64, dy64, names)
-    tol = 1e-4 if dtype == NBSS_F32 else 3e-2
+    tol = 1e-4 if dtype == NBSS_F32 else bf16_tol
     assert rel_l2(dx, want_dx) < tol, ("dx", rel_l2(dx, want_dx))
     assert rel_l2(dx.double().cpu() - dy64, want_dx - dy64) < 3 * tol  # the branch gradient itself
     check_param_grads(cs, G, want_g, tol)
@@ -88,3 +88,49 @@ def test_mhsa_bwd(backend, dtype):
             return ops.mhsa_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, o, ws)
 
         run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.mhsa(x, p, "layers.0"), bwd, MH_NAMES, seed=30)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("which", [0, 1])
+def test_fconv_bwd(backend, dtype, which):
+    pre = f"layers.0.fconv{which + 1}"
+    names = [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.1.weight", f"{pre}.1.bias", f"{pre}.2.weight"]
+    for (B, F, T) in shapes_for(backend):
+        run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.fconv(x, p, pre),
+                      lambda cs, G, x, dy, ws: ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, which, x, dy, ws), names, seed=40 + which,
+                      bf16_tol=8e-2)  # PReLU kink: bf16 rounding flips the sign of ~1% of the pre-activations
+
+
+FULL_NAMES = ["layers.0.norm_full.weight", "layers.0.norm_full.bias", "layers.0.squeeze.0.weight", "layers.0.squeeze.0.bias",
+              "layers.0.full.weight", "layers.0.full.bias", "layers.0.unsqueeze.0.weight", "layers.0.unsqueeze.0.bias"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_full_bwd(backend, dtype):
+    for (B, F, T) in shapes_for(backend):
+        run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.full(x, p, "layers.0"),
+                      lambda cs, G, x, dy, ws: ops.full_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws), FULL_NAMES, seed=50)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_encoder_decoder_bwd(backend, dtype):
+    for (B, F, T) in shapes_for(backend):
+        cs = Case(backend, B, F, T, dtype)
+        tol = 1e-4 if dtype == NBSS_F32 else 3e-2
+        ws = ops.workspace(cs.lib, cs.cfg, backend.device)
+        # decoder
+        x, x64 = cs.stream(seed=60)
+        g = torch.Generator().manual_seed(61)
+        dout = torch.randn(B, F, T, 4, generator=g)
+        G = torch.zeros_like(cs.flat)
+        dx = ops.decoder_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, x, dout.to(backend.device), ws)
+        want_dx, want_g = oracle_grads(lambda xx, pp: ref.decoder(xx, pp), x64, cs.p64, dout.double(), ["decoder.weight", "decoder.bias"])
+        assert rel_l2(dx, want_dx) < tol
+        check_param_grads(cs, G, want_g, tol)
+        # encoder (parameter gradients only)
+        xin, xin64 = cs.stream(seed=62, H=12)
+        dy, dy64 = cs.stream(seed=63)
+        G = torch.zeros_like(cs.flat)
+        ops.encoder_bwd(cs.lib, cs.cfg, G, xin, dy)
+        _, want_g = oracle_grads(lambda xx, pp: ref.encoder(xx, pp), xin64, cs.p64, dy64, ["encoder.weight", "encoder.bias"])
+        check_param_grads(cs, G, want_g, tol)
