@@ -106,6 +106,55 @@ int nbss_decoder_bwd(const nbss_cfg* cfg, const float* params, float* grads, con
 /* encoder: weight/bias gradient only (the network input needs none); dy = gradient of the encoder output */
 int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const void* dy, void* stream);
 
+/* ---- whole network (SpatialNet.forward, SpatialNet.py:202-220, and its autograd) ---------------
+ * Native sequencing of the sub-block kernels: encoder, L x [fconv1, full, fconv2, mhsa, tconvffn],
+ * decoder.  xin [B,F,T,C_in] of cfg->dtype, out/dout [B,F,T,C_out] fp32.
+ * acts: nbss_acts_bytes() bytes holding the 5L+1 block inputs and the L attention outputs that
+ * backward re-reads; pass NULL for inference (then ws, >= nbss_train_ws_bytes(), is used as two
+ * ping-pong stream buffers).  Backward accumulates into `grads` and needs ws >= nbss_train_ws_bytes(). */
+int64_t nbss_acts_bytes(const nbss_cfg* cfg);
+int64_t nbss_train_ws_bytes(const nbss_cfg* cfg);
+int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* xin, void* acts, void* ws, float* out,
+                        void* stream);
+int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
+                        const float* dout, void* ws, void* stream);
+
+/* ---- signal front / back end (always fp32 arithmetic) ------------------------------------------
+ * n_fft in {256, 512}, hop = n_fft/2, win_len = n_fft; window 0 = periodic hann, 1 = sqrt-hann
+ * (models/io/stft.py:23-35).  `tables` = windowed DFT matrices packed as MFMA fragments, built once
+ * per (n_fft, window) into caller memory of nbss_stft_tables_bytes() bytes. */
+int64_t nbss_stft_tables_bytes(int n_fft);
+int nbss_stft_tables(int n_fft, int window, float* tables, void* stream);
+/* STFT.stft (stft.py:49-66) + Norm('frequency', online=True).norm (norm.py:77-81,94) + the
+ * [B,C,F,T] complex -> [B,F,T,2C] real re-layout of TrainModule.forward (SharedTrainer.py:113-117).
+ * x [B,C,N] fp32 -> X [B,F,T,2C] of `dtype` (T = N/hop + 1), xrmm [B,F,T] fp32 = |X_ref| + 1e-6. */
+int nbss_stft_norm_fwd(int n_fft, int dtype, int B, int C, int N, int ref_channel, const float* tables, const float* x, void* X, float* xrmm,
+                       void* stream);
+/* Norm.inorm (norm.py:97-108) + STFT.istft (stft.py:68-97): out [B,F,T,2S] fp32 -> y [B,S,N].
+ * ws: nbss_istft_ws_bytes() bytes of scratch (overlap-add buffer). */
+int64_t nbss_istft_ws_bytes(int n_fft, int B, int S, int N);
+int nbss_inorm_istft_fwd(int n_fft, int B, int S, int N, const float* tables, const float* out, const float* xrmm, float* ws, float* y,
+                         void* stream);
+/* adjoint: dy [B,S,N] -> dout [B,F,T,2S] */
+int nbss_inorm_istft_bwd(int n_fft, int B, int S, int N, const float* tables, const float* dy, const float* xrmm, float* dout, void* stream);
+
+/* Loss(neg_si_sdr, pit=True).forward (models/io/loss.py:21-29,95-118; torchmetrics si_sdr + pit
+ * 'permutation-wise'/'min').  preds/target [B,S,N] fp32.  loss: 1 float (mean over the batch),
+ * perm [B,S] (prediction index paired with target s), dpreds (optional) = d loss / d preds.
+ * ws: nbss_pit_ws_bytes() bytes. */
+int64_t nbss_pit_ws_bytes(int B, int S);
+int nbss_pit_neg_sisdr(int B, int S, int N, const float* preds, const float* target, float* loss, int32_t* perm, float* dpreds, float* ws,
+                       void* stream);
+
+/* clip_grad_norm_(max_norm, L2) + torch.optim.Adam(W) step on the flat fp32 buffers
+ * (configs/SpatialNet.yaml:3-4,44; general_steps.py:243-271).  grads are first multiplied by
+ * grad_scale (1/world_size after a SUM all-reduce).  scratch: >= 258 floats; scratch[0] returns the
+ * (scaled) gradient norm.  step counts from 1.  zero_grad != 0 clears grads for the next step.
+ * weight_decay follows torch.optim.Adam (L2 added to the gradient). */
+int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* scratch, float max_norm,
+                        float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
+                        void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */

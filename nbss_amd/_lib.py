@@ -57,6 +57,19 @@ SIGNATURES = {
     "nbss_full_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "nbss_decoder_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nbss_encoder_bwd": (_I, [_CP, _P, _P, _P, _P]),
+    "nbss_acts_bytes": (C.c_int64, [_CP]),
+    "nbss_train_ws_bytes": (C.c_int64, [_CP]),
+    "nbss_spatialnet_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_spatialnet_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_stft_tables_bytes": (C.c_int64, [_I]),
+    "nbss_stft_tables": (_I, [_I, _I, _P, _P]),
+    "nbss_stft_norm_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "nbss_istft_ws_bytes": (C.c_int64, [_I, _I, _I, _I]),
+    "nbss_inorm_istft_fwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "nbss_inorm_istft_bwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "nbss_pit_ws_bytes": (C.c_int64, [_I, _I]),
+    "nbss_pit_neg_sisdr": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_clip_adam_step": (_I, [C.c_int64, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),
     "nbss_build_info": (C.c_char_p, []),
 }

@@ -25,6 +25,16 @@ int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pa
                      hipStream_t st);
 int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, hipStream_t st);
 
+size_t stft_tables_bytes_impl(int nfft);
+int stft_tables_impl(int nfft, int win_kind, float* tab, hipStream_t st);
+int stft_norm_impl(int nfft, int dtype, int B, int C, int N, int ref, const float* tab, const float* x, void* X, float* xrmm, hipStream_t st);
+int inorm_istft_impl(int nfft, int B, int S, int N, const float* tab, const float* out, const float* xrmm, float* ybuf, float* y, hipStream_t st);
+int inorm_istft_bwd_impl(int nfft, int B, int S, int N, const float* tab, const float* dy, const float* xrmm, float* dout, hipStream_t st);
+size_t pit_ws_floats(int B, int S);
+int pit_sisdr_impl(int B, int S, int N, const float* p, const float* t, float* loss, int* perm, float* dp, float* ws, hipStream_t st);
+int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal, float max_norm, float grad_scale, float lr, float beta1,
+                   float beta2, float eps, float wd, int step, int zero_grad, hipStream_t st);
+
 #define CHECK_CFG(cfg)                         \
     if (!(cfg)) return NBSS_EINVAL;            \
     {                                          \
@@ -159,6 +169,125 @@ int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const v
     CHECK_CFG(cfg);
     if (!grads || !xin || !dy) return NBSS_EINVAL;
     return encoder_bwd_impl(*cfg, grads, xin, dy, (hipStream_t)stream);
+}
+
+// ---- whole network: native sequencing of the sub-block kernels (one C call per direction) --------
+static size_t stream_bytes(const nbss_cfg& c) {
+    return ws_align((size_t)c.B * c.F * c.T * c.H * (c.dtype == NBSS_BF16 ? 2 : 4));
+}
+
+int64_t nbss_acts_bytes(const nbss_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
+    return (int64_t)((size_t)(6 * cfg->L + 1) * stream_bytes(*cfg));
+}
+
+int64_t nbss_train_ws_bytes(const nbss_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
+    return (int64_t)(workspace_bytes(*cfg) + 2 * stream_bytes(*cfg));
+}
+
+int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* xin, void* acts, void* ws, float* out,
+                        void* stream) {
+    CHECK_CFG(cfg);
+    if (!params || !packed || !xin || !out || (!acts && !ws)) return NBSS_EINVAL;
+    const nbss_cfg& c = *cfg;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sb = stream_bytes(c);
+    // training: every block input is kept (acts = [5L+1 stream copies | L attention outputs]);
+    // inference: two ping-pong buffers at the tail of ws
+    char* pp = acts ? nullptr : (char*)ws + workspace_bytes(c);
+    int k = 0;
+    auto buf = [&](int i) -> void* { return acts ? (void*)((char*)acts + (size_t)i * sb) : (void*)(pp + (size_t)(i & 1) * sb); };
+    int e = encoder_fwd_impl(c, params, packed, xin, buf(0), st);
+    if (e) return e;
+    for (int l = 0; l < c.L; ++l) {
+        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1 + l) * sb) : nullptr;
+        if ((e = fconv_fwd_impl(c, params, packed, l, 0, buf(k), buf(k + 1), st))) return e;
+        if ((e = full_fwd_impl(c, params, packed, l, buf(k + 1), buf(k + 2), st))) return e;
+        if ((e = fconv_fwd_impl(c, params, packed, l, 1, buf(k + 2), buf(k + 3), st))) return e;
+        if ((e = mhsa_fwd_impl(c, params, packed, l, buf(k + 3), buf(k + 4), osave, st))) return e;
+        if ((e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), st))) return e;
+        k += 5;
+    }
+    return decoder_fwd_impl(c, params, packed, buf(k), out, st);
+}
+
+int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
+                        const float* dout, void* ws, void* stream) {
+    CHECK_CFG(cfg);
+    if (!params || !grads || !packed || !xin || !acts || !dout || !ws) return NBSS_EINVAL;
+    const nbss_cfg& c = *cfg;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sb = stream_bytes(c);
+    auto act = [&](int i) -> const void* { return (const char*)acts + (size_t)i * sb; };
+    char* gb = (char*)ws + workspace_bytes(c);
+    void* dA = gb;
+    void* dB = gb + sb;
+    int k = 5 * c.L;
+    int e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, dA, ws, st);
+    if (e) return e;
+    for (int l = c.L - 1; l >= 0; --l) {
+        const void* osave = act(5 * c.L + 1 + l);
+        if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), dA, dB, ws, st))) return e;
+        if ((e = mhsa_bwd_impl(c, params, grads, packed, l, act(k - 2), dB, osave, dA, ws, st))) return e;
+        if ((e = fconv_bwd_impl(c, params, grads, packed, l, 1, act(k - 3), dA, dB, ws, st))) return e;
+        if ((e = full_bwd_impl(c, params, grads, packed, l, act(k - 4), dB, dA, ws, st))) return e;
+        if ((e = fconv_bwd_impl(c, params, grads, packed, l, 0, act(k - 5), dA, dB, ws, st))) return e;
+        void* t = dA; dA = dB; dB = t;
+        k -= 5;
+    }
+    return encoder_bwd_impl(c, grads, xin, dA, st);
+}
+
+int64_t nbss_stft_tables_bytes(int n_fft) {
+    if (n_fft != 256 && n_fft != 512) return -1;
+    return (int64_t)stft_tables_bytes_impl(n_fft);
+}
+
+int nbss_stft_tables(int n_fft, int window, float* tables, void* stream) {
+    if (!tables || (window != 0 && window != 1)) return NBSS_EINVAL;
+    return stft_tables_impl(n_fft, window, tables, (hipStream_t)stream);
+}
+
+int nbss_stft_norm_fwd(int n_fft, int dtype, int B, int C, int N, int ref_channel, const float* tables, const float* x, void* X, float* xrmm,
+                       void* stream) {
+    if (!tables || !x || !X || !xrmm || B <= 0 || C <= 0 || (dtype != NBSS_F32 && dtype != NBSS_BF16)) return NBSS_EINVAL;
+    return stft_norm_impl(n_fft, dtype, B, C, N, ref_channel, tables, x, X, xrmm, (hipStream_t)stream);
+}
+
+int64_t nbss_istft_ws_bytes(int n_fft, int B, int S, int N) {
+    if (n_fft <= 0 || B <= 0 || S <= 0 || N <= 0) return -1;
+    return (int64_t)B * S * ((int64_t)(N / (n_fft / 2) + 2) * (n_fft / 2)) * (int64_t)sizeof(float);
+}
+
+int nbss_inorm_istft_fwd(int n_fft, int B, int S, int N, const float* tables, const float* out, const float* xrmm, float* ws, float* y,
+                         void* stream) {
+    if (!tables || !out || !xrmm || !ws || !y || B <= 0 || S <= 0 || N < n_fft) return NBSS_EINVAL;
+    return inorm_istft_impl(n_fft, B, S, N, tables, out, xrmm, ws, y, (hipStream_t)stream);
+}
+
+int nbss_inorm_istft_bwd(int n_fft, int B, int S, int N, const float* tables, const float* dy, const float* xrmm, float* dout, void* stream) {
+    if (!tables || !dy || !xrmm || !dout || B <= 0 || S <= 0 || N < n_fft) return NBSS_EINVAL;
+    return inorm_istft_bwd_impl(n_fft, B, S, N, tables, dy, xrmm, dout, (hipStream_t)stream);
+}
+
+int64_t nbss_pit_ws_bytes(int B, int S) {
+    if (B <= 0 || S <= 0) return -1;
+    return (int64_t)pit_ws_floats(B, S) * (int64_t)sizeof(float);
+}
+
+int nbss_pit_neg_sisdr(int B, int S, int N, const float* preds, const float* target, float* loss, int32_t* perm, float* dpreds, float* ws,
+                       void* stream) {
+    if (!preds || !target || !loss || !perm || !ws || N <= 0) return NBSS_EINVAL;
+    return pit_sisdr_impl(B, S, N, preds, target, loss, perm, dpreds, ws, (hipStream_t)stream);
+}
+
+int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* scratch, float max_norm,
+                        float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
+                        void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n <= 0) return NBSS_EINVAL;
+    return clip_adam_impl((size_t)n, params, grads, exp_avg, exp_avg_sq, scratch, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
+                          zero_grad, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

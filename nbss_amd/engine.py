@@ -1,0 +1,154 @@
+"""Host-side engine: owns the flat parameter / gradient / optimizer buffers, the packed MFMA weight
+fragments, the saved activations and the workspace for one (B, F, T) geometry, and sequences the C-ABI
+calls of a full training step (SharedTrainer.py:104-149 + general_steps.py:243-271 semantics):
+
+    stft+norm -> SpatialNet fwd -> inorm+istft -> uPIT neg-SI-SDR (+grad) -> istft adjoint
+    -> SpatialNet bwd -> [RCCL all-reduce of the flat fp32 gradient] -> clip + Adam -> re-pack weights
+
+torch provides device memory, streams and torch.distributed only; every arithmetic step is a HIP kernel
+behind include/nbss_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import NBSS_BF16, NBSS_F32, Cfg, Lib, NbssError, make_cfg
+from .params import param_table
+
+
+class SpatialNetEngine:
+    def __init__(self, lib: Lib, device, *, dim_input: int, dim_output: int, num_freqs: int, num_layers: int = 8, dim_hidden: int = 96,
+                 dim_ffn: int = 192, dim_squeeze: int = 8, num_heads: int = 4, encoder_kernel_size: int = 5, kernel_size=(5, 3),
+                 conv_groups=(8, 8), full_share: int = 0, dtype: int = NBSS_BF16):
+        self.lib, self.device = lib, torch.device(device)
+        self.kw = dict(C_in=dim_input, C_out=dim_output, H=dim_hidden, FFN=dim_ffn, SQ=dim_squeeze, L=num_layers, heads=num_heads,
+                       enc_ks=encoder_kernel_size, f_ks=kernel_size[0], t_ks=kernel_size[1], f_groups=conv_groups[0], t_groups=conv_groups[1],
+                       full_share=full_share)
+        self.num_freqs = num_freqs
+        self.dtype = dtype
+        cfg0 = self.cfg_for(1, 16)
+        n = lib.nbss_param_count(C.byref(cfg0))
+        if n <= 0:
+            raise NbssError("this SpatialNet configuration has no HIP kernels in this build (SpatialNet-small geometry only)")
+        self.table = param_table(lib, cfg0)
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.packed: Dict[int, Tensor] = {}
+        self._packed_version = -1
+        self.version = 0  # bump whenever params change
+        self._geom: Optional[Tuple[int, int, int]] = None
+        self.acts = self.ws = None
+
+    # ---- configuration / buffers -------------------------------------------------------------
+    def cfg_for(self, B: int, T: int, dtype: Optional[int] = None) -> Cfg:
+        return make_cfg(B, self.num_freqs, T, dtype=self.dtype if dtype is None else dtype, **self.kw)
+
+    def stream_dtype(self, dtype: Optional[int] = None) -> torch.dtype:
+        return torch.bfloat16 if (self.dtype if dtype is None else dtype) == NBSS_BF16 else torch.float32
+
+    def load_params(self, p: Dict[str, Tensor]) -> None:
+        self.params.copy_(ops.flatten_params(self.lib, self.cfg_for(1, 16), p, self.device))
+        self.version += 1
+
+    def param_views(self, flat: Tensor) -> Dict[str, Tensor]:
+        return {name: flat[off:off + _numel(shape)].view(shape) for name, (off, shape) in self.table.items()}
+
+    def packed_for(self, dtype: int) -> Tensor:
+        if self._packed_version != self.version:
+            self.packed.clear()
+            self._packed_version = self.version
+        if dtype not in self.packed:
+            self.packed[dtype] = ops.pack_params(self.lib, self.cfg_for(1, 16, dtype), self.params)
+        return self.packed[dtype]
+
+    def ensure_geometry(self, B: int, T: int, train: bool, dtype: int) -> Cfg:
+        cfg = self.cfg_for(B, T, dtype)
+        key = (B, T, dtype, train)
+        if self._geom != key:
+            self.ws = torch.empty(self.lib.nbss_train_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+            self.acts = torch.empty(self.lib.nbss_acts_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device) if train else None
+            self._geom = key
+        return cfg
+
+    # ---- network ---------------------------------------------------------------------------------
+    def forward(self, xin: Tensor, train: bool, dtype: Optional[int] = None) -> Tensor:
+        """xin [B,F,T,C_in] (stream dtype) -> out [B,F,T,C_out] fp32.  train=True keeps the block inputs."""
+        dtype = self.dtype if dtype is None else dtype
+        B, F, T, _ = xin.shape
+        cfg = self.ensure_geometry(B, T, train, dtype)
+        out = torch.empty(B, F, T, cfg.C_out, dtype=torch.float32, device=xin.device)
+        lib = self.lib
+        lib.call("nbss_spatialnet_fwd", C.byref(cfg), ops._ptr(lib, self.params), ops._ptr(lib, self.packed_for(dtype)),
+                 ops._ptr(lib, xin, self.stream_dtype(dtype)), ops._ptr(lib, self.acts), ops._ptr(lib, self.ws), ops._ptr(lib, out),
+                 ops._stream(lib, xin))
+        return out
+
+    def backward(self, xin: Tensor, dout: Tensor, dtype: Optional[int] = None) -> None:
+        """accumulates parameter gradients of the LAST train-mode forward into self.grads"""
+        dtype = self.dtype if dtype is None else dtype
+        B, F, T, _ = xin.shape
+        if self._geom != (B, T, dtype, True):
+            raise NbssError("backward() needs a preceding forward(train=True) with the same geometry")
+        cfg = self.cfg_for(B, T, dtype)
+        lib = self.lib
+        lib.call("nbss_spatialnet_bwd", C.byref(cfg), ops._ptr(lib, self.params), ops._ptr(lib, self.grads), ops._ptr(lib, self.packed_for(dtype)),
+                 ops._ptr(lib, xin, self.stream_dtype(dtype)), ops._ptr(lib, self.acts), ops._ptr(lib, dout, torch.float32), ops._ptr(lib, self.ws),
+                 ops._stream(lib, xin))
+
+
+def _numel(shape) -> int:
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class TrainStep:
+    """One full SpatialNet training step on the HIP path (the unit bench.py times)."""
+
+    def __init__(self, engine: SpatialNetEngine, *, n_fft: int = 256, ref_channel: int = 0, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, clip: float = 5.0, process_group=None):
+        self.e = engine
+        self.lib = engine.lib
+        self.n_fft, self.ref = n_fft, ref_channel
+        self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
+        self.tables = ops.stft_tables(self.lib, n_fft, 0, engine.device)
+        self.m = torch.zeros_like(engine.params)
+        self.v = torch.zeros_like(engine.params)
+        self.scratch = torch.zeros(512, dtype=torch.float32, device=engine.device)
+        self.step_count = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+
+    def forward_loss(self, x: Tensor, yr: Tensor, need_grad: bool = True):
+        """x [B,C,N] fp32 mixture, yr [B,S,N] fp32 targets -> (loss [1], yr_hat [B,S,N], dout or None, xin, xrmm)"""
+        e, lib = self.e, self.lib
+        N = x.shape[-1]
+        xin, xrmm = ops.stft_norm_fwd(lib, self.n_fft, e.dtype, self.tables, x, self.ref)
+        out = e.forward(xin, train=need_grad)
+        yr_hat = ops.inorm_istft_fwd(lib, self.n_fft, self.tables, out, xrmm, N)
+        loss, perm, dyh = ops.pit_neg_sisdr(lib, yr_hat, yr, need_grad=need_grad)
+        dout = ops.inorm_istft_bwd(lib, self.n_fft, self.tables, dyh, xrmm) if need_grad else None
+        return loss, yr_hat, dout, xin, perm
+
+    def step(self, x: Tensor, yr: Tensor) -> Tensor:
+        """forward + backward + (all-reduce) + clip + Adam + re-pack; returns the loss (device tensor [1])"""
+        e = self.e
+        loss, _, dout, xin, _ = self.forward_loss(x, yr, need_grad=True)
+        e.backward(xin, dout)
+        if self.world > 1:
+            # data parallel: ONE all-reduce (SUM) of the flat fp32 gradient over RCCL; the mean is folded into the clip kernel
+            torch.distributed.all_reduce(e.grads, group=self.pg)
+        self.step_count += 1
+        ops.clip_adam_step(self.lib, e.params, e.grads, self.m, self.v, self.scratch, self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
+                           weight_decay=self.wd, max_norm=self.clip, grad_scale=1.0 / self.world, zero_grad=True)
+        e.version += 1
+        e.packed_for(e.dtype)  # re-pack inside the step: the next forward needs fresh fragments
+        return loss

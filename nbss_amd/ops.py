@@ -150,6 +150,66 @@ def encoder_bwd(lib, cfg, grads, xin, dy):
              _ptr(lib, dy, stream_dtype(cfg)), _stream(lib, xin))
 
 
+def stft_tables(lib, n_fft: int, window: int, device) -> Tensor:
+    nb = lib.nbss_stft_tables_bytes(n_fft)
+    if nb <= 0:
+        raise NbssError(f"n_fft={n_fft} is not supported (256 or 512)")
+    tab = torch.empty(nb // 4, dtype=torch.float32, device=device)
+    lib.call("nbss_stft_tables", n_fft, window, _ptr(lib, tab), _stream(lib, tab))
+    return tab
+
+
+def stft_norm_fwd(lib, n_fft, dtype, tables, x, ref_channel):
+    """x [B,C,N] fp32 -> (X [B,F,T,2C] stream dtype, xrmm [B,F,T] fp32)"""
+    B, Cc, N = x.shape
+    F, T = n_fft // 2 + 1, N // (n_fft // 2) + 1
+    X = torch.empty(B, F, T, 2 * Cc, dtype=torch.bfloat16 if dtype == NBSS_BF16 else torch.float32, device=x.device)
+    xrmm = torch.empty(B, F, T, dtype=torch.float32, device=x.device)
+    lib.call("nbss_stft_norm_fwd", n_fft, dtype, B, Cc, N, ref_channel, _ptr(lib, tables), _ptr(lib, x, torch.float32), _ptr(lib, X), _ptr(lib, xrmm),
+             _stream(lib, x))
+    return X, xrmm
+
+
+def inorm_istft_fwd(lib, n_fft, tables, out, xrmm, N):
+    """out [B,F,T,2S] fp32 -> y [B,S,N] fp32"""
+    B, F, T, S2 = out.shape
+    S = S2 // 2
+    ws = torch.empty(lib.nbss_istft_ws_bytes(n_fft, B, S, N) // 4, dtype=torch.float32, device=out.device)
+    y = torch.empty(B, S, N, dtype=torch.float32, device=out.device)
+    lib.call("nbss_inorm_istft_fwd", n_fft, B, S, N, _ptr(lib, tables), _ptr(lib, out, torch.float32), _ptr(lib, xrmm, torch.float32), _ptr(lib, ws),
+             _ptr(lib, y), _stream(lib, out))
+    return y
+
+
+def inorm_istft_bwd(lib, n_fft, tables, dy, xrmm):
+    B, S, N = dy.shape
+    F, T = xrmm.shape[1], xrmm.shape[2]
+    dout = torch.empty(B, F, T, 2 * S, dtype=torch.float32, device=dy.device)
+    lib.call("nbss_inorm_istft_bwd", n_fft, B, S, N, _ptr(lib, tables), _ptr(lib, dy, torch.float32), _ptr(lib, xrmm, torch.float32), _ptr(lib, dout),
+             _stream(lib, dy))
+    return dout
+
+
+def pit_neg_sisdr(lib, preds, target, need_grad=True):
+    """-> (loss [1], perm [B,S] int32, dpreds or None)"""
+    B, S, N = preds.shape
+    dev = preds.device
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    perm = torch.empty(B, S, dtype=torch.int32, device=dev)
+    dp = torch.empty_like(preds) if need_grad else None
+    ws = torch.empty(lib.nbss_pit_ws_bytes(B, S) // 4, dtype=torch.float32, device=dev)
+    lib.call("nbss_pit_neg_sisdr", B, S, N, _ptr(lib, preds, torch.float32), _ptr(lib, target, torch.float32), _ptr(lib, loss), _ptr(lib, perm),
+             _ptr(lib, dp), _ptr(lib, ws), _stream(lib, preds))
+    return loss, perm, dp
+
+
+def clip_adam_step(lib, params, grads, exp_avg, exp_avg_sq, scratch, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                   max_norm=5.0, grad_scale=1.0, zero_grad=True):
+    lib.call("nbss_clip_adam_step", params.numel(), _ptr(lib, params, torch.float32), _ptr(lib, grads, torch.float32), _ptr(lib, exp_avg, torch.float32),
+             _ptr(lib, exp_avg_sq, torch.float32), _ptr(lib, scratch, torch.float32), float(max_norm), float(grad_scale), float(lr), float(betas[0]),
+             float(betas[1]), float(eps), float(weight_decay), int(step), int(bool(zero_grad)), _stream(lib, params))
+
+
 def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:
     D = torch.empty(16, 16, dtype=torch.float32, device=A.device)
     lib.call("nbss_selftest_mma", dtype, kperm, _ptr(lib, A, torch.float32), _ptr(lib, B, torch.float32), _ptr(lib, D), _stream(lib, A))
