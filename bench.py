@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py — utterances/sec of a full SpatialNet-small bf16-mixed TRAINING step on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic 4-s, 6-channel, 8-kHz mixtures
+(x[B,6,32000], 2 speakers), n_fft 256 / hop 128 -> F=129, T=251; one step = STFT + per-bin norm ->
+SpatialNet-small (8 layers, H=96) forward -> inorm + iSTFT -> uPIT neg-SI-SDR -> full backward ->
+[gradient all-reduce over RCCL] -> clip(5) + Adam(1e-3) -> re-pack of the MFMA weight fragments.
+Inputs are resident in HBM before the timed region.  One process per GPU (torchrun sets RANK / LOCAL_RANK /
+WORLD_SIZE), weak scaling: the per-GPU batch is fixed.
+
+Prints ONE JSON line (rank 0) with the contract keys plus
+  roofline     : dominant kernel (largest share of GPU time), algorithmic HBM bytes per launch / its average
+                 duration measured with HIP events on the launch stream during the timed steps, vs 8 TB/s
+  cpu_baseline : the oracle (a CPU restatement of the reference's fp32 training step) timed on this host
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+S_BYTES_BF16 = 129 * 251 * 96 * 2  # one utterance's residual stream (S)
+HBM_PEAK = 8.0e12
+
+
+def synth_batch(B, C, S, N, seed, device):
+    """two random 'speech-like' sources (low-passed noise bursts) mixed into C channels with random gains/delays + noise"""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, S, N, generator=g)
+    k = torch.hann_window(33)[None, None]
+    src = torch.nn.functional.conv1d(src.reshape(B * S, 1, N), k / k.sum(), padding=16).reshape(B, S, N)
+    env = (torch.rand(B, S, N // 800 + 1, generator=g) > 0.3).float().repeat_interleave(800, -1)[..., :N]
+    src = src * env * 3.0
+    gains = 0.5 + torch.rand(B, C, S, generator=g)
+    mix = torch.einsum("bcs,bsn->bcn", gains, src) + 0.01 * torch.randn(B, C, N, generator=g)
+    yr = src * gains[:, 0, :, None]  # targets at the reference channel
+    return mix.to(device), yr.contiguous().to(device)
+
+
+def profile_read(lib):
+    n = lib.nbss_profile_kernels()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    lib.nbss_profile_read(ms, cnt)
+    return {lib.nbss_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
+
+
+def algorithmic_bytes(name, B):
+    """per-launch algorithmic HBM bytes (each residual sub-block reads + writes the stream once in
+    forward (2S) and reads x, dy, writes dx in backward (3S); S = 6.2 MB per utterance in bf16)"""
+    S = S_BYTES_BF16 * B
+    if name.endswith("_fwd") and name.split("_")[0] in ("fconv", "full", "mhsa", "tconvffn"):
+        return 2 * S
+    if name.endswith("_bwd") and name.split("_")[0] in ("fconv", "full", "mhsa", "tconvffn"):
+        return 3 * S
+    return None
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """the oracle's fp32 training step (reference semantics) on the host cores; bounded sample"""
+    from oracle import io_ref
+    from oracle import spatialnet_ref as ref
+    torch.manual_seed(2)
+    threads = torch.get_num_threads()
+    p = ref.init_params(num_layers=8)
+    leaves, seen = [], {}
+    for k, v in p.items():
+        if id(v) not in seen:
+            seen[id(v)] = v.clone().requires_grad_(True)
+            leaves.append(seen[id(v)])
+        p[k] = seen[id(v)]
+    opt = torch.optim.Adam(leaves, lr=1e-3)
+    B = 1
+    x, yr = synth_batch(B, 6, 2, 32000, 99, "cpu")
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _, _ = io_ref.train_forward(x, yr, p, 8)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 5.0)
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "utterances/s", "cores": threads, "kind": "port",
+            "sample": f"{n} fp32 training steps of the oracle (reference semantics: STFT..Adam) at batch {B}, 4-s 6-ch utterances, torch CPU {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")  # RCCL on ROCm
+
+    from models.arch.SpatialNet import SpatialNet
+    from nbss_amd._lib import NBSS_BF16, hip
+    from nbss_amd.engine import SpatialNetEngine, TrainStep
+
+    lib = hip()
+    torch.manual_seed(2)  # seed_everything: 2 (configs/SpatialNet.yaml:1); identical init on every rank
+    net = SpatialNet(dim_input=12, dim_output=4, num_layers=8, encoder_kernel_size=5, dim_hidden=96, dim_ffn=192, num_heads=4, dropout=(0, 0, 0),
+                     kernel_size=(5, 3), conv_groups=(8, 8), norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=8, num_freqs=129, full_share=0)
+    eng = SpatialNetEngine(lib, dev, dtype=NBSS_BF16, **net.hp)
+    eng.load_params({k: v for k, v in net.named_parameters(remove_duplicate=False)})
+    ts = TrainStep(eng, n_fft=256, ref_channel=0, lr=1e-3, clip=5.0)
+    B = args.batch
+    x, yr = synth_batch(B, 6, 2, 32000, 1234 + rank, dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up (untimed); the first two steps are fully profiled to find the dominant kernel -------
+    nk = lib.nbss_profile_kernels()
+    lib.nbss_profile_enable((1 << nk) - 1)
+    losses = []
+    for i in range(args.warmup):
+        if i == 2:
+            torch.cuda.synchronize()
+            prof = profile_read(lib)
+            lib.nbss_profile_enable(0)
+        losses.append(ts.step(x, yr))
+    torch.cuda.synchronize()
+    if args.warmup <= 2:
+        prof = profile_read(lib)
+    lib.nbss_profile_enable(0)
+    cand = {k: v for k, v in prof.items() if algorithmic_bytes(k, B) and v[1] > 0}
+    dominant = max(cand, key=lambda k: cand[k][0]) if cand else None
+    dom_id = [i for i in range(nk) if lib.nbss_profile_name(i).decode() == dominant][0] if dominant else None
+
+    # ---- timed region: EXACTLY --steps steps, events only around the dominant kernel ------------------
+    if dom_id is not None:
+        lib.nbss_profile_enable(1 << dom_id)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ts.step(x, yr)
+    sync()
+    dt = time.perf_counter() - t0
+    lib.nbss_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    timed_prof = profile_read(lib)
+    final_loss = float(loss)
+
+    if rank == 0:
+        roof = None
+        if dominant and timed_prof[dominant][1] > 0:
+            ms, cnt = timed_prof[dominant]
+            per_launch = algorithmic_bytes(dominant, B)
+            ach = per_launch / (ms / cnt * 1e-3)
+            total_gpu_ms = sum(v[0] for v in prof.values())
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                    "traffic": None, "avg_launch_us": ms / cnt * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": per_launch,
+                    "share_of_gpu_time": prof[dominant][0] / total_gpu_ms if total_gpu_ms > 0 else None,
+                    "step_algorithmic": {"bytes_per_utt": 204 * S_BYTES_BF16, "achieved_GBps": world * B * args.steps / dt * 204 * S_BYTES_BF16 / 1e9 / world,
+                                         "frac_of_hbm_per_gpu": (B * args.steps / dt) * 204 * S_BYTES_BF16 / HBM_PEAK}}
+        base = None
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline()
+        line = {
+            "metric": "utterances/sec (4 s, 6ch, 129 freqs) SpatialNet bf16 train at 1/2/4/8 MI355X",
+            "value": world * B * args.steps / dt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "SpatialNet-small 6ch->2spk, 4-s 8-kHz utterances (32000 samples), n_fft 256/hop 128 (F=129, T=251), 8 layers, "
+                                   "full train step (STFT..Adam), bf16 stream + fp32 master/stats", "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "final_loss": final_loss},
+            "roofline": roof, "cpu_baseline": base,
+            "kernel_ms_per_step": {k: round(v[0] / 2, 4) for k, v in prof.items() if v[1] > 0},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,13 @@ int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, 
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream);
 const char* nbss_build_info(void);
+/* Opt-in per-kernel timing: HIP events recorded on the launch stream around each kernel whose bit is
+ * set in `mask` (bit i = kernel id i, 0 .. nbss_profile_kernels()-1; 0 disables).  nbss_profile_read
+ * waits for the recorded events, returns summed milliseconds / launch counts per id and clears them. */
+int nbss_profile_enable(int64_t mask);
+int nbss_profile_kernels(void);
+const char* nbss_profile_name(int id);
+int nbss_profile_read(double* total_ms, int64_t* count);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,10 @@ SIGNATURES = {
     "nbss_clip_adam_step": (_I, [C.c_int64, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),
     "nbss_build_info": (C.c_char_p, []),
+    "nbss_profile_enable": (_I, [C.c_int64]),
+    "nbss_profile_kernels": (_I, []),
+    "nbss_profile_name": (C.c_char_p, [_I]),
+    "nbss_profile_read": (_I, [_P, _P]),
 }
 
 

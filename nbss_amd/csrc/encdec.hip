@@ -7,6 +7,7 @@
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
+#include "prof.h"
 
 #define ENC_H 96
 
@@ -97,6 +98,7 @@ template <class T>
 static int encoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, const void* xin, void* y, hipStream_t st) {
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
+    ProfScope ps(PK_ENC_F, st);
     NBSS_LAUNCH((encoder_fwd_kernel<T>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_ENC), (const T*)xin, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
@@ -104,6 +106,7 @@ template <class T>
 static int decoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st) {
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
+    ProfScope ps(PK_DEC_F, st);
     NBSS_LAUNCH((decoder_fwd_kernel<T>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_DEC), (const T*)x, out);
     return NBSS_CHECK_LAUNCH();
 }
@@ -159,10 +162,12 @@ int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pa
     const int CP = (c.C_out + 3) & ~3;
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
+    prof_begin(PK_DEC_B, st);
     if (c.dtype == NBSS_BF16)
         NBSS_LAUNCH((decoder_bwd_kernel<bf16_t>), grid, block, 0, st, c, (const bf16_t*)packed + pack_off(c, 0, K_DEC_T), dout, (bf16_t*)dx, (bf16_t*)ws, CP);
     else
         NBSS_LAUNCH((decoder_bwd_kernel<float>), grid, block, 0, st, c, (const float*)packed + pack_off(c, 0, K_DEC_T), dout, (float*)dx, (float*)ws, CP);
+    prof_end(PK_DEC_B, st);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;
     WgradArgs a;

@@ -10,6 +10,7 @@
 // residual add + store are full 16-byte coalesced accesses.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
 
@@ -351,6 +352,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* 
     int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * c.T), block(256);
+    ProfScope ps(PK_FCONV_B, st);
     NBSS_LAUNCH((fconv_bwd_kernel<T>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
                 P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), G + param_off(c, layer, lw),
                 G + param_off(c, layer, lb), G + param_off(c, layer, sl), pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
@@ -389,6 +391,7 @@ static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, in
     int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, TT)), block(256);
+    ProfScope ps(PK_FCONV_F, st);
     NBSS_LAUNCH((fconv_fwd_kernel<T, TT>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }

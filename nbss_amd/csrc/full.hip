@@ -11,6 +11,7 @@
 //   pass 3  y = x + SiLU(Wu z + bu)
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
 
@@ -356,6 +357,7 @@ static int full_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* p
     int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
+    ProfScope ps(PK_FULL_B, st);
     NBSS_LAUNCH((full_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
                 pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
                 (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4]);
@@ -413,6 +415,7 @@ static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
+    ProfScope ps(PK_FULL_F, st);
     NBSS_LAUNCH((full_fwd_kernel<T>), grid, block, lds, st, c, P + param_off(c, layer, P_FULL_LN_W), P + param_off(c, layer, P_FULL_LN_B),
                 P + param_off(c, layer, P_SQ_B), P + param_off(c, layer, P_FULL_B), P + param_off(c, layer, P_USQ_B),
                 pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);

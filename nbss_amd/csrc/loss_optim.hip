@@ -14,6 +14,7 @@
 // elementwise launch which also re-zeroes the gradient buffer for the next step.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 
 #define LS_MAXS 4
 #define LS_CHUNKS 64
@@ -150,6 +151,7 @@ int pit_sisdr_impl(int B, int S, int N, const float* p, const float* t, float* l
     float* part = ws;
     float* loss_b = part + (size_t)B * LS_CHUNKS * nq;
     float* coef = loss_b + B;
+    ProfScope ps(PK_LOSS, st);
     NBSS_LAUNCH(sisdr_dots_kernel, dim3(LS_CHUNKS, B), dim3(256), 64, st, S, N, p, t, part);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;
@@ -210,6 +212,7 @@ int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal
                    float lr, float beta1, float beta2, float eps, float wd, int step, int zero_grad, hipStream_t st) {
     if (step < 1) return NBSS_EINVAL;
     float* part = scal + 2;
+    ProfScope ps(PK_ADAM, st);
     NBSS_LAUNCH(sumsq_kernel, dim3(OP_BLOCKS), dim3(256), 64, st, n, (const float*)g, part);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;

@@ -16,6 +16,7 @@
 // T = 251 is padded to 16 tiles of 16 keys; padded keys are masked to -inf.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 
 #define MH_H 96
 #define MH_HEADS 4
@@ -266,6 +267,7 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(256);
+    ProfScope ps(PK_MHSA_F, st);
     NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
                 pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave);

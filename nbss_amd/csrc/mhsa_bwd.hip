@@ -13,6 +13,7 @@
 // du += Win^T dqkv, followed by the in-register LayerNorm backward.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
 
@@ -366,6 +367,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* p
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
+    ProfScope ps(PK_MHSA_B, st);
     NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_T),
                 pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (T*)dx, stats, (T*)dqkv);
     return NBSS_CHECK_LAUNCH();

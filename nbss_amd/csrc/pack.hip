@@ -4,6 +4,7 @@
 // fragment with a single 16-byte (bf16) load per lane and no index arithmetic.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 
 NBSS_DEV int perm_k(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
 
@@ -132,6 +133,7 @@ __global__ void pack_kernel(nbss_cfg c, const float* __restrict__ P, T* __restri
 
 int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipStream_t stream) {
     dim3 grid(32, NUM_PACK_KINDS, c.L), block(256);
+    ProfScope ps(PK_PACK, stream);
     if (c.dtype == NBSS_BF16)
         NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, params, (bf16_t*)packed);
     else

@@ -12,6 +12,7 @@
 // frames are the MFMA N dimension, so a lane holds (re,im) pairs of one frame.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 
 #define SG_PI 3.14159265358979323846
 
@@ -286,6 +287,7 @@ static int grid_for(int ntask) { return cdiv(ntask, 4) < 4096 ? cdiv(ntask, 4) :
 int stft_norm_impl(int nfft, int dtype, int B, int C, int N, int ref, const float* tab, const float* x, void* X, float* xrmm, hipStream_t st) {
     if (ref < 0 || ref >= C || N < nfft) return NBSS_EINVAL;
     const int Tn = N / (nfft / 2) + 1, MTq = cdiv(nfft + 2, 16);
+    ProfScope ps(PK_STFT, st);
     dim3 grid(grid_for(B * cdiv(Tn, 16) * MTq)), block(256);
     if (nfft == 256) {
         if (dtype == NBSS_BF16) NBSS_LAUNCH((stft_norm_kernel<bf16_t, 256>), grid, block, 0, st, B, C, N, Tn, ref, tab, x, (bf16_t*)X, xrmm);
@@ -302,6 +304,7 @@ int stft_norm_impl(int nfft, int dtype, int B, int C, int N, int ref, const floa
 int inorm_istft_impl(int nfft, int B, int S, int N, const float* tab, const float* out, const float* xrmm, float* ybuf, float* y, hipStream_t st) {
     const int Tn = N / (nfft / 2) + 1;
     const size_t LP = (size_t)(Tn + 1) * (nfft / 2);
+    ProfScope ps(PK_ISTFT, st);
     int e = memset_async_impl(ybuf, (size_t)B * S * LP * sizeof(float), st);
     if (e) return e;
     dim3 grid(grid_for(B * S * cdiv(Tn, 16))), block(256);
@@ -317,6 +320,7 @@ int inorm_istft_impl(int nfft, int B, int S, int N, const float* tab, const floa
 
 int inorm_istft_bwd_impl(int nfft, int B, int S, int N, const float* tab, const float* dy, const float* xrmm, float* dout, hipStream_t st) {
     const int Tn = N / (nfft / 2) + 1;
+    ProfScope ps(PK_ISTFT_B, st);
     dim3 grid(grid_for(B * S * cdiv(Tn, 16))), block(256);
     if (nfft == 256) NBSS_LAUNCH((inorm_istft_bwd_kernel<256>), grid, block, 0, st, B, S, N, Tn, tab, dy, xrmm, dout);
     else if (nfft == 512) NBSS_LAUNCH((inorm_istft_bwd_kernel<512>), grid, block, 0, st, B, S, N, Tn, tab, dy, xrmm, dout);

@@ -11,6 +11,7 @@
 // intermediates of the reference never exist in memory.
 #include "launch.h"
 #include "layout.h"
+#include "prof.h"
 #include "wgrad.h"
 
 #define TF_H 96
@@ -703,6 +704,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, const voi
     int e = NBSS_SET_MAX_LDS((tconvffn_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
+    ProfScope ps(PK_TCF_B, st);
     NBSS_LAUNCH((tconvffn_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
                 pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W1_T),
                 pk + pack_off(c, layer, K_TF_C1_T), pk + pack_off(c, layer, K_TF_C2_T), pk + pack_off(c, layer, K_TF_C3_T),
@@ -751,6 +753,7 @@ static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed,
     const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float);
     const T* pk = (const T*)packed;
     dim3 grid(c.B * c.F), block(512);
+    ProfScope ps(PK_TCF_F, st);
     NBSS_LAUNCH((tconvffn_fwd_kernel<T>), grid, block, lds, st, c, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
                 pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W2), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();

@@ -15,6 +15,7 @@
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
+#include "prof.h"
 
 #define WG_KC 32
 #define WG_LD 40     // LDS row length in elements (32 tokens + pad)
@@ -167,6 +168,7 @@ int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     if (xbl < 8) xbl = 8;
     if (xbl > nchunks) xbl = nchunks;
     dim3 grid(xbl, ybl), block(256);
+    ProfScope ps(PK_WGRAD, st);
     int e;
     if (dtype == NBSS_BF16) {
         e = NBSS_SET_MAX_LDS((wgrad_kernel<bf16_t>), lds);

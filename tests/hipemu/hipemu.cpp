@@ -12,9 +12,35 @@ thread_local Fiber* g_fiber = nullptr;
 
 static const size_t kStackBytes = 256 * 1024;
 
+// Minimal x86-64 SysV context switch: save callee-saved registers on the current stack, publish the
+// stack pointer, adopt the other one.  (glibc's swapcontext does a sigprocmask syscall per switch.)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
 void yield_to_sched() {
     Fiber* f = g_fiber;
-    swapcontext(&f->ctx, &g_block->sched);
+    hipemu_switch(&f->sp, g_block->sched_sp);
 }
 
 void block_barrier() {
@@ -63,7 +89,8 @@ static void fiber_main() {
         w.arrived = 0;
         w.gen++;
     }
-    swapcontext(&f->ctx, &b->sched);
+    hipemu_switch(&f->sp, b->sched_sp);
+    abort();  // a finished fiber is never resumed
 }
 
 struct Worker {
@@ -113,11 +140,14 @@ static void run_block(Worker& wk, dim3 bid, dim3 grid, dim3 bdim, size_t lds_byt
         f.wave = i >> 6;
         blk.waves[f.wave].alive++;
         f.stack = wk.stacks[i];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStackBytes;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+        // initial frame: 6 callee-saved slots + return address (fiber_main); keep the ABI's 16-byte alignment
+        uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + kStackBytes) & ~uintptr_t(15);
+        void** a = reinterpret_cast<void**>(top - 16);
+        a[0] = reinterpret_cast<void*>(&fiber_main);
+        a[1] = nullptr;
+        void** regs = a - 6;
+        for (int r = 0; r < 6; ++r) regs[r] = nullptr;
+        f.sp = regs;
     }
     std::vector<int> order(nthreads);
     for (int i = 0; i < nthreads; ++i) order[i] = i;
@@ -136,7 +166,7 @@ static void run_block(Worker& wk, dim3 bid, dim3 grid, dim3 bdim, size_t lds_byt
             f.wait = 0;
             progress = true;
             g_fiber = &f;
-            swapcontext(&blk.sched, &f.ctx);
+            hipemu_switch(&blk.sched_sp, f.sp);
             if (f.done) remaining--;
         }
         if (!progress) {

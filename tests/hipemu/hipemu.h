@@ -11,7 +11,6 @@
 // HIPEMU_ORDER=rev|rand to expose missing barriers) and the MFMA fragment bookkeeping.
 // Nothing in the product (nbss_amd/, models/, bench.py) may load the emulator library.
 #pragma once
-#include <ucontext.h>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -35,7 +34,7 @@ struct Wave {
 };
 
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;  // saved stack pointer (hand-rolled x86-64 context switch: no signal-mask syscalls)
     char* stack = nullptr;
     dim3 tid;
     int linear = 0, lane = 0, wave = 0;
@@ -53,7 +52,7 @@ struct Block {
     int alive = 0;
     char* lds = nullptr;
     size_t lds_bytes = 0;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     void (*entry)(void*) = nullptr;
     void* entry_arg = nullptr;
 };
