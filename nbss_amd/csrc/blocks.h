@@ -118,8 +118,19 @@ NBSS_DEV void ln_bwd_row96(f32x4 (&du)[BK_MT], const T* __restrict__ xr, const T
     }
 }
 
+// Small per-channel parameter gradients (LN / GN affine, PReLU slope) are summed per workgroup in LDS
+// (ds_add_f32) and written as ONE partial row per workgroup; util.hip's affine_reduce folds the rows
+// into the gradient buffer.  (Same-address global atomics from every wave serialise in the memory
+// system and stalled the barriers of the first version: 24.7 ms -> see profiles/.)
+struct AffSegs {
+    int n;
+    long long off[6];  // destination offsets in the flat gradient buffer
+    int cnt[6];        // consecutive elements per segment; the partial row is the concatenation
+};
+int affine_reduce_launch(const float* part, int nwg, const AffSegs& segs, float* G, hipStream_t st);
+
 // reduce the per-lane dgamma/dbeta partials over the 16 rows of the lane group and add them to the
-// fp32 gradient buffer (one atomicAdd per channel per wave)
+// workgroup's LDS accumulators (gw/gb may also be global: then these are plain atomicAdd's)
 NBSS_DEV void ln_affine_flush(float (&dlw)[BK_MT][4], float (&dlb)[BK_MT][4], float* __restrict__ gw, float* __restrict__ gb) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
 #pragma unroll

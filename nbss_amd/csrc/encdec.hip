@@ -60,14 +60,13 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(nbss_cfg c, const floa
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void decoder_fwd_kernel(nbss_cfg c, const float* __restrict__ P, const T* __restrict__ Wp,
+__global__ __launch_bounds__(256) void decoder_fwd_kernel(nbss_cfg c, const float* __restrict__ bias, const T* __restrict__ Wp,
                                                           const T* __restrict__ x, float* __restrict__ out) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
     const int T_ = c.T, Co = c.C_out;
     const int nst = cdiv(T_, 16);
     const int nstrips = c.B * c.F * nst;
     constexpr int KS = ENC_H / 32;
-    const float* bias = P + param_off_dec_b(c);
     Frag<T> a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wfrag_load(a[ks], Wp, 0, KS, ks);
@@ -107,7 +106,7 @@ static int decoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, 
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
     ProfScope ps(PK_DEC_F, st);
-    NBSS_LAUNCH((decoder_fwd_kernel<T>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_DEC), (const T*)x, out);
+    NBSS_LAUNCH((decoder_fwd_kernel<T>), grid, block, 0, st, c, P + param_off_dec_b(c), (const T*)packed + pack_off(c, 0, K_DEC), (const T*)x, out);
     return NBSS_CHECK_LAUNCH();
 }
 

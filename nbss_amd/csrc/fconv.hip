@@ -190,8 +190,8 @@ NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int f, int ch0, 
 
 template <class T>
 __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                                        const float* __restrict__ cb, const float* __restrict__ slope, float* __restrict__ g_lnw,
-                                                        float* __restrict__ g_lnb, float* __restrict__ g_slope, const T* __restrict__ Wp,
+                                                        const float* __restrict__ cb, const float* __restrict__ slope, float* __restrict__ part,
+                                                        const T* __restrict__ Wp,
                                                         const T* __restrict__ WpT, const T* __restrict__ x, const T* __restrict__ dy,
                                                         T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout) {
     NBSS_LDS(smem);
@@ -200,6 +200,8 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
     const int mtf = cdiv(F, 16), FP = mtf * 16 + 4;
     T* u = reinterpret_cast<T*>(smem);       // [FP][H]  LN(x), rows f+2
     T* dvb = u + (size_t)FP * FC_H;          // [FP][H]  dv, rows f+2
+    float* aff = reinterpret_cast<float*>(dvb + (size_t)FP * FC_H);  // [3H] LN weight | LN bias | PReLU slope gradient sums
+    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
     constexpr int VN = VecOf<T>::N;
     constexpr int VPR = FC_H / VN;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -334,19 +336,21 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
             const float a = sum_l15_(dlw[g][r]), bb = sum_l15_(dlb[g][r]), s2 = sum_l15_(dsl[g][r]);
             if (l15 == 0 && cvalid) {
                 const int ch = g * FC_CG + 4 * g4 + r;
-                atomicAdd(g_lnw + ch, a);
-                atomicAdd(g_lnb + ch, bb);
-                atomicAdd(g_slope + ch, s2);
+                atomicAdd(aff + ch, a);
+                atomicAdd(aff + FC_H + ch, bb);
+                atomicAdd(aff + 2 * FC_H + ch, s2);
             }
         }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) part[(size_t)blockIdx.x * 3 * FC_H + i] = aff[i];
 }
 
 template <class T>
-static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
+static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                        float* stats, void* dv, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (mtf * 16 + 4) * FC_H * sizeof(T);
+    const size_t lds = (size_t)2 * (mtf * 16 + 4) * FC_H * sizeof(T) + 3 * FC_H * sizeof(float);
     const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T>), lds);
@@ -354,8 +358,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* 
     dim3 grid(c.B * c.T), block(256);
     ProfScope ps(PK_FCONV_B, st);
     NBSS_LAUNCH((fconv_bwd_kernel<T>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
-                P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), G + param_off(c, layer, lw),
-                G + param_off(c, layer, lb), G + param_off(c, layer, sl), pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
+                P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), part, pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
                 pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv);
     return NBSS_CHECK_LAUNCH();
 }
@@ -365,9 +368,16 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     const size_t N = (size_t)c.B * c.F * c.T;
     float* stats = (float*)ws;
     void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));
-    int e = c.dtype == NBSS_BF16 ? fconv_bwd_t<bf16_t>(c, P, G, packed, layer, which, x, dy, dx, stats, dv, st)
-                                 : fconv_bwd_t<float>(c, P, G, packed, layer, which, x, dy, dx, stats, dv, st);
+    float* part = (float*)((char*)ws + ws_part_offset(c));
+    int e = c.dtype == NBSS_BF16 ? fconv_bwd_t<bf16_t>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+                                 : fconv_bwd_t<float>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
     if (e) return e;
+    AffSegs sg;
+    sg.n = 3;
+    sg.off[0] = param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); sg.cnt[0] = FC_H;
+    sg.off[1] = param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B); sg.cnt[1] = FC_H;
+    sg.off[2] = param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU); sg.cnt[2] = FC_H;
+    if ((e = affine_reduce_launch(part, c.B * c.T, sg, G, st))) return e;
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
     WgradArgs a;
     a.mvalid = 0; a.nvalid = 0;

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
 #define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
 
 template <class T>
-__global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, const float* __restrict__ P, float* __restrict__ G, int layer,
+__global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
@@ -172,18 +172,20 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, const float* 
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]   s, later dz
     T* sp = s + FL_SQ * FL_TT * FK;                // [FM][TT][SQ]   s_pre
     T* z = sp + FM * FL_TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
+    float* aff = reinterpret_cast<float*>(z + FM * FL_TT * FL_SQ);  // [2H] LN weight | bias gradient sums
     const int ntt = cdiv(T_, FL_TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
     const int ntile = cdiv(F, 2);
-    const float* lnw = P + param_off(c, layer, P_FULL_LN_W);
-    const float* lnb = P + param_off(c, layer, P_FULL_LN_B);
-    const float* bs = P + param_off(c, layer, P_SQ_B);
-    const float* bfull = P + param_off(c, layer, P_FULL_B);
-    const float* bu = P + param_off(c, layer, P_USQ_B);
+    const float* lnw = lp.p[P_FULL_LN_W];
+    const float* lnb = lp.p[P_FULL_LN_B];
+    const float* bs = lp.p[P_SQ_B];
+    const float* bfull = lp.p[P_FULL_B];
+    const float* bu = lp.p[P_USQ_B];
 
     for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
+    for (int i = tid; i < 2 * FL_H; i += nthr) aff[i] = 0.f;
     __syncthreads();
 
     // ---- p1: LN + squeeze ----
@@ -344,21 +346,24 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, const float* 
             for (int mt = 0; mt < FL_MT; ++mt) du[mt] = mma(a[mt], bq, F32X4_ZERO);
             ln_bwd_row96<T>(du, x + n * FL_H, dy + n * FL_H, dx + n * FL_H, stats + n * 2, valid, lnw, dlw, dlb);
         }
-        ln_affine_flush(dlw, dlb, G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B));
+        ln_affine_flush(dlw, dlb, aff, aff + FL_H);
     }
+    __syncthreads();
+    for (int i = tid; i < 2 * FL_H; i += nthr) part[(size_t)blockIdx.x * 2 * FL_H + i] = aff[i];
 }
 
 template <class T>
-static int full_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
+static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                       float* stats, void* const* o, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T);
+    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + 2 * FL_H * sizeof(float);
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
     ProfScope ps(PK_FULL_B, st);
-    NBSS_LAUNCH((full_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
+    NBSS_LAUNCH((full_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
                 pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
                 (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4]);
     return NBSS_CHECK_LAUNCH();
@@ -368,6 +373,7 @@ int memset_async_impl(void* p, size_t bytes, hipStream_t st);
 
 int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx, void* ws,
                   hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats | s [B*T][SQ][FKP] | dz [B*T][SQ][FKP] | z [N][SQ] | dy_pre [N][H] | ds_pre [N][SQ]
     const size_t N = (size_t)c.B * c.F * c.T, BT = (size_t)c.B * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const int FKP = FL_FKP(c.F);
@@ -382,9 +388,15 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     // the F..FKP padding columns of s / dz are read by the wgrad staging: keep them zero
     int e = memset_async_impl(o[0], 2 * ws_align(BT * FL_SQ * FKP * esz), st);
     if (e) return e;
-    e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t>(c, P, G, packed, layer, x, dy, dx, stats, o, st)
-                             : full_bwd_t<float>(c, P, G, packed, layer, x, dy, dx, stats, o, st);
+    float* part = (float*)((char*)ws + ws_part_offset(c));
+    e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
+                             : full_bwd_t<float>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
     if (e) return e;
+    AffSegs sg;
+    sg.n = 2;
+    sg.off[0] = param_off(c, layer, P_FULL_LN_W); sg.cnt[0] = FL_H;
+    sg.off[1] = param_off(c, layer, P_FULL_LN_B); sg.cnt[1] = FL_H;
+    if ((e = affine_reduce_launch(part, c.B * cdiv(c.T, FL_TT), sg, G, st))) return e;
     WgradArgs a;
     a.mvalid = 0; a.nvalid = 0;
     a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.taps = 1;
@@ -402,13 +414,14 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     // squeeze: dWs[SQ][H] = ds_pre^T LN(x) ; dbs = colsum(ds_pre)
     a.Ntok = (int)N; a.groups = 1; a.mvalid = 0; a.nvalid = 0;
     a.A = o[4]; a.lda = FL_SQ; a.MA = FL_SQ; a.B = x; a.ldb = FL_H; a.NB = FL_H;
-    a.stats = stats; a.gamma = P + param_off(c, layer, P_FULL_LN_W); a.beta = P + param_off(c, layer, P_FULL_LN_B);
+    a.stats = stats; a.gamma = lp.p[P_FULL_LN_W]; a.beta = lp.p[P_FULL_LN_B];
     a.dW = G + param_off(c, layer, P_SQ_W); a.dbias = G + param_off(c, layer, P_SQ_B);
     return wgrad_launch(a, c.dtype, st);
 }
 
 template <class T>
 static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
     const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)mtf * 16 * FL_TT * FL_SQ) * sizeof(T);
     const T* pk = (const T*)packed;
@@ -416,8 +429,8 @@ static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
     ProfScope ps(PK_FULL_F, st);
-    NBSS_LAUNCH((full_fwd_kernel<T>), grid, block, lds, st, c, P + param_off(c, layer, P_FULL_LN_W), P + param_off(c, layer, P_FULL_LN_B),
-                P + param_off(c, layer, P_SQ_B), P + param_off(c, layer, P_FULL_B), P + param_off(c, layer, P_USQ_B),
+    NBSS_LAUNCH((full_fwd_kernel<T>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+                lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
                 pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }

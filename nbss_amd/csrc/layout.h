@@ -76,6 +76,17 @@ NBSS_HD int64_t param_off_dec_w(const nbss_cfg& c) { return layer_base(c, c.L); 
 NBSS_HD int64_t param_off_dec_b(const nbss_cfg& c) { return param_off_dec_w(c) + (int64_t)c.C_out * c.H; }
 NBSS_HD int64_t param_total(const nbss_cfg& c) { return param_off_dec_b(c) + c.C_out; }
 
+// per-layer parameter pointers, resolved on the HOST and passed by value: the offset arithmetic above
+// loops over layers and must never run inside a kernel (it cost +290 us per layer index when it did)
+struct LayerPtrs {
+    const float* p[NUM_LAYER_PARAMS];
+};
+inline LayerPtrs layer_ptrs(const nbss_cfg& c, const float* P, int layer) {
+    LayerPtrs lp;
+    for (int i = 0; i < NUM_LAYER_PARAMS; ++i) lp.p[i] = P + param_off(c, layer, i);
+    return lp;
+}
+
 // ---- packed fragment buffer ------------------------------------------------------------------
 // Every entry is [MT tiles][KS ksteps][64 lanes][8] elements of the stream dtype.
 enum PackKind {
@@ -168,7 +179,13 @@ NBSS_HD int64_t pack_total(const nbss_cfg& c) {
 NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
-    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + 256;
+    const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
+    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + 256;
+}
+// per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands
+NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
+    const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz);
 }
 
 NBSS_HD int check_cfg(const nbss_cfg& c) {

@@ -65,7 +65,7 @@ NBSS_DEV void col_frag(Frag<T>& f, const T* __restrict__ base, int tp, int half,
 }
 
 template <class T>
-__global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, const float* __restrict__ P, float* __restrict__ G, int layer,
+__global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Win, const T* __restrict__ WinT, const T* __restrict__ WoutT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ osave,
                                                        T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dqkv) {
@@ -81,13 +81,15 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, const float* 
     float* m2s = reinterpret_cast<float*>(dOt + (size_t)tp * MB_DH);
     float* lis = m2s + tp;
     float* Dds = lis + tp;
+    float* aff = Dds + tp;  // [2H] per-workgroup LN weight | bias gradient sums
+    for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) aff[i] = 0.f;
     const int bf = blockIdx.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
     const T* xb = x + n0 * MB_H;
     const T* dyb = dy + n0 * MB_H;
     const T* ob = osave + n0 * MB_H;
-    const float* bin = P + param_off(c, layer, P_INP_B);
+    const float* bin = lp.p[P_INP_B];
     const float rs_dh = rsqrtf((float)MB_DH);
     const float qscale = 1.4426950408889634f * rs_dh;
 
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, const float* 
     Frag<T> u[MB_NSW][MB_KS], dyf[MB_NSW][MB_KS];
     {
         float gam[BK_KS][8], bet[BK_KS][8];
-        load_ln_affine(P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B), gam, bet);
+        load_ln_affine(lp.p[P_MH_LN_W], lp.p[P_MH_LN_B], gam, bet);
 #pragma unroll
         for (int si = 0; si < MB_NSW; ++si) {
             ln_strip96<T>(xb + (size_t)tt[si] * MB_H, tv[si], gam, bet, u[si]);
@@ -351,36 +353,46 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, const float* 
 #pragma unroll
     for (int si = 0; si < MB_NSW; ++si) {
         const size_t n = n0 + tt[si];
-        ln_bwd_row96<T>(du[si], x + n * MB_H, dy + n * MB_H, dx + n * MB_H, stats + n * 2, tv[si], P + param_off(c, layer, P_MH_LN_W), dlw, dlb);
+        ln_bwd_row96<T>(du[si], x + n * MB_H, dy + n * MB_H, dx + n * MB_H, stats + n * 2, tv[si], lp.p[P_MH_LN_W], dlw, dlb);
     }
-    ln_affine_flush(dlw, dlb, G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B));
+    ln_affine_flush(dlw, dlb, aff, aff + MB_H);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) part[(size_t)blockIdx.x * 2 * MB_H + i] = aff[i];
 }
 
 template <class T>
-static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
+static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                       void* dx, float* stats, void* dqkv, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int tp = cdiv(c.T, 16) * 16;
     if (tp > 256) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)7 * tp * MB_DH * sizeof(T) + (size_t)3 * tp * sizeof(float);
+    const size_t lds = (size_t)7 * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 2 * MB_H) * sizeof(float);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_MHSA_B, st);
-    NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_T),
+    NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_T),
                 pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (T*)dx, stats, (T*)dqkv);
     return NBSS_CHECK_LAUNCH();
 }
 
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                   void* dx, void* ws, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     const size_t N = (size_t)c.B * c.F * c.T;
     float* stats = (float*)ws;
     void* dqkv = (char*)ws + ws_align(N * 2 * sizeof(float));
-    int e = c.dtype == NBSS_BF16 ? mhsa_bwd_t<bf16_t>(c, P, G, packed, layer, x, dy, osave, dx, stats, dqkv, st)
-                                 : mhsa_bwd_t<float>(c, P, G, packed, layer, x, dy, osave, dx, stats, dqkv, st);
+    float* part = (float*)((char*)ws + ws_part_offset(c));
+    int e = c.dtype == NBSS_BF16 ? mhsa_bwd_t<bf16_t>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+                                 : mhsa_bwd_t<float>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st);
     if (e) return e;
+    AffSegs sg;
+    sg.n = 2;
+    sg.off[0] = param_off(c, layer, P_MH_LN_W); sg.cnt[0] = MB_H;
+    sg.off[1] = param_off(c, layer, P_MH_LN_B); sg.cnt[1] = MB_H;
+    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
     WgradArgs a;
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
@@ -391,7 +403,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     if ((e = wgrad_launch(a, c.dtype, st))) return e;
     // in_proj: dWin[3H][H] = dqkv^T LN(x) ; dbin = colsum(dqkv)
     a.A = dqkv; a.lda = 3 * MB_H; a.MA = 3 * MB_H; a.B = x; a.ldb = MB_H; a.NB = MB_H;
-    a.stats = stats; a.gamma = P + param_off(c, layer, P_MH_LN_W); a.beta = P + param_off(c, layer, P_MH_LN_B);
+    a.stats = stats; a.gamma = lp.p[P_MH_LN_W]; a.beta = lp.p[P_MH_LN_B];
     a.dW = G + param_off(c, layer, P_INP_W); a.dbias = G + param_off(c, layer, P_INP_B);
     return wgrad_launch(a, c.dtype, st);
 }

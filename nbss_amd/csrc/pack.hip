@@ -8,8 +8,30 @@
 
 NBSS_DEV int perm_k(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
 
+
+// flat-buffer offset of the weight tensor a pack kind reads (hoisted out of the per-element loop)
+static int64_t pack_src_base(const nbss_cfg& c, int kind, int layer) {
+    switch (kind) {
+        case K_ENC: return param_off_enc_w(c);
+        case K_DEC: case K_DEC_T: return param_off_dec_w(c);
+        case K_FC1: case K_FC1_T: return param_off(c, layer, P_FC1_W);
+        case K_FC2: case K_FC2_T: return param_off(c, layer, P_FC2_W);
+        case K_SQ: case K_SQ_T: return param_off(c, layer, P_SQ_W);
+        case K_FULL: case K_FULL_T: return param_off(c, layer, P_FULL_W);
+        case K_USQ: case K_USQ_T: return param_off(c, layer, P_USQ_W);
+        case K_INP: case K_INP_T: return param_off(c, layer, P_INP_W);
+        case K_OUTP: case K_OUTP_T: return param_off(c, layer, P_OUTP_W);
+        case K_TF_W1: case K_TF_W1_T: return param_off(c, layer, P_TF_W1);
+        case K_TF_C1: case K_TF_C1_T: return param_off(c, layer, P_TF_C1W);
+        case K_TF_C2: case K_TF_C2_T: return param_off(c, layer, P_TF_C2W);
+        case K_TF_C3: case K_TF_C3_T: return param_off(c, layer, P_TF_C3W);
+        case K_TF_W2: case K_TF_W2_T: return param_off(c, layer, P_TF_W2);
+    }
+    return 0;
+}
+
 // value of A[m-tile mt, row i=lane&15][kstep ks, lane group g4, slot j] for (kind, layer, block nb)
-NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P, int kind, int layer, int nb, int mt, int ks, int lane, int j) {
+NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the source weight tensor */, int kind, int nb, int mt, int ks, int lane, int j) {
     const int l15 = lane & 15, g4 = lane >> 4;
     const int m = mt * 16 + l15;
     const int knat = ks * 32 + 8 * g4 + j;
@@ -19,126 +41,140 @@ NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P, int ki
             const int pc = c.C_in / 4, p = ks * 8 + g4 * 2 + (j >> 2);
             if (p >= c.enc_ks * pc) return 0.f;
             const int tap = p / pc, i = (p % pc) * 4 + (j & 3);
-            return P[param_off_enc_w(c) + ((int64_t)m * c.C_in + i) * c.enc_ks + tap];
+            return P[((int64_t)m * c.C_in + i) * c.enc_ks + tap];
         }
         case K_DEC:
-            return m < c.C_out ? P[param_off_dec_w(c) + (int64_t)m * H + knat] : 0.f;
+            return m < c.C_out ? P[(int64_t)m * H + knat] : 0.f;
         case K_FC1: case K_FC2: {
             const int fg = H / c.f_groups, pc = fg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
             if (m >= fg || p >= c.f_ks * pc) return 0.f;
             const int tap = p / pc, i = (p % pc) * 4 + (j & 3);
-            const int64_t w = param_off(c, layer, kind == K_FC1 ? P_FC1_W : P_FC2_W);
-            return P[w + ((int64_t)(nb * fg + m) * fg + i) * c.f_ks + tap];
+            return P[((int64_t)(nb * fg + m) * fg + i) * c.f_ks + tap];
         }
         case K_SQ:
-            return m < c.SQ ? P[param_off(c, layer, P_SQ_W) + (int64_t)m * H + knat] : 0.f;
+            return m < c.SQ ? P[(int64_t)m * H + knat] : 0.f;
         case K_FULL:
-            return (m < c.F && knat < c.F) ? P[param_off(c, layer, P_FULL_W) + ((int64_t)nb * c.F + m) * c.F + knat] : 0.f;
+            return (m < c.F && knat < c.F) ? P[((int64_t)nb * c.F + m) * c.F + knat] : 0.f;
         case K_USQ:
-            return knat < c.SQ ? P[param_off(c, layer, P_USQ_W) + (int64_t)m * c.SQ + knat] : 0.f;
+            return knat < c.SQ ? P[(int64_t)m * c.SQ + knat] : 0.f;
         case K_INP: {
             const int dh = H / c.heads;
             const int which = mt / (c.heads * 2), rem = mt % (c.heads * 2), head = rem >> 1, d = (rem & 1) * 16 + l15;
             if (d >= dh) return 0.f;
-            return P[param_off(c, layer, P_INP_W) + (int64_t)(which * H + head * dh + d) * H + knat];
+            return P[(int64_t)(which * H + head * dh + d) * H + knat];
         }
         case K_OUTP: {
             const int dh = H / c.heads, d = perm_k(g4, j);
             if (d >= dh) return 0.f;
-            return P[param_off(c, layer, P_OUTP_W) + (int64_t)m * H + ks * dh + d];
+            return P[(int64_t)m * H + ks * dh + d];
         }
         case K_TF_W1: {
             const int cg = c.FFN / c.t_groups, grp = mt >> 1, ci = (mt & 1) * 16 + l15;
             if (ci >= cg) return 0.f;
-            return P[param_off(c, layer, P_TF_W1) + (int64_t)(grp * cg + ci) * H + knat];
+            return P[(int64_t)(grp * cg + ci) * H + knat];
         }
         case K_TF_C1: case K_TF_C2: case K_TF_C3: {
             const int cg = c.FFN / c.t_groups, pc = cg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
             if (m >= cg || p >= c.t_ks * pc) return 0.f;
             const int tap = p / pc, i = (p % pc) * 4 + (j & 3);
-            const int pk = kind == K_TF_C1 ? P_TF_C1W : (kind == K_TF_C2 ? P_TF_C2W : P_TF_C3W);
-            return P[param_off(c, layer, pk) + ((int64_t)(nb * cg + m) * cg + i) * c.t_ks + tap];
+            return P[((int64_t)(nb * cg + m) * cg + i) * c.t_ks + tap];
         }
         case K_TF_W2: {
             const int cg = c.FFN / c.t_groups, d = perm_k(g4, j);
             if (d >= cg) return 0.f;
-            return P[param_off(c, layer, P_TF_W2) + (int64_t)m * c.FFN + ks * cg + d];
+            return P[(int64_t)m * c.FFN + ks * cg + d];
         }
         // ---- transposed (data-gradient) operands ----
         case K_DEC_T:
-            return knat < c.C_out ? P[param_off_dec_w(c) + (int64_t)knat * H + m] : 0.f;
+            return knat < c.C_out ? P[(int64_t)knat * H + m] : 0.f;
         case K_FC1_T: case K_FC2_T: {
             // du[f][i] = sum_{tap',o} W[o][i][ks-1-tap'] dv[f + tap' - half][o]
             const int fg = H / c.f_groups, pc = fg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
             if (m >= fg || p >= c.f_ks * pc) return 0.f;
             const int tapp = p / pc, o = (p % pc) * 4 + (j & 3);
-            const int64_t w = param_off(c, layer, kind == K_FC1_T ? P_FC1_W : P_FC2_W);
-            return P[w + ((int64_t)(nb * fg + o) * fg + m) * c.f_ks + (c.f_ks - 1 - tapp)];
+            return P[((int64_t)(nb * fg + o) * fg + m) * c.f_ks + (c.f_ks - 1 - tapp)];
         }
         case K_SQ_T:
-            return knat < c.SQ ? P[param_off(c, layer, P_SQ_W) + (int64_t)knat * H + m] : 0.f;
+            return knat < c.SQ ? P[(int64_t)knat * H + m] : 0.f;
         case K_FULL_T:
-            return (m < c.F && knat < c.F) ? P[param_off(c, layer, P_FULL_W) + ((int64_t)nb * c.F + knat) * c.F + m] : 0.f;
+            return (m < c.F && knat < c.F) ? P[((int64_t)nb * c.F + knat) * c.F + m] : 0.f;
         case K_USQ_T: {
             const int ch = ks * 32 + perm_k(g4, j);
-            return m < c.SQ ? P[param_off(c, layer, P_USQ_W) + (int64_t)ch * c.SQ + m] : 0.f;
+            return m < c.SQ ? P[(int64_t)ch * c.SQ + m] : 0.f;
         }
         case K_INP_T: {
             const int dh = H / c.heads, which = ks / c.heads, head = ks % c.heads, d = perm_k(g4, j);
             if (d >= dh) return 0.f;
-            return P[param_off(c, layer, P_INP_W) + (int64_t)(which * H + head * dh + d) * H + m];
+            return P[(int64_t)(which * H + head * dh + d) * H + m];
         }
         case K_OUTP_T: {
             const int dh = H / c.heads, head = mt >> 1, d = (mt & 1) * 16 + l15;
             if (d >= dh) return 0.f;
-            return P[param_off(c, layer, P_OUTP_W) + (int64_t)knat * H + head * dh + d];
+            return P[(int64_t)knat * H + head * dh + d];
         }
         case K_TF_W1_T: {
             const int cg = c.FFN / c.t_groups, d = perm_k(g4, j);
             if (d >= cg) return 0.f;
-            return P[param_off(c, layer, P_TF_W1) + (int64_t)(ks * cg + d) * H + m];
+            return P[(int64_t)(ks * cg + d) * H + m];
         }
         case K_TF_C1_T: case K_TF_C2_T: case K_TF_C3_T: {
             const int cg = c.FFN / c.t_groups, pc = cg / 4, p = ks * 8 + g4 * 2 + (j >> 2);
             if (m >= cg || p >= c.t_ks * pc) return 0.f;
             const int tapp = p / pc, o = (p % pc) * 4 + (j & 3);
-            const int pk = kind == K_TF_C1_T ? P_TF_C1W : (kind == K_TF_C2_T ? P_TF_C2W : P_TF_C3W);
-            return P[param_off(c, layer, pk) + ((int64_t)(nb * cg + o) * cg + m) * c.t_ks + (c.t_ks - 1 - tapp)];
+            return P[((int64_t)(nb * cg + o) * cg + m) * c.t_ks + (c.t_ks - 1 - tapp)];
         }
         case K_TF_W2_T: {
             const int cg = c.FFN / c.t_groups, grp = mt >> 1, ci = (mt & 1) * 16 + l15;
             if (ci >= cg) return 0.f;
-            return P[param_off(c, layer, P_TF_W2) + (int64_t)knat * c.FFN + grp * cg + ci];
+            return P[(int64_t)knat * c.FFN + grp * cg + ci];
         }
     }
     return 0.f;
 }
 
+// per-kind source / destination offsets of one layer, resolved on the host (the offset arithmetic loops
+// over layers and kinds: never inside a kernel)
+struct PackTable {
+    long long src[NUM_PACK_KINDS], dst[NUM_PACK_KINDS];
+    int skip[NUM_PACK_KINDS];
+};
+
 template <class T>
-__global__ void pack_kernel(nbss_cfg c, const float* __restrict__ P, T* __restrict__ out) {
-    const int kind = blockIdx.y, layer = blockIdx.z;
-    if (pack_is_global(kind) && layer != 0) return;
+__global__ void pack_kernel(nbss_cfg c, PackTable tb, const float* __restrict__ P, T* __restrict__ out) {
+    const int kind = blockIdx.y;
+    if (tb.skip[kind]) return;
     const PackGeom g = pack_geom(c, kind);
     const int64_t n = (int64_t)g.NB * g.MT * g.KS * 512;
-    T* dst = out + pack_off(c, layer, kind);
+    T* dst = out + tb.dst[kind];
+    const float* W = P + tb.src[kind];
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t r = e >> 9;
         const int ks = (int)(r % g.KS);
         r /= g.KS;
         const int mt = (int)(r % g.MT), nb = (int)(r / g.MT);
-        store1(dst + e, pack_value(c, P, kind, layer, nb, mt, ks, lane, j));
+        store1(dst + e, pack_value(c, W, kind, nb, mt, ks, lane, j));
     }
 }
 
 int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipStream_t stream) {
-    dim3 grid(32, NUM_PACK_KINDS, c.L), block(256);
+    dim3 grid(16, NUM_PACK_KINDS), block(256);
     ProfScope ps(PK_PACK, stream);
-    if (c.dtype == NBSS_BF16)
-        NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, params, (bf16_t*)packed);
-    else
-        NBSS_LAUNCH((pack_kernel<float>), grid, block, 0, stream, c, params, (float*)packed);
-    return NBSS_CHECK_LAUNCH();
+    for (int layer = 0; layer < c.L; ++layer) {
+        PackTable tb;
+        for (int k = 0; k < NUM_PACK_KINDS; ++k) {
+            tb.skip[k] = pack_is_global(k) && layer != 0;
+            tb.src[k] = pack_src_base(c, k, layer);
+            tb.dst[k] = pack_off(c, layer, k);
+        }
+        if (c.dtype == NBSS_BF16)
+            NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, tb, params, (bf16_t*)packed);
+        else
+            NBSS_LAUNCH((pack_kernel<float>), grid, block, 0, stream, c, tb, params, (float*)packed);
+        int e = NBSS_CHECK_LAUNCH();
+        if (e) return e;
+    }
+    return NBSS_OK;
 }
 
 // ---- MFMA fragment self-test -------------------------------------------------------------

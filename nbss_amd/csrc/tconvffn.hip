@@ -13,6 +13,7 @@
 #include "layout.h"
 #include "prof.h"
 #include "wgrad.h"
+#include "blocks.h"
 
 #define TF_H 96
 #define TF_FFN 192
@@ -21,7 +22,11 @@
 #define TF_TP 256
 #define TF_NSW 2     // strips per wave, 8 waves
 #define TF_KS (TF_H / 32)
+#ifndef TF_FWD_WPS
+#define TF_FWD_WPS 2
+#endif
 #define TF_CKS 3     // conv k-steps: 18 pieces of 4 channels -> 3 x 8
+#define TF_AFF (2 * TF_FFN + 2 * TF_H)  // GN weight, GN bias, LN weight, LN bias partial sums per workgroup
 
 template <class T>
 NBSS_DEV void ln_strip_tf(const T* __restrict__ xr, bool valid, const float (&gam)[TF_KS][8], const float (&bet)[TF_KS][8], Frag<T> (&u)[TF_KS]) {
@@ -105,7 +110,7 @@ NBSS_DEV void store_rows(T* __restrict__ h, int t, bool valid, const f32x4& lo, 
 }
 
 template <class T>
-__global__ __launch_bounds__(512) void tconvffn_fwd_kernel(nbss_cfg c, const float* __restrict__ P, int layer, const T* __restrict__ W1,
+__global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, int layer, const T* __restrict__ W1,
                                                            const T* __restrict__ Wc1, const T* __restrict__ Wc2, const T* __restrict__ Wc3,
                                                            const T* __restrict__ W2, const T* __restrict__ x, T* __restrict__ y) {
     NBSS_LDS(smem);
@@ -117,15 +122,15 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_kernel(nbss_cfg c, const flo
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const T* xb = x + (size_t)bf * T_ * TF_H;
     T* yb = y + (size_t)bf * T_ * TF_H;
-    const float* lnw = P + param_off(c, layer, P_TF_LN_W);
-    const float* lnb = P + param_off(c, layer, P_TF_LN_B);
-    const float* b1 = P + param_off(c, layer, P_TF_B1);
-    const float* cb1 = P + param_off(c, layer, P_TF_C1B);
-    const float* cb2 = P + param_off(c, layer, P_TF_C2B);
-    const float* cb3 = P + param_off(c, layer, P_TF_C3B);
-    const float* gnw = P + param_off(c, layer, P_TF_GN_W);
-    const float* gnb = P + param_off(c, layer, P_TF_GN_B);
-    const float* b2 = P + param_off(c, layer, P_TF_B2);
+    const float* lnw = lp.p[P_TF_LN_W];
+    const float* lnb = lp.p[P_TF_LN_B];
+    const float* b1 = lp.p[P_TF_B1];
+    const float* cb1 = lp.p[P_TF_C1B];
+    const float* cb2 = lp.p[P_TF_C2B];
+    const float* cb3 = lp.p[P_TF_C3B];
+    const float* gnw = lp.p[P_TF_GN_W];
+    const float* gnb = lp.p[P_TF_GN_B];
+    const float* b2 = lp.p[P_TF_B2];
 
     // halo rows (t = -1 and t = TP) are never written by the strips: zero them once
     if (tid < TF_CG) {
@@ -317,7 +322,7 @@ NBSS_DEV float sum_l15(float v) {
 }
 
 template <class T>
-__global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, const float* __restrict__ P, float* __restrict__ G, int layer,
+__global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                            const T* __restrict__ W1, const T* __restrict__ Wc1, const T* __restrict__ Wc2,
                                                            const T* __restrict__ Wc3, const T* __restrict__ W1t, const T* __restrict__ Wc1t,
                                                            const T* __restrict__ Wc2t, const T* __restrict__ Wc3t, const T* __restrict__ W2t,
@@ -331,21 +336,23 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, const flo
     T* buf2 = buf1 + (size_t)(tp + 2) * TF_CG;
     T* buf3 = buf2 + (size_t)(tp + 2) * TF_CG;
     float* red = reinterpret_cast<float*>(buf3 + (size_t)(tp + 2) * TF_CG);  // [8 waves][2]
+    float* aff = red + 16;  // [576] per-workgroup sums: GN weight | GN bias | LN weight | LN bias
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
     const T* xb = x + n0 * TF_H;
     const T* dyb = dy + n0 * TF_H;
     T* dxb = dx + n0 * TF_H;
-    const float* lnw = P + param_off(c, layer, P_TF_LN_W);
-    const float* lnb = P + param_off(c, layer, P_TF_LN_B);
-    const float* b1 = P + param_off(c, layer, P_TF_B1);
-    const float* cb1 = P + param_off(c, layer, P_TF_C1B);
-    const float* cb2 = P + param_off(c, layer, P_TF_C2B);
-    const float* cb3 = P + param_off(c, layer, P_TF_C3B);
-    const float* gnw = P + param_off(c, layer, P_TF_GN_W);
-    const float* gnb = P + param_off(c, layer, P_TF_GN_B);
+    const float* lnw = lp.p[P_TF_LN_W];
+    const float* lnb = lp.p[P_TF_LN_B];
+    const float* b1 = lp.p[P_TF_B1];
+    const float* cb1 = lp.p[P_TF_C1B];
+    const float* cb2 = lp.p[P_TF_C2B];
+    const float* cb3 = lp.p[P_TF_C3B];
+    const float* gnw = lp.p[P_TF_GN_W];
+    const float* gnb = lp.p[P_TF_GN_B];
 
+    for (int i = tid; i < TF_AFF; i += blockDim.x) aff[i] = 0.f;
     if (tid < TF_CG) {
         T* bs[4] = {buf0, buf1, buf2, buf3};
 #pragma unroll
@@ -549,11 +556,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, const flo
         for (int r = 0; r < 4; ++r) {
             const float w0 = sum_l15(dgw[0][r]), w1 = sum_l15(dgw[1][r]), q0 = sum_l15(dgb[0][r]), q1 = sum_l15(dgb[1][r]);
             if (l15 == 0 && wact) {
-                atomicAdd(G + param_off(c, layer, P_TF_GN_W) + cbase + d0 + r, w0);
-                atomicAdd(G + param_off(c, layer, P_TF_GN_B) + cbase + d0 + r, q0);
+                atomicAdd(aff + cbase + d0 + r, w0);
+                atomicAdd(aff + TF_FFN + cbase + d0 + r, q0);
                 if (v1) {
-                    atomicAdd(G + param_off(c, layer, P_TF_GN_W) + cbase + d1 + r, w1);
-                    atomicAdd(G + param_off(c, layer, P_TF_GN_B) + cbase + d1 + r, q1);
+                    atomicAdd(aff + cbase + d1 + r, w1);
+                    atomicAdd(aff + TF_FFN + cbase + d1 + r, q1);
                 }
             }
         }
@@ -685,17 +692,20 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, const flo
         for (int r = 0; r < 4; ++r) {
             const float a = sum_l15(dlw[mt][r]), b = sum_l15(dlb[mt][r]);
             if (l15 == 0 && wact) {
-                atomicAdd(G + param_off(c, layer, P_TF_LN_W) + 16 * mt + 4 * g4 + r, a);
-                atomicAdd(G + param_off(c, layer, P_TF_LN_B) + 16 * mt + 4 * g4 + r, b);
+                atomicAdd(aff + 2 * TF_FFN + 16 * mt + 4 * g4 + r, a);
+                atomicAdd(aff + 2 * TF_FFN + TF_H + 16 * mt + 4 * g4 + r, b);
             }
         }
+    __syncthreads();
+    for (int i = tid; i < TF_AFF; i += blockDim.x) part[(size_t)blockIdx.x * TF_AFF + i] = aff[i];
 }
 
 template <class T>
-static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
+static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                           float* stats, void* const* opsv, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float);
+    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF) * sizeof(float);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
     TfOps<T> ops;
@@ -705,7 +715,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, const voi
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_B, st);
-    NBSS_LAUNCH((tconvffn_bwd_kernel<T>), grid, block, lds, st, c, P, G, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
+    NBSS_LAUNCH((tconvffn_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
                 pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W1_T),
                 pk + pack_off(c, layer, K_TF_C1_T), pk + pack_off(c, layer, K_TF_C2_T), pk + pack_off(c, layer, K_TF_C3_T),
                 pk + pack_off(c, layer, K_TF_W2_T), (const T*)x, (const T*)dy, (T*)dx, stats, ops);
@@ -714,15 +724,24 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, const voi
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
                       void* ws, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats [N][2] f32 | h1 h2 h4 h5 da1 da2 da3 da5, each [N][FFN] of the stream dtype
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     float* stats = (float*)ws;
     char* base = (char*)ws + ws_align(N * 2 * sizeof(float));
     void* ops[8];
     for (int i = 0; i < 8; ++i) ops[i] = base + (size_t)i * ws_align(N * TF_FFN * esz);
-    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_t<bf16_t>(c, P, G, packed, layer, x, dy, dx, stats, ops, st)
-                                 : tconvffn_bwd_t<float>(c, P, G, packed, layer, x, dy, dx, stats, ops, st);
+    float* part = (float*)((char*)ws + ws_part_offset(c));
+    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_t<bf16_t>(c, P, part, packed, layer, x, dy, dx, stats, ops, st)
+                                 : tconvffn_bwd_t<float>(c, P, part, packed, layer, x, dy, dx, stats, ops, st);
     if (e) return e;
+    AffSegs sg;
+    sg.n = 4;
+    sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
+    sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
+    sg.off[2] = param_off(c, layer, P_TF_LN_W); sg.cnt[2] = TF_H;
+    sg.off[3] = param_off(c, layer, P_TF_LN_B); sg.cnt[3] = TF_H;
+    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
     WgradArgs a;
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
@@ -742,19 +761,20 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     }
     // W1: dW1[FFN][H] = da1^T LN(x) ; db1 = colsum(da1)
     a.A = ops[4]; a.lda = TF_FFN; a.MA = TF_FFN; a.B = x; a.ldb = TF_H; a.NB = TF_H; a.groups = 1; a.taps = 1;
-    a.stats = stats; a.gamma = P + param_off(c, layer, P_TF_LN_W); a.beta = P + param_off(c, layer, P_TF_LN_B);
+    a.stats = stats; a.gamma = lp.p[P_TF_LN_W]; a.beta = lp.p[P_TF_LN_B];
     a.dW = G + param_off(c, layer, P_TF_W1); a.dbias = G + param_off(c, layer, P_TF_B1);
     return wgrad_launch(a, c.dtype, st);
 }
 
 template <class T>
 static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
     const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float);
     const T* pk = (const T*)packed;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_F, st);
-    NBSS_LAUNCH((tconvffn_fwd_kernel<T>), grid, block, lds, st, c, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
+    NBSS_LAUNCH((tconvffn_fwd_kernel<T>), grid, block, lds, st, c, lp, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
                 pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W2), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
