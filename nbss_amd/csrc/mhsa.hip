@@ -23,7 +23,7 @@
 #define MH_DH 24
 #define MH_TP 256
 #define MH_NT 16       // key/query tiles of 16 frames
-#define MH_NSW 4       // strips per wave (4 waves x 4 strips = 16 strips)
+#define MH_NSW 2       // strips per wave (8 waves x 2 strips = 16 strips; two waves per SIMD share one K/V image)
 #define MH_KS (MH_H / 32)
 
 // LN of a 16-frame strip held as natural-order B fragments (lane: frame l&15, channels 32ks+8g+j)
@@ -58,7 +58,7 @@ NBSS_DEV void ln_strip(const T* __restrict__ xr, bool valid, const float (&gam)[
 }
 
 template <class T, int HPP>
-__global__ __launch_bounds__(256) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+__global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
                                                        const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave) {
@@ -266,7 +266,7 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.F), block(256);
+    dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_MHSA_F, st);
     NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),

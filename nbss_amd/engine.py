@@ -143,6 +143,12 @@ class TrainStep:
         e = self.e
         loss, _, dout, xin, _ = self.forward_loss(x, yr, need_grad=True)
         e.backward(xin, dout)
+        self.apply_gradients()
+        return loss
+
+    def apply_gradients(self) -> None:
+        """[all-reduce] + clip + Adam + re-pack on whatever is in engine.grads"""
+        e = self.e
         if self.world > 1:
             # data parallel: ONE all-reduce (SUM) of the flat fp32 gradient over RCCL; the mean is folded into the clip kernel
             torch.distributed.all_reduce(e.grads, group=self.pg)
@@ -151,4 +157,3 @@ class TrainStep:
                            weight_decay=self.wd, max_norm=self.clip, grad_scale=1.0 / self.world, zero_grad=True)
         e.version += 1
         e.packed_for(e.dtype)  # re-pack inside the step: the next forward needs fresh fragments
-        return loss

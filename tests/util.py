@@ -6,9 +6,19 @@ from nbss_amd._lib import NBSS_BF16, NBSS_F32, make_cfg
 from oracle import spatialnet_ref as ref
 
 
+def _t(a):
+    import numpy as np
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(a)
+    a = a.detach().cpu()
+    if a.is_complex():
+        a = torch.view_as_real(a.to(torch.complex128))
+    return a.double()
+
+
 def rel_l2(a, b):
-    a = a.detach().double().cpu()
-    b = b.detach().double().cpu()
+    a = _t(a)
+    b = _t(b)
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
