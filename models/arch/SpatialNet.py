@@ -69,7 +69,7 @@ class _SpatialNetFn(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         eng, dtype = module._engine, module._stream_dtype()
         xin = x.detach().to(eng.stream_dtype(dtype)).contiguous()
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        train = module._want_grad  # grad mode is always off inside Function.forward: the module samples it before apply()
         out = eng.forward(xin, train=train, dtype=dtype)
         ctx.module, ctx.dtype, ctx.train = module, dtype, train
         ctx.save_for_backward(xin)
@@ -157,6 +157,7 @@ class SpatialNet(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.hp["num_freqs"] or x.shape[3] != self.hp["dim_input"]:
             raise ValueError(f"expected [B, {self.hp['num_freqs']}, T, {self.hp['dim_input']}], got {tuple(x.shape)}")
         self._engine_for(x.device)
+        self._want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._flat_params)
         y = _SpatialNetFn.apply(self, x, *self._flat_params)
         if return_attn_score:
             return y.contiguous(), [None] * len(self.layers)

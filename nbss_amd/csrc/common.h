@@ -43,6 +43,7 @@ NBSS_DEV float bf2f(bf16_t h) {
     c.u = ((uint32_t)h) << 16;
     return c.f;
 }
+#ifdef NBSS_EMU
 NBSS_DEV bf16_t f2bf(float f) {
     union { uint32_t u; float f; } c;
     c.f = f;
@@ -51,12 +52,34 @@ NBSS_DEV bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 NBSS_DEV uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+#else
+// gfx950: v_cvt_pk_bf16_f32 (round to nearest even), one instruction per pair instead of ~10 integer ops
+NBSS_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+NBSS_DEV uint32_t pack2bf(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+#endif
 
 NBSS_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 NBSS_DEV float dsilu_f(float x) {
     float s = 1.0f / (1.0f + __expf(-x));
     return s * (1.0f + x * (1.0f - s));
+}
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) but NOT for its global loads /
+// stores (vmcnt) — __syncthreads() drains both, which exposed the full global-store latency at each of the ~80 barriers
+// of the narrow-band backward kernels.  Use __syncthreads() wherever global memory written by another wave is read.
+NBSS_DEV void lds_barrier() {
+#ifdef NBSS_EMU
+    __syncthreads();
+#else
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt/expcnt untouched
+    __builtin_amdgcn_s_barrier();
+#endif
 }
 
 NBSS_DEV int lane_id() { return (int)(threadIdx.x & 63); }

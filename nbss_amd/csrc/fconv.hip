@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
         else
             vec_zero(d);
     }
-    __syncthreads();
+    lds_barrier();
     for (int r = tid; r < F * TT; r += nthr) {
         const int f = r / TT, tt = r % TT;
         if (t0 + tt < T_) ln_row_inplace(u + (size_t)(f + 2) * ROW + tt * FC_H, lnw, lnb);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 2: grouped conv on the matrix cores -----------------------------------------
     f32x4 acc[2][TT][FC_MTF_MAX];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
             }
         }
     }
-    __syncthreads();  // everyone is done reading u
+    lds_barrier();  // everyone is done reading u
 
     // ---- phase 3: bias + PReLU -> LDS [f][tt][H] ---------------------------------------------
     if (g4 < 3) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 4: residual add + coalesced store -------------------------------------------------
     for (int i = tid; i < F * VPR; i += nthr) {
@@ -214,9 +214,9 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
         else vec_zero(u + (size_t)rr * FC_H + off);
         vec_zero(dvb + (size_t)rr * FC_H + off);
     }
-    __syncthreads();
+    lds_barrier();
     for (int f = tid; f < F; f += nthr) ln_row_inplace(u + (size_t)(f + 2) * FC_H, lnw, lnb);
-    __syncthreads();
+    lds_barrier();
 
     float dsl[FC_G][4];
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- transposed conv -> du, LayerNorm backward, residual ----
     float dlw[FC_G][4], dlb[FC_G][4];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
                 atomicAdd(aff + 2 * FC_H + ch, s2);
             }
         }
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) part[(size_t)blockIdx.x * 3 * FC_H + i] = aff[i];
 }
 

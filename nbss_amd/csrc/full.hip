@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
     const int ntile = cdiv(F, 2);  // n-tiles of (2 freqs x 8 frames)
 
     for (int i = tid; i < FL_SQ * FL_TT * FK + FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
-    __syncthreads();
+    lds_barrier();
 
     // ---- pass 1: LN + squeeze + SiLU ---------------------------------------------------------
     {
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- pass 2: LinearGroup along F, one F x F matrix per squeeze channel -------------------
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- pass 3: unsqueeze + SiLU + residual -----------------------------------------------------
     {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 
     for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
     for (int i = tid; i < 2 * FL_H; i += nthr) aff[i] = 0.f;
-    __syncthreads();
+    lds_barrier();
 
     // ---- p1: LN + squeeze ----
     {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- p2: z = Wf s + bf ----
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- p3: recompute y_pre, dy_pre, dz = Wu^T dy_pre (dz overwrites s) ----
     {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- p4: ds = Wf^T dz ; ds_pre = ds * SiLU'(s_pre)  (ds_pre overwrites z) ----
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- p5: du = Ws^T ds_pre, LayerNorm backward + residual ----
     {
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         }
         ln_affine_flush(dlw, dlb, aff, aff + FL_H);
     }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < 2 * FL_H; i += nthr) part[(size_t)blockIdx.x * 2 * FL_H + i] = aff[i];
 }
 

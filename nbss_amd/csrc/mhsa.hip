@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
     for (int pass = 0; pass < MH_HEADS / HPP; ++pass) {
         // (all 16 strips are always projected, so every K / V^T entry is (re)written each pass and
         //  padded frames hold finite values: their keys are masked and their probabilities are 0)
-        if (pass > 0) __syncthreads();
+        if (pass > 0) lds_barrier();
 
         // ---- stage A: LN, then Q (registers), K and V^T (LDS) for this pass's heads --------
         Frag<T> qf[MH_NSW][HPP];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- stage B: attention per (strip, head); outputs stay in registers as B fragments ---
         Frag<T> of[MH_NSW][HPP];

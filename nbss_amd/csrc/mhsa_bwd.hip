@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---------------- pass 1: query strips -> dQ ----------------
 #pragma unroll
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 du[si][mt] = mma(a, dqf, du[si][mt]);
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---------------- pass 2: key strips -> dK, dV ----------------
 #pragma unroll
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 du[si][mt] = mma(a, dvf, du[si][mt]);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---------------- LayerNorm backward + residual ----------------
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         ln_bwd_row96<T>(du[si], x + n * MB_H, dy + n * MB_H, dx + n * MB_H, stats + n * 2, tv[si], lp.p[P_MH_LN_W], dlw, dlb);
     }
     ln_affine_flush(dlw, dlb, aff, aff + MB_H);
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) part[(size_t)blockIdx.x * 2 * MB_H + i] = aff[i];
 }
 

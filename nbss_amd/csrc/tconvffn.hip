@@ -73,6 +73,16 @@ NBSS_DEV void conv_bfrags(const T* __restrict__ hin, int t, Frag<T> (&bq)[TF_CKS
     }
 }
 
+// cooperative copy of `nfrag` packed weight fragments (512 elements each) global -> LDS; 16-byte vectors
+template <class T>
+NBSS_DEV void stage_frags(T* __restrict__ dst, const T* __restrict__ src, int nfrag) {
+    constexpr int VN = 16 / sizeof(T);
+    for (int v = threadIdx.x; v < nfrag * 512 / VN; v += blockDim.x)
+        *reinterpret_cast<u32x4*>(dst + (size_t)v * VN) = *reinterpret_cast<const u32x4*>(src + (size_t)v * VN);
+}
+template <class T>
+NBSS_DEV void lfrag(Frag<T>& f, const T* __restrict__ wl, int idx) { frag_load(f, wl + ((size_t)idx * 64 + lane_id()) * 8); }
+
 // one grouped conv for the wave's strips: out[si][half] (C tiles: lane = frame, rows = 4 channels)
 template <class T>
 NBSS_DEV void conv_group(const T* __restrict__ Wc, const T* __restrict__ hin, int w, f32x4 (&out)[TF_NSW][2]) {
@@ -117,6 +127,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
     T* ha = reinterpret_cast<T*>(smem);                    // [TP+2][24]
     T* hb = ha + (TF_TP + 2) * TF_CG;                      // [TP+2][24]
     float* red = reinterpret_cast<float*>(hb + (TF_TP + 2) * TF_CG);  // [8 waves][2]
+    T* wl = reinterpret_cast<T*>(red + 16);  // this group's weights: W1 | conv1 | conv2 | conv3 | W2, 6 fragments each
     const int T_ = c.T;
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -175,12 +186,20 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
         f32x4 ct[TF_NSW][2];
+        // the group's 30 weight fragments go through LDS once per workgroup (8 waves share them; the packed buffer is
+        // regularly evicted from L2 by the activation traffic, and per-wave global fragment loads sat in every MFMA chain)
+        stage_frags<T>(wl, W1 + (size_t)gr * 6 * 512, 6);
+        stage_frags<T>(wl + 6 * 512, Wc1 + (size_t)gr * 6 * 512, 6);
+        stage_frags<T>(wl + 12 * 512, Wc2 + (size_t)gr * 6 * 512, 6);
+        stage_frags<T>(wl + 18 * 512, Wc3 + (size_t)gr * 6 * 512, 6);
+        for (int mt = 0; mt < TF_H / 16; ++mt) stage_frags<T>(wl + (24 + mt) * 512, W2 + (size_t)(mt * TF_G + gr) * 512, 1);
+        lds_barrier();
         // (a) h1 = SiLU(W1_g LN(x) + b1_g) -> ha
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             Frag<T> a[TF_KS];
 #pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) wfrag_load(a[ks], W1, gr * 2 + half, TF_KS, ks);
+            for (int ks = 0; ks < TF_KS; ++ks) lfrag<T>(a[ks], wl, half * 3 + ks);
 #pragma unroll
             for (int si = 0; si < TF_NSW; ++si) {
                 f32x4 acc = F32X4_ZERO;
@@ -198,9 +217,9 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
             }
             store_rows<T>(ha, tt[si], tv[si], ct[si][0], ct[si][1]);
         }
-        __syncthreads();
+        lds_barrier();
         // (b) h2 = SiLU(gconv1(h1)) -> hb
-        conv_group<T>(Wc1 + (size_t)gr * 2 * TF_CKS * 512, ha, w, ct);
+        conv_group<T>(wl + 6 * 512, ha, w, ct);
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
 #pragma unroll
@@ -210,9 +229,9 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
             }
             store_rows<T>(hb, tt[si], tv[si], ct[si][0], ct[si][1]);
         }
-        __syncthreads();
+        lds_barrier();
         // (c) h3 = gconv2(h2); GroupNorm over (24 ch x T) ; h4 = SiLU(GN(h3)) -> ha
-        conv_group<T>(Wc2 + (size_t)gr * 2 * TF_CKS * 512, hb, w, ct);
+        conv_group<T>(wl + 12 * 512, hb, w, ct);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
@@ -232,7 +251,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
             red[2 * w] = s1;
             red[2 * w + 1] = s2;
         }
-        __syncthreads();
+        lds_barrier();
         float ts1 = 0.f, ts2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -252,9 +271,9 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
             }
             store_rows<T>(ha, tt[si], tv[si], ct[si][0], ct[si][1]);
         }
-        __syncthreads();
+        lds_barrier();
         // (d) h5 = SiLU(gconv3(h4)) stays in registers and feeds y += W2[:, group] h5
-        conv_group<T>(Wc3 + (size_t)gr * 2 * TF_CKS * 512, ha, w, ct);
+        conv_group<T>(wl + 18 * 512, ha, w, ct);
         Frag<T> h5[TF_NSW];
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
@@ -268,11 +287,11 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
 #pragma unroll
         for (int mt = 0; mt < TF_H / 16; ++mt) {
             Frag<T> a;
-            wfrag_load(a, W2, mt, TF_G, gr);
+            lfrag<T>(a, wl, 24 + mt);
 #pragma unroll
             for (int si = 0; si < TF_NSW; ++si) yacc[si][mt] = mma(a, h5[si], yacc[si][mt]);
         }
-        __syncthreads();  // ha / hb / red are rewritten by the next group
+        lds_barrier();  // ha / hb / red are rewritten by the next group
     }
 
 #pragma unroll
@@ -337,6 +356,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     T* buf3 = buf2 + (size_t)(tp + 2) * TF_CG;
     float* red = reinterpret_cast<float*>(buf3 + (size_t)(tp + 2) * TF_CG);  // [8 waves][2]
     float* aff = red + 16;  // [576] per-workgroup sums: GN weight | GN bias | LN weight | LN bias
+    T* wl = reinterpret_cast<T*>(aff + TF_AFF);  // this group's weights: W1 c1 c2 c3 | W2^T c3^T c2^T c1^T W1^T, 6 fragments each
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
@@ -405,12 +425,27 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
         f32x4 a1[TF_NSW][2], a2[TF_NSW][2], a3h[TF_NSW][2], a5[TF_NSW][2], ct[TF_NSW][2];
+        // this group's 54 weight fragments: global -> LDS once per workgroup (see the forward kernel); the fp32 stream has
+        // no LDS room for them and keeps reading the packed buffer directly
+        constexpr bool STAGE = sizeof(T) == 2;
+        const T* srcs[8] = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
+        const T* wsl[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wsl[i] = STAGE ? wl + (size_t)i * 6 * 512 : srcs[i] + (size_t)gr * 6 * 512;
+        const T* w1t_base = STAGE ? wl + 48 * 512 : W1t + (size_t)gr * 512;
+        const int w1t_stride = STAGE ? 512 : TF_G * 512;
+        if (STAGE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stage_frags<T>(wl + (size_t)i * 6 * 512, srcs[i] + (size_t)gr * 6 * 512, 6);
+            for (int mt = 0; mt < TF_H / 16; ++mt) stage_frags<T>(wl + (48 + mt) * 512, W1t + (size_t)(mt * TF_G + gr) * 512, 1);
+            lds_barrier();
+        }
         // ---------------- forward recompute ----------------
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             Frag<T> a[TF_KS];
 #pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) wfrag_load(a[ks], W1, gr * 2 + half, TF_KS, ks);
+            for (int ks = 0; ks < TF_KS; ++ks) lfrag<T>(a[ks], wsl[0], half * 3 + ks);
 #pragma unroll
             for (int si = 0; si < TF_NSW; ++si) {
                 f32x4 acc = F32X4_ZERO;
@@ -431,8 +466,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             store_rows<T>(buf0, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.h1, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
         }
-        __syncthreads();
-        conv_group<T>(Wc1 + (size_t)gr * 2 * TF_CKS * 512, buf0, w, a2);
+        lds_barrier();
+        conv_group<T>(wsl[1], buf0, w, a2);
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
 #pragma unroll
@@ -445,8 +480,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.h2, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
         }
-        __syncthreads();
-        conv_group<T>(Wc2 + (size_t)gr * 2 * TF_CKS * 512, buf1, w, a3h);
+        lds_barrier();
+        conv_group<T>(wsl[2], buf1, w, a3h);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si)
@@ -465,7 +500,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             red[2 * w] = s1;
             red[2 * w + 1] = s2;
         }
-        __syncthreads();
+        lds_barrier();
         float ts1 = 0.f, ts2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -492,8 +527,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.h4, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
         }
-        __syncthreads();
-        conv_group<T>(Wc3 + (size_t)gr * 2 * TF_CKS * 512, buf2, w, a5);
+        lds_barrier();
+        conv_group<T>(wsl[3], buf2, w, a5);
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
 #pragma unroll
@@ -511,7 +546,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         for (int half = 0; half < 2; ++half) {
             Frag<T> a[TF_KS];
 #pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) wfrag_load(a[ks], W2t, gr * 2 + half, TF_KS, ks);
+            for (int ks = 0; ks < TF_KS; ++ks) lfrag<T>(a[ks], wsl[4], half * 3 + ks);
 #pragma unroll
             for (int si = 0; si < TF_NSW; ++si) {
                 f32x4 acc = F32X4_ZERO;
@@ -530,9 +565,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             store_rows<T>(buf3, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.da5, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
         }
-        __syncthreads();
+        lds_barrier();
         // dh4 = conv3^T(da5) ; dn3 = dh4 * silu'(n3) ; GroupNorm backward -> da3 -> buf2
-        conv_group<T>(Wc3t + (size_t)gr * 2 * TF_CKS * 512, buf3, w, ct);
+        conv_group<T>(wsl[5], buf3, w, ct);
         float sa = 0.f, sb = 0.f;
         float dgw[2][4], dgb[2][4];
 #pragma unroll
@@ -566,12 +601,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         }
         sa = wave_sum64(sa);
         sb = wave_sum64(sb);
-        __syncthreads();  // red is free again (everyone has read the forward statistics)
+        lds_barrier();  // red is free again (everyone has read the forward statistics)
         if (lane == 0) {
             red[2 * w] = sa;
             red[2 * w + 1] = sb;
         }
-        __syncthreads();
+        lds_barrier();
         float tsa = 0.f, tsb = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -590,9 +625,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.da3, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
         }
-        __syncthreads();
+        lds_barrier();
         // dh2 = conv2^T(da3) ; da2 = dh2 * silu'(a2) -> buf1
-        conv_group<T>(Wc2t + (size_t)gr * 2 * TF_CKS * 512, buf2, w, ct);
+        conv_group<T>(wsl[6], buf2, w, ct);
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
 #pragma unroll
@@ -603,9 +638,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.da2, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
         }
-        __syncthreads();
+        lds_barrier();
         // dh1 = conv1^T(da2) ; da1 = dh1 * silu'(a1) ; du += W1[group]^T da1
-        conv_group<T>(Wc1t + (size_t)gr * 2 * TF_CKS * 512, buf1, w, ct);
+        conv_group<T>(wsl[7], buf1, w, ct);
         Frag<T> da1f[TF_NSW];
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
@@ -620,11 +655,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 #pragma unroll
         for (int mt = 0; mt < TF_H / 16; ++mt) {
             Frag<T> a;
-            wfrag_load(a, W1t, mt, TF_G, gr);
+            lfrag<T>(a, w1t_base + (size_t)mt * w1t_stride, 0);
 #pragma unroll
             for (int si = 0; si < TF_NSW; ++si) du[si][mt] = mma(a, da1f[si], du[si][mt]);
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---------------- LayerNorm backward + residual, in registers ----------------
@@ -696,7 +731,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 atomicAdd(aff + 2 * TF_FFN + TF_H + 16 * mt + 4 * g4 + r, b);
             }
         }
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < TF_AFF; i += blockDim.x) part[(size_t)blockIdx.x * TF_AFF + i] = aff[i];
 }
 
@@ -705,7 +740,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
                           float* stats, void* const* opsv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF) * sizeof(float);
+    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF) * sizeof(float) + (sizeof(T) == 2 ? (size_t)54 * 512 * sizeof(T) : 0);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
     TfOps<T> ops;
@@ -770,7 +805,7 @@ template <class T>
 static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float);
+    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float) + (size_t)30 * 512 * sizeof(T);
     const T* pk = (const T*)packed;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_F, st);

@@ -7,218 +7,251 @@
 // (b,t).  X may be LayerNorm(x) applied on the fly from the per-token (mean, rstd) the data-gradient
 // kernels emit, so the normalised tensor is never materialised.
 //
-// One workgroup contracts its share of 64-token chunks.  Both operands are staged TRANSPOSED in LDS
-// ([column][64 tokens], 144-byte rows: conflict-free 16-byte fragment reads): a thread fetches a 4-token x
-// 4-channel block with four 8-byte loads, transposes it in registers (free) and writes four 8-byte rows.
-// The next chunk's global loads are issued before the current chunk's MFMAs (register prefetch).  Up to 8
-// output tiles per wave accumulate in registers across all chunks and are flushed with atomicAdd into the
-// fp32 gradient buffer; column sums of dY (the bias gradients) ride along.
+// One workgroup (8 waves) owns ALL output tiles of a problem (of one group for LinearGroup) and contracts its
+// share of 32-token chunks: full operand rows are fetched once (16-byte loads where the width allows), a thread
+// transposes a 4-token x 4|8-channel block in registers and writes 8-byte rows into the TRANSPOSED LDS images
+// ([column][32 tokens], 80-byte rows: conflict-free 16-byte fragment reads), so MFMA A/B fragments (K = tokens) are
+// single ds_read_b128's.  Up to 14 C tiles per wave accumulate in registers across all chunks and are flushed with
+// atomicAdd into the fp32 gradient buffer; column sums of dY (the bias gradients) ride along.
+// r01 history (profiles/): per-group workgroups re-read every row 8x in 48-byte pieces and dense problems re-staged the
+// operands once per 32-tile block (27 ms/step); runtime integer divisions in the staging loop (-3 ms when hoisted);
+// a register prefetch across the barrier spilled and was slower (26.8 vs 24.4 ms/step).
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
 #include "prof.h"
 
-#define WG_KC 64
-#define WG_LD 72     // LDS row length in elements (64 tokens + pad)
-#define WG_TPW 8     // output tiles per wave
-#define WG_WAVES 4
-#define WG_MAXBLK 2  // 4x4 blocks a thread prefetches per chunk (wider operands: the rest is fetched in place)
+#define WG_KC 32
+#define WG_LD 40     // LDS row length in elements (32 tokens + pad)
+#define WG_TPW 14    // output tiles per wave
+#define WG_WAVES 8
+#define WG_THREADS (WG_WAVES * 64)
 
-struct Blk {  // one 4-token x 4-channel block in flight
-    float v[4][4];
-};
+template <class T, int CW>  // CW = channels per staging block (4 or 8)
+NBSS_DEV void load_cw(const T* p, float (&v)[8]) {
+    if (CW == 8) load8(p, v);
+    else load4(p, v);
+}
 
-template <class T>
-__global__ __launch_bounds__(256, 4) void wgrad_kernel(WgradArgs a) {
+template <class T, int CW>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
     NBSS_LDS(smem);
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
     const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
-    const int tiles_per_group = mtiles * ntiles;
-    const int TPB = WG_WAVES * WG_TPW;
-    int grp, tile0, acols0, ncolsA, bcols0, ncolsB;
-    if (a.groups > 1) {
-        const int bpg = cdiv(tiles_per_group, TPB);
-        grp = blockIdx.y / bpg;
-        tile0 = (blockIdx.y % bpg) * TPB;
-        acols0 = grp * mg; ncolsA = mg;
-        bcols0 = grp * ng; ncolsB = ng;
-    } else {
-        grp = 0;
-        tile0 = blockIdx.y * TPB;
-        acols0 = 0; ncolsA = a.MA;
-        bcols0 = 0; ncolsB = a.NB;
-    }
-    const int rowsA = mtiles * 16, rowsB = ntiles * 16;
-    T* At = reinterpret_cast<T*>(smem);            // [rowsA][WG_LD]
-    T* Bt = At + (size_t)rowsA * WG_LD;            // [rowsB][WG_LD]  (expanded columns: tap * ng + i)
-    for (int i = tid; i < (rowsA + rowsB) * WG_LD; i += blockDim.x) store1(At + i, 0.f);
+    const int tpg = mtiles * ntiles;
+    // blockIdx.y selects a group when the groups are too large to share a workgroup (LinearGroup); else all groups
+    const bool per_group = gridDim.y > 1;
+    const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
+    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
+    const int mgp = mtiles * 16, ngp = ntiles * 16;
+    const int rowsA = ngrp * mgp, rowsB = ngrp * ngp;
+    T* At = reinterpret_cast<T*>(smem);            // [rowsA][WG_LD]   row = g*mgp + m
+    T* Bt = At + (size_t)rowsA * WG_LD;            // [rowsB][WG_LD]   row = g*ngp + tap*ng + i
+    for (int i = tid; i < (rowsA + rowsB) * WG_LD; i += WG_THREADS) store1(At + i, 0.f);
 
     f32x4 acc[WG_TPW];
 #pragma unroll
     for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
-    float bsum[2] = {0.f, 0.f};
-    const bool do_bias = a.dbias != nullptr && tile0 == 0;
+    float bsum = 0.f;
+    const bool do_bias = a.dbias != nullptr;
     const T* Ag = reinterpret_cast<const T*>(a.A);
     const T* Bg = reinterpret_cast<const T*>(a.B);
-    const int pcA = ncolsA / 4, pcB = ncolsB / 4, center = a.taps / 2;
+    const int pcA = ncolsA / CW, pcB = ncolsB / CW, center = a.taps / 2;
     const int qB = (WG_KC / 4) * pcB;
     const int nblkA = (WG_KC / 4) * pcA, nblk = nblkA + a.taps * qB;
     const int nchunks = cdiv(a.Ntok, WG_KC);
+    const int ntot = ngrp * tpg;
+    lds_barrier();
 
-    // fetch block `bi` of the chunk starting at token n0 into registers (zero outside the valid range)
-    auto fetch = [&](int bi, int n0, Blk& blk) {
-        if (bi < nblkA) {
-            const int q = bi / pcA, pc = bi % pcA;
+    // Block descriptors are chunk-independent: resolve the (token quad, columns, tap, LDS rows) of this thread's blocks ONCE
+    // (runtime integer divisions are ~40 VALU instructions each and used to dominate the staging loop).
+    constexpr int MAXB = 3;
+    int bq[MAXB], bc0[MAXB], bd[MAXB];
+    T* brow[MAXB];
+    bool bA[MAXB], bok[MAXB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 4 * q + r;
-                if (n < a.Ntok) load4(Ag + (size_t)n * a.lda + acols0 + 4 * pc, blk.v[r]);
-                else blk.v[r][0] = blk.v[r][1] = blk.v[r][2] = blk.v[r][3] = 0.f;
-            }
+    for (int u = 0; u < MAXB; ++u) {
+        const int bi = tid + u * WG_THREADS;
+        bok[u] = bi < nblk;
+        bA[u] = bi < nblkA;
+        int tap = 0, c0;
+        if (bA[u]) {
+            bq[u] = bi / pcA;
+            c0 = (bi % pcA) * CW;
+            brow[u] = At + (size_t)((c0 / mg) * mgp + c0 % mg) * WG_LD;
         } else {
-            const int b2 = bi - nblkA;
-            const int tap = b2 / qB, rem = b2 % qB, q = rem / pcB, pc = rem % pcB;
-            const int d = tap - center;
+            const int b2 = bok[u] ? bi - nblkA : 0, rem = b2 % qB;
+            tap = b2 / qB;
+            bq[u] = rem / pcB;
+            c0 = (rem % pcB) * CW;
+            brow[u] = Bt + (size_t)((c0 / ng) * ngp + tap * ng + c0 % ng) * WG_LD;
+        }
+        bc0[u] = c0;
+        bd[u] = tap - center;
+    }
+    const bool shifted = a.taps > 1;
+
+    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int n0 = ch * WG_KC;
+        // ---- stage both operands, transposed (4 tokens x CW channels per thread-block) ----
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 4 * q + r;
-                blk.v[r][0] = blk.v[r][1] = blk.v[r][2] = blk.v[r][3] = 0.f;
-                if (n < a.Ntok) {
-                    const int pos = a.shift_dim == 0 ? n % a.T : (n / a.T) % a.F;
-                    const int lim = a.shift_dim == 0 ? a.T : a.F;
-                    if (pos + d >= 0 && pos + d < lim) {
-                        const size_t ns = (size_t)((long)n + (long)d * a.shift_stride);
-                        load4(Bg + ns * a.ldb + bcols0 + 4 * pc, blk.v[r]);
+        for (int u = 0; u < MAXB; ++u) {
+            if (!bok[u]) continue;
+            float v[4][8];
+            const int nb = n0 + 4 * bq[u];
+            if (bA[u]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nb + r < a.Ntok) load_cw<T, CW>(Ag + (size_t)(nb + r) * a.lda + acols0 + bc0[u], v[r]);
+                    else
+#pragma unroll
+                        for (int e = 0; e < CW; ++e) v[r][e] = 0.f;
+                }
+            } else {
+                int pos = 0;
+                if (shifted) pos = a.shift_dim == 0 ? nb % a.T : (nb / a.T) % a.F;  // one division per block and chunk
+                const int lim = a.shift_dim == 0 ? a.T : a.F;
+                const int tb = (shifted && a.shift_dim == 1) ? nb % a.T : 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb + r;
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[r][e] = 0.f;
+                    // index along the shifted axis of row r (frames wrap at T; the frequency changes every T rows)
+                    int pr = pos;
+                    if (shifted) {
+                        if (a.shift_dim == 0) { pr = pos + r; if (pr >= a.T) pr -= a.T; }
+                        else if (tb + r >= a.T) pr = (n / a.T) % a.F;
+                    }
+                    if (n < a.Ntok && pr + bd[u] >= 0 && pr + bd[u] < lim) {
+                        const size_t ns = (size_t)((long)n + (long)bd[u] * a.shift_stride);
+                        load_cw<T, CW>(Bg + ns * a.ldb + bcols0 + bc0[u], v[r]);
                         if (a.stats) {
                             const float mu = a.stats[2 * ns], rs = a.stats[2 * ns + 1];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int col = bcols0 + 4 * pc + e;
-                                blk.v[r][e] = round_to((blk.v[r][e] - mu) * rs * a.gamma[col] + a.beta[col], Bg);
+                            for (int e = 0; e < CW; ++e) {
+                                const int col = bcols0 + bc0[u] + e;
+                                v[r][e] = round_to((v[r][e] - mu) * rs * a.gamma[col] + a.beta[col], Bg);
                             }
                         }
                     }
                 }
             }
-        }
-    };
-    // write the (register-)transposed block: 4 channels x 4 consecutive tokens
-    auto stash = [&](int bi, const Blk& blk) {
-        T* dst;
-        int q;
-        if (bi < nblkA) {
-            q = bi / pcA;
-            dst = At + (size_t)(4 * (bi % pcA)) * WG_LD;
-        } else {
-            const int b2 = bi - nblkA;
-            const int tap = b2 / qB, rem = b2 % qB;
-            q = rem / pcB;
-            dst = Bt + (size_t)(tap * ng + 4 * (rem % pcB)) * WG_LD;
-        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) store4(dst + (size_t)e * WG_LD + 4 * q, blk.v[0][e], blk.v[1][e], blk.v[2][e], blk.v[3][e]);
-    };
-
-    __syncthreads();  // zero fill done
-    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        // latency is hidden by occupancy (4+ workgroups per CU), not by a register prefetch: keeping blocks in flight
-        // across the barrier cost 3x the registers and 2.5x the time (profiles/r01_c_*)
-        for (int bi = tid; bi < nblk; bi += 256) {
-            Blk t;
-            fetch(bi, ch * WG_KC, t);
-            stash(bi, t);
+            for (int e = 0; e < CW; ++e) store4(brow[u] + (size_t)e * WG_LD + 4 * bq[u], v[0][e], v[1][e], v[2][e], v[3][e]);
         }
-        __syncthreads();
-        // ---- MFMA: K = the 64 tokens of this chunk (two k-steps) ----
+        for (int bi = tid + MAXB * WG_THREADS; bi < nblk; bi += WG_THREADS) {  // (very wide operands only; none on the SpatialNet-small path)
+            float v[4][8];
+            const bool isA = bi < nblkA;
+            int q, c0, tap = 0;
+            if (isA) { q = bi / pcA; c0 = (bi % pcA) * CW; }
+            else { const int b2 = bi - nblkA, rem = b2 % qB; tap = b2 / qB; q = rem / pcB; c0 = (rem % pcB) * CW; }
+            const int d = tap - center;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * q + r;
+#pragma unroll
+                for (int e = 0; e < CW; ++e) v[r][e] = 0.f;
+                if (n >= a.Ntok) continue;
+                if (isA) { load_cw<T, CW>(Ag + (size_t)n * a.lda + acols0 + c0, v[r]); continue; }
+                const int pos = a.shift_dim == 0 ? n % a.T : (n / a.T) % a.F, lim = a.shift_dim == 0 ? a.T : a.F;
+                if (pos + d < 0 || pos + d >= lim) continue;
+                const size_t ns = (size_t)((long)n + (long)d * a.shift_stride);
+                load_cw<T, CW>(Bg + ns * a.ldb + bcols0 + c0, v[r]);
+                if (a.stats) {
+                    const float mu = a.stats[2 * ns], rs = a.stats[2 * ns + 1];
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) v[r][e] = round_to((v[r][e] - mu) * rs * a.gamma[bcols0 + c0 + e] + a.beta[bcols0 + c0 + e], Bg);
+                }
+            }
+            T* row = isA ? At + (size_t)((c0 / mg) * mgp + c0 % mg) * WG_LD : Bt + (size_t)((c0 / ng) * ngp + tap * ng + c0 % ng) * WG_LD;
+#pragma unroll
+            for (int e = 0; e < CW; ++e) store4(row + (size_t)e * WG_LD + 4 * q, v[0][e], v[1][e], v[2][e], v[3][e]);
+        }
+        lds_barrier();
+        // ---- MFMA: K = the 32 tokens of this chunk ----
 #pragma unroll
         for (int s = 0; s < WG_TPW; ++s) {
-            const int tl = tile0 + s * WG_WAVES + w;
-            if (tl < tiles_per_group) {
-                const int mt = tl / ntiles, nt = tl % ntiles;
-#pragma unroll
-                for (int ks = 0; ks < WG_KC / 32; ++ks) {
-                    Frag<T> fa, fb;
-                    frag_load(fa, At + (size_t)(mt * 16 + l15) * WG_LD + ks * 32 + 8 * g4);
-                    frag_load(fb, Bt + (size_t)(nt * 16 + l15) * WG_LD + ks * 32 + 8 * g4);
-                    acc[s] = mma(fa, fb, acc[s]);
-                }
+            const int tl = s * WG_WAVES + w;
+            if (tl < ntot) {
+                const int g = tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+                Frag<T> fa, fb;
+                frag_load(fa, At + (size_t)(g * mgp + mt * 16 + l15) * WG_LD + 8 * g4);
+                frag_load(fb, Bt + (size_t)(g * ngp + nt * 16 + l15) * WG_LD + 8 * g4);
+                acc[s] = mma(fa, fb, acc[s]);
             }
         }
-        if (do_bias) {
+        if (do_bias && tid < rowsA) {
+            float v[8];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int col = tid + q * 256;
-                if (col < ncolsA) {
-                    float v[8], sacc = 0.f;
+            for (int k8 = 0; k8 < WG_KC; k8 += 8) {
+                load8(At + (size_t)tid * WG_LD + k8, v);
 #pragma unroll
-                    for (int k8 = 0; k8 < WG_KC; k8 += 8) {
-                        load8(At + (size_t)col * WG_LD + k8, v);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sacc += v[e];
-                    }
-                    bsum[q] += sacc;
-                }
+                for (int e = 0; e < 8; ++e) bsum += v[e];
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- flush ----
 #pragma unroll
     for (int s = 0; s < WG_TPW; ++s) {
-        const int tl = tile0 + s * WG_WAVES + w;
-        if (tl < tiles_per_group) {
-            const int mt = tl / ntiles, nt = tl % ntiles;
+        const int tl = s * WG_WAVES + w;
+        if (tl < ntot) {
+            const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
             const int q = nt * 16 + l15;
             if (q < nexp) {
                 const int tap = q / ng, i = q % ng;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mt * 16 + 4 * g4 + r;
-                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(grp * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
+                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
                 }
             }
         }
     }
-    if (do_bias) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int col = tid + q * 256;
-            if (col < ncolsA && (col % mg) < mv) atomicAdd(a.dbias + (size_t)((acols0 + col) / mg) * mv + (col % mg), bsum[q]);
-        }
+    if (do_bias && tid < rowsA) {
+        const int g = g_lo + tid / mgp, m = tid % mgp;
+        if (m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, bsum);
     }
+}
+
+template <class T>
+static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
+    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
+    const int mtiles = cdiv(mg, 16), ntiles = cdiv(a.taps * ng, 16), tpg = mtiles * ntiles;
+    const int cap = WG_WAVES * WG_TPW;
+    if (tpg > cap) return NBSS_EUNSUPPORTED;
+    // all groups in one workgroup when their tiles and LDS images fit, else one group per blockIdx.y
+    size_t lds_all = (size_t)a.groups * (mtiles + ntiles) * 16 * WG_LD * sizeof(T);
+    const bool all = a.groups * tpg <= cap && lds_all <= 80 * 1024 && mtiles * 16 * a.groups <= WG_THREADS;
+    const int ybl = all ? 1 : a.groups;
+    const size_t lds = all ? lds_all : (size_t)(mtiles + ntiles) * 16 * WG_LD * sizeof(T);
+    if (lds > 160 * 1024 || mtiles * 16 > WG_THREADS) return NBSS_EUNSUPPORTED;
+    // a staging block must not straddle a group: the per-group widths have to be multiples of the block width
+    const bool cw8 = mg % 8 == 0 && ng % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && sizeof(T) == 2;
+    const int nchunks = cdiv(a.Ntok, WG_KC);
+    int xbl = 384 / ybl;  // 1-2 resident workgroups (8-16 waves) per CU; every x-block ends with one atomicAdd per output element
+    if (xbl < 16) xbl = 16;
+    if (xbl > nchunks) xbl = nchunks;
+    dim3 grid(xbl, ybl), block(WG_THREADS);
+    ProfScope ps(PK_WGRAD, st);
+    int e;
+    if (cw8) {
+        if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, 8>), lds))) return e;
+        NBSS_LAUNCH((wgrad_kernel<T, 8>), grid, block, lds, st, a);
+    } else {
+        if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, 4>), lds))) return e;
+        NBSS_LAUNCH((wgrad_kernel<T, 4>), grid, block, lds, st, a);
+    }
+    return NBSS_CHECK_LAUNCH();
 }
 
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
     if (a.MA % a.groups || a.NB % a.groups) return NBSS_EINVAL;
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
-    if (mg % 4 || ng % 4 || mg > 512) return NBSS_EUNSUPPORTED;
-    const int mtiles = cdiv(mg, 16), ntiles = cdiv(a.taps * ng, 16);
-    const int tpb = WG_WAVES * WG_TPW;
-    const int ybl = a.groups > 1 ? a.groups * cdiv(mtiles * ntiles, tpb) : cdiv(mtiles * ntiles, tpb);
-    const int rowsA = (a.groups > 1 ? mtiles : cdiv(a.MA, 16)) * 16, rowsB = ntiles * 16;
-    const size_t esz = dtype == NBSS_BF16 ? 2 : 4;
-    const size_t lds = (size_t)(rowsA + rowsB) * WG_LD * esz;
-    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
-    const int nchunks = cdiv(a.Ntok, WG_KC);
-    // every x-block ends with one atomicAdd per output element: keep the per-address contention bounded
-    int xbl = 768 / ybl;
-    if (xbl > 192) xbl = 192;
-    if (xbl < 8) xbl = 8;
-    if (xbl > nchunks) xbl = nchunks;
-    dim3 grid(xbl, ybl), block(256);
-    ProfScope ps(PK_WGRAD, st);
-    int e;
-    if (dtype == NBSS_BF16) {
-        e = NBSS_SET_MAX_LDS((wgrad_kernel<bf16_t>), lds);
-        if (e) return e;
-        NBSS_LAUNCH((wgrad_kernel<bf16_t>), grid, block, lds, st, a);
-    } else {
-        e = NBSS_SET_MAX_LDS((wgrad_kernel<float>), lds);
-        if (e) return e;
-        NBSS_LAUNCH((wgrad_kernel<float>), grid, block, lds, st, a);
-    }
-    return NBSS_CHECK_LAUNCH();
+    if (mg % 4 || ng % 4) return NBSS_EUNSUPPORTED;
+    return dtype == NBSS_BF16 ? wgrad_launch_t<bf16_t>(a, st) : wgrad_launch_t<float>(a, st);
 }

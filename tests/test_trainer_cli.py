@@ -1,0 +1,64 @@
+"""The LightningCLI-shaped surface: the reference's own configs/SpatialNet.yaml (when present) and this repo's configs
+parse with the reference's command line and build the drop-in modules; `fit` itself is a gpu test."""
+from pathlib import Path
+
+import pytest
+import torch
+
+from SharedTrainer import TrainCLI, build_module, parse_cli
+
+ROOT = Path(__file__).resolve().parent.parent
+ARGS = ["--model.arch.dim_input=12", "--model.arch.dim_output=4", "--model.arch.num_freqs=129", "--trainer.precision=bf16-mixed",
+        "--model.exp_name", "notag", "--data.batch_size=[2,4]"]
+
+
+@pytest.mark.parametrize("cfg", [ROOT / "configs" / "SpatialNet.yaml", Path("/root/reference/configs/SpatialNet.yaml")])
+def test_config_builds_dropin_modules(cfg):
+    if not cfg.exists():
+        pytest.skip("reference tree not present")
+    sub, c = parse_cli(["fit", "--config", str(cfg), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml")] + ARGS)
+    assert sub == "fit" and c["trainer"]["precision"] == "bf16-mixed" and c["trainer"]["gradient_clip_val"] == 5
+    assert c["data"]["init_args"]["batch_size"] == [2, 4]
+    m = build_module(c)
+    assert type(m.arch).__module__ == "models.arch.SpatialNet"
+    assert sum(p.numel() for p in m.arch.parameters()) == 1191092  # reference: 1.2 M (images/model_size_and_flops.png)
+    sd = m.arch.state_dict()
+    for k, shape in {"encoder.weight": (96, 12, 5), "layers.3.fconv1.1.weight": (96, 12, 5), "layers.7.full.weight": (8, 129, 129),
+                     "layers.0.mhsa.in_proj_weight": (288, 96), "layers.5.tconvffn.6.weight": (192,), "layers.2.tconvffn.8.weight": (192, 24, 3),
+                     "decoder.weight": (4, 96)}.items():
+        assert tuple(sd[k].shape) == shape, k  # checkpoint contract, SURVEY.md §8(b)
+    assert sd["layers.7.full.weight"].data_ptr() == sd["layers.0.full.weight"].data_ptr()  # full_share=0: one shared LinearGroup
+    assert m.loss.name == "neg_si_sdr" and m.loss.pit and m.optimizer == ("Adam", {"lr": 0.001})
+
+
+@pytest.mark.gpu
+def test_fit_one_epoch_on_gpu():
+    argv = ["fit", "--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml"),
+            "--model.arch.dim_input=12", "--model.arch.dim_output=4", "--trainer.precision=bf16-mixed", "--trainer.max_epochs=2",
+            "--data.num_samples=[8,2,2]", "--data.audio_time_len=[1.0,1.0,1.0]", "--model.arch.num_layers=2"]
+    cli = TrainCLI(argv=argv)
+    log = cli.result["log"]
+    assert len(log) == 2 and all(torch.isfinite(torch.tensor(r["train/neg_si_sdr"])) for r in log)
+    assert log[1]["train/neg_si_sdr"] < log[0]["train/neg_si_sdr"]
+
+
+@pytest.mark.gpu
+def test_dropin_module_autograd_on_gpu():
+    """models.arch.SpatialNet.SpatialNet as a plain nn.Module under torch autograd + torch.optim (generic trainer path)"""
+    from models.arch.SpatialNet import SpatialNet
+    torch.manual_seed(0)
+    net = SpatialNet(dim_input=12, dim_output=4, num_layers=1, dim_hidden=96, dim_ffn=192, num_heads=4, dim_squeeze=8, num_freqs=129).cuda()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    x = torch.randn(2, 129, 40, 12, device="cuda")
+    tgt = torch.randn(2, 129, 40, 4, device="cuda")
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+        loss = ((y - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    assert all(p.grad is not None for p in net.parameters())
