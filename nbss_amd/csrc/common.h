@@ -207,6 +207,27 @@ NBSS_DEV f32x4 mma(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
     return c;
 }
 
+// Transposing LDS read (bf16 only): the 16 lanes of a group read a 4-row x 16-column block of a row-major image — lane p
+// passes the address of row (p>>2), columns 4(p&3)..+3 — and lane l receives column l of the 4 rows.  Two of these turn a
+// row-major [token][channel] tile into an MFMA operand whose K dimension is the token axis (permuted K order).
+NBSS_DEV u32x2 lds_tr4_b16(const bf16_t* p) {
+#ifdef NBSS_EMU
+    uint64_t r = hipemu::ds_read_tr16_b64(p);
+    u32x2 v = {(uint32_t)(r & 0xFFFFFFFFu), (uint32_t)(r >> 32)};
+    return v;
+#else
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+    return __builtin_bit_cast(u32x2, v);
+#endif
+}
+// fragment (K = 32 tokens, permuted order) of 16 channels from a row-major LDS image; `p` = &img[4(l>>4) + ((l&15)>>2)][c0 + 4(l&3)]
+NBSS_DEV void frag_load_tr(Frag<bf16_t>& f, const bf16_t* p, int row_stride) {
+    const u32x2 lo = lds_tr4_b16(p), hi = lds_tr4_b16(p + 16 * (size_t)row_stride);
+    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    f.v = __builtin_bit_cast(s16x8, v);
+}
+
 #define F32X4_ZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
 
 // packed weight fragments live in global memory as [tile][kstep][lane][8] of T

@@ -218,6 +218,144 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 fast path: ROW-MAJOR LDS images + transposing LDS reads (ds_read_b64_tr_b16).  Staging is a plain 16-byte copy
+// (global row -> LDS row, one image per tap with out-of-range rows zeroed); an MFMA operand with K = tokens is two
+// transposing reads of a 4-token x 16-channel block each.  No register transposes, no scalar LDS writes.
+// Row stride = (cols + pad) with stride/2 dwords == 8 (mod 64): the 8 rows a 32-lane service group touches tile all 64 banks.
+NBSS_HD int tr_ld(int cols) {
+    int ld = cols + 16;
+    while (ld % 128 != 16) ld += 8;
+    return ld;
+}
+
+__global__ __launch_bounds__(WG_THREADS) void wgrad_tr_kernel(WgradArgs a) {
+    NBSS_LDS(smem);
+    typedef bf16_t T;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
+    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
+    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
+    const int tpg = mtiles * ntiles;
+    const bool per_group = gridDim.y > 1;
+    const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
+    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
+    const int lda = tr_ld(ncolsA), ldb = tr_ld(ncolsB);
+    T* Ai = reinterpret_cast<T*>(smem);                 // [KC][lda]
+    T* Bi = Ai + (size_t)WG_KC * lda;                   // [taps][KC][ldb]
+    for (int i = tid; i < (WG_KC * lda + a.taps * WG_KC * ldb) / 2; i += WG_THREADS) reinterpret_cast<uint32_t*>(Ai)[i] = 0u;
+
+    f32x4 acc[WG_TPW];
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
+    float bsum[WG_TPW];
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) bsum[s] = 0.f;
+    const bool do_bias = a.dbias != nullptr;
+    const T* Ag = reinterpret_cast<const T*>(a.A);
+    const T* Bg = reinterpret_cast<const T*>(a.B);
+    const int pA = ncolsA / 8, pB = ncolsB / 8, center = a.taps / 2;
+    const int nvA = WG_KC * pA, nvB = a.taps * WG_KC * pB;
+    const int nchunks = cdiv(a.Ntok, WG_KC);
+    const int ntot = ngrp * tpg;
+    const bool shifted = a.taps > 1;
+
+    // per-slot LDS addresses of this lane's transposing reads (chunk independent)
+    const T* pa[WG_TPW];
+    const T* pb[WG_TPW];
+    bool first_n[WG_TPW];
+    const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) {
+        const int tl = s * WG_WAVES + w;
+        pa[s] = Ai; pb[s] = Bi; first_n[s] = false;
+        if (tl < ntot) {
+            const int g = tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+            pa[s] = Ai + (size_t)trow * lda + g * mg + mt * 16 + tcol;
+            int q0 = nt * 16 + tcol;
+            if (q0 >= nexp) q0 = 0;  // padding columns of the last tile: any valid address, discarded at the flush
+            pb[s] = Bi + ((size_t)(q0 / ng) * WG_KC + trow) * ldb + g * ng + q0 % ng;
+            first_n[s] = nt == 0;
+        }
+    }
+    lds_barrier();
+
+    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const int n0 = ch * WG_KC;
+        // ---- stage: 16-byte row pieces, global -> LDS, row-major ----
+        for (int v = tid; v < nvA; v += WG_THREADS) {
+            const int k = v / pA, c8 = v % pA, n = n0 + k;
+            u32x4 x = {0, 0, 0, 0};
+            if (n < a.Ntok) x = *reinterpret_cast<const u32x4*>(Ag + (size_t)n * a.lda + acols0 + 8 * c8);
+            *reinterpret_cast<u32x4*>(Ai + (size_t)k * lda + 8 * c8) = x;
+        }
+        for (int v = tid; v < nvB; v += WG_THREADS) {
+            const int tap = v / (WG_KC * pB), r2 = v % (WG_KC * pB), k = r2 / pB, c8 = r2 % pB, n = n0 + k, d = tap - center;
+            u32x4 x = {0, 0, 0, 0};
+            bool ok = n < a.Ntok;
+            if (ok && shifted) {
+                const int pos = a.shift_dim == 0 ? n % a.T : (n / a.T) % a.F, lim = a.shift_dim == 0 ? a.T : a.F;
+                ok = pos + d >= 0 && pos + d < lim;
+            }
+            if (ok) {
+                const size_t ns = (size_t)((long)n + (long)d * a.shift_stride);
+                x = *reinterpret_cast<const u32x4*>(Bg + ns * a.ldb + bcols0 + 8 * c8);
+                if (a.stats) {  // LayerNorm on the fly
+                    const float mu = a.stats[2 * ns], rs = a.stats[2 * ns + 1];
+                    float f[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (f[e] - mu) * rs * a.gamma[bcols0 + 8 * c8 + e] + a.beta[bcols0 + 8 * c8 + e];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+                }
+            }
+            *reinterpret_cast<u32x4*>(Bi + ((size_t)tap * WG_KC + k) * ldb + 8 * c8) = x;
+        }
+        lds_barrier();
+        // ---- MFMA: K = the 32 tokens of this chunk; operands through transposing reads ----
+#pragma unroll
+        for (int s = 0; s < WG_TPW; ++s) {
+            if (s * WG_WAVES + w < ntot) {
+                Frag<T> fa, fb;
+                frag_load_tr(fa, pa[s], lda);
+                frag_load_tr(fb, pb[s], ldb);
+                acc[s] = mma(fa, fb, acc[s]);
+                if (do_bias && first_n[s]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[s] += frag_get(fa, j);
+                }
+            }
+        }
+        lds_barrier();
+    }
+
+    // ---- flush ----
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) {
+        const int tl = s * WG_WAVES + w;
+        if (tl < ntot) {
+            const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+            const int q = nt * 16 + l15;
+            if (q < nexp) {
+                const int tap = q / ng, i = q % ng;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 16 + 4 * g4 + r;
+                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
+                }
+            }
+            if (do_bias && nt == 0) {  // fragment lanes: channel = 16 mt + l15, the 4 lane groups hold disjoint tokens
+                const float tsum = wave_sum16(bsum[s]);
+                const int m = mt * 16 + l15;
+                if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
+            }
+        }
+    }
+}
+
 template <class T>
 static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
@@ -233,6 +371,20 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     // a staging block must not straddle a group: the per-group widths have to be multiples of the block width
     const bool cw8 = mg % 8 == 0 && ng % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && sizeof(T) == 2;
     const int nchunks = cdiv(a.Ntok, WG_KC);
+    if (sizeof(T) == 2 && mg % 8 == 0 && ng % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
+        const int ncA = all ? a.MA : mg, ncB = all ? a.NB : ng;
+        const size_t lds_tr = ((size_t)WG_KC * tr_ld(ncA) + (size_t)a.taps * WG_KC * tr_ld(ncB)) * 2;
+        if (lds_tr <= 120 * 1024) {
+            int xb = 256 / ybl;
+            if (xb < 16) xb = 16;
+            if (xb > nchunks) xb = nchunks;
+            ProfScope ps(PK_WGRAD, st);
+            int e2 = NBSS_SET_MAX_LDS(wgrad_tr_kernel, lds_tr);
+            if (e2) return e2;
+            NBSS_LAUNCH(wgrad_tr_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds_tr, st, a);
+            return NBSS_CHECK_LAUNCH();
+        }
+    }
     int xbl = 384 / ybl;  // 1-2 resident workgroups (8-16 waves) per CU; every x-block ends with one atomicAdd per output element
     if (xbl < 16) xbl = 16;
     if (xbl > nchunks) xbl = nchunks;

@@ -147,6 +147,27 @@ inline f32x4_t mfma_16x16x4_f32(float a, float b, f32x4_t c) {
     return d;
 }
 
+// ds_read_b64_tr_b16 (gfx950), semantics pinned on hardware by tools/probe/tr_read.cpp: every lane loads 4 x b16 from ITS
+// address; within each 16-lane group  out[l][j] = in[lane 4j + (l>>2)][l & 3]  — a 4-row x 16-column block whose lane p holds
+// row p>>2, columns 4(p&3)..+3 comes back as lane = column, elements = the 4 rows.
+inline uint64_t ds_read_tr16_b64(const void* p) {
+    Wave& w = cur_wave();
+    int l = g_fiber->lane;
+    std::memcpy(w.scratch[l], p, 8);
+    wave_sync();
+    int g = l >> 4, li = l & 15;
+    unsigned short o[4];
+    for (int j = 0; j < 4; ++j) {
+        unsigned short in4[4];
+        std::memcpy(in4, w.scratch[g * 16 + 4 * j + (li >> 2)], 8);
+        o[j] = in4[li & 3];
+    }
+    wave_sync();
+    uint64_t r;
+    std::memcpy(&r, o, 8);
+    return r;
+}
+
 inline float atomic_add_f32(float* p, float v) {
     auto* ap = reinterpret_cast<std::atomic<uint32_t>*>(p);
     uint32_t old = ap->load(std::memory_order_relaxed);
