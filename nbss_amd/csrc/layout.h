@@ -113,6 +113,8 @@ enum PackKind {
     K_TF_W1_T,   // du = W1^T da1: rows = H, K = groups x 32 permuted
     K_TF_C1_T, K_TF_C2_T, K_TF_C3_T,  // t-conv^T per group: rows = cg in ch, K = (flipped tap, 4-out-ch piece)
     K_TF_W2_T,   // dh5 = W2^T dy: rows = groups x (cg + pad to 32), K = H natural
+    K_TF_W1_TN,  // du = W1^T da1 from the emitted [N][FFN] operand: rows = H, K = FFN natural
+    K_INP_TN,    // du = Win^T dqkv from the emitted [N][3H] operand: rows = H, K = 3H natural
     NUM_PACK_KINDS
 };
 
@@ -147,6 +149,8 @@ NBSS_HD PackGeom pack_geom(const nbss_cfg& c, int kind) {
         case K_TF_W1_T: g.MT = c.H / 16; g.KS = c.t_groups * cdiv(cg, 32); break;
         case K_TF_C1_T: case K_TF_C2_T: case K_TF_C3_T: g.MT = cdiv(cg, 32) * 2; g.KS = cdiv(c.t_ks * (cg / 4), 8); g.NB = c.t_groups; break;
         case K_TF_W2_T: g.MT = c.t_groups * cdiv(cg, 32) * 2; g.KS = c.H / 32; break;
+        case K_TF_W1_TN: g.MT = c.H / 16; g.KS = c.FFN / 32; break;
+        case K_INP_TN: g.MT = c.H / 16; g.KS = 3 * c.H / 32; break;
     }
     return g;
 }

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     float* lis = m2s + tp;
     float* Dds = lis + tp;
     float* aff = Dds + tp;  // [2H] per-workgroup LN weight | bias gradient sums
+    float* lnp = aff + 2 * MB_H;  // [2H] LayerNorm gamma | beta
     for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) aff[i] = 0.f;
     const int bf = blockIdx.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -102,25 +103,31 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         sact[si] = (w * MB_NSW + si) < nst;  // wave-uniform
     }
 
-    Frag<T> u[MB_NSW][MB_KS], dyf[MB_NSW][MB_KS];
-    {
-        float gam[BK_KS][8], bet[BK_KS][8];
-        load_ln_affine(lp.p[P_MH_LN_W], lp.p[P_MH_LN_B], gam, bet);
+    // Only the row statistics persist across the head loop: LN(x) and dy fragments are rebuilt per head and du is formed after
+    // the loop from the emitted dqkv operand (keeping them live spilled 336 B/lane in the first version).
+    for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) lnp[i] = i < MB_H ? lp.p[P_MH_LN_W][i] : lp.p[P_MH_LN_B][i - MB_H];
+    float smean[MB_NSW], srstd[MB_NSW];
 #pragma unroll
-        for (int si = 0; si < MB_NSW; ++si) {
-            ln_strip96<T>(xb + (size_t)tt[si] * MB_H, tv[si], gam, bet, u[si]);
+    for (int si = 0; si < MB_NSW; ++si) {
+        float v[MB_KS][8], sum = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < MB_KS; ++ks) {
-                if (tv[si]) frag_load(dyf[si][ks], dyb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
-                else frag_zero(dyf[si][ks]);
-            }
+        for (int ks = 0; ks < MB_KS; ++ks) {
+            if (tv[si]) load8(xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4, v[ks]);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[ks][j];
         }
+        smean[si] = wave_sum16(sum) * (1.0f / MB_H);
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < MB_KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += (v[ks][j] - smean[si]) * (v[ks][j] - smean[si]);
+        srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / MB_H) + 1e-5f);
     }
-    f32x4 du[MB_NSW][BK_MT];
-#pragma unroll
-    for (int si = 0; si < MB_NSW; ++si)
-#pragma unroll
-        for (int mt = 0; mt < BK_MT; ++mt) du[si][mt] = F32X4_ZERO;
+    lds_barrier();  // lnp is read below
 
     for (int head = 0; head < MB_HEADS; ++head) {
         Frag<T> qf[MB_NSW], dof[MB_NSW];
@@ -130,21 +137,37 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         for (int which = 0; which < 4; ++which) {  // 0 q, 1 k, 2 v, 3 dO
             f32x4 ct[MB_NSW][2];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                Frag<T> a[MB_KS];
+            for (int si = 0; si < MB_NSW; ++si) ct[si][0] = ct[si][1] = F32X4_ZERO;
 #pragma unroll
-                for (int ks = 0; ks < MB_KS; ++ks) {
-                    if (which < 3) wfrag_load(a[ks], Win, (which * MB_HEADS + head) * 2 + half, MB_KS, ks);
-                    else wfrag_load(a[ks], WoutT, head * 2 + half, MB_KS, ks);
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                Frag<T> a[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (which < 3) wfrag_load(a[half], Win, (which * MB_HEADS + head) * 2 + half, MB_KS, ks);
+                    else wfrag_load(a[half], WoutT, head * 2 + half, MB_KS, ks);
                 }
 #pragma unroll
                 for (int si = 0; si < MB_NSW; ++si) {
-                    f32x4 acc = F32X4_ZERO;
-                    if (sact[si]) {
+                    if (!sact[si]) continue;
+                    Frag<T> opf;
+                    const int c0 = ks * 32 + 8 * g4;
+                    if (which < 3) {  // LN(x), rebuilt from x + row statistics + gamma|beta in LDS
+                        float v[8], gm[8], bt[8];
+                        if (tv[si]) load8(xb + (size_t)tt[si] * MB_H + c0, v);
+                        else
 #pragma unroll
-                        for (int ks = 0; ks < MB_KS; ++ks) acc = mma(a[ks], which < 3 ? u[si][ks] : dyf[si][ks], acc);
+                            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                        load8(lnp + c0, gm);
+                        load8(lnp + MB_H + c0, bt);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) frag_set(opf, j, (v[j] - smean[si]) * srstd[si] * gm[j] + bt[j]);
+                    } else if (tv[si]) {
+                        frag_load(opf, dyb + (size_t)tt[si] * MB_H + c0);
+                    } else {
+                        frag_zero(opf);
                     }
-                    ct[si][half] = acc;
+                    ct[si][0] = mma(a[0], opf, ct[si][0]);
+                    ct[si][1] = mma(a[1], opf, ct[si][1]);
                 }
             }
             float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -266,14 +289,6 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 dq[1][r] *= rs_dh;
             }
             if (tv[si]) store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + head * MB_DH, dq[0], dq[1]);
-            Frag<T> dqf;
-            frag_from_c2(dqf, dq[0], dq[1]);
-#pragma unroll
-            for (int mt = 0; mt < BK_MT; ++mt) {
-                Frag<T> a;
-                wfrag_load(a, WinT, mt, 3 * MB_HEADS, head);
-                du[si][mt] = mma(a, dqf, du[si][mt]);
-            }
         }
         lds_barrier();
 
@@ -329,19 +344,29 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + MB_H + head * MB_DH, dk[0], dk[1]);
                 store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + 2 * MB_H + head * MB_DH, dv[0], dv[1]);
             }
-            Frag<T> dkf, dvf;
-            frag_from_c2(dkf, dk[0], dk[1]);
-            frag_from_c2(dvf, dv[0], dv[1]);
+        }
+        lds_barrier();
+    }
+
+    // du = Win^T dqkv from the [N][3H] operand this workgroup has just written (full barrier: the other waves' stores are
+    // complete, and these lines were never read before, so no stale L1 copies exist)
+    __syncthreads();
+    f32x4 du[MB_NSW][BK_MT];
+#pragma unroll
+    for (int si = 0; si < MB_NSW; ++si) {
+#pragma unroll
+        for (int mt = 0; mt < BK_MT; ++mt) du[si][mt] = F32X4_ZERO;
+        for (int k9 = 0; k9 < 3 * MB_H / 32; ++k9) {
+            Frag<T> df;
+            if (tv[si]) frag_load(df, dqkv + (n0 + tt[si]) * (3 * MB_H) + k9 * 32 + 8 * g4);
+            else frag_zero(df);
 #pragma unroll
             for (int mt = 0; mt < BK_MT; ++mt) {
                 Frag<T> a;
-                wfrag_load(a, WinT, mt, 3 * MB_HEADS, MB_HEADS + head);
-                du[si][mt] = mma(a, dkf, du[si][mt]);
-                wfrag_load(a, WinT, mt, 3 * MB_HEADS, 2 * MB_HEADS + head);
-                du[si][mt] = mma(a, dvf, du[si][mt]);
+                wfrag_load(a, WinT, mt, 3 * MB_H / 32, k9);
+                du[si][mt] = mma(a, df, du[si][mt]);
             }
         }
-        lds_barrier();
     }
 
     // ---------------- LayerNorm backward + residual ----------------
@@ -366,14 +391,14 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int tp = cdiv(c.T, 16) * 16;
     if (tp > 256) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)7 * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 2 * MB_H) * sizeof(float);
+    const size_t lds = (size_t)7 * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_MHSA_B, st);
-    NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_T),
+    NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
                 pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (T*)dx, stats, (T*)dqkv);
     return NBSS_CHECK_LAUNCH();
 }

@@ -26,6 +26,8 @@ static int64_t pack_src_base(const nbss_cfg& c, int kind, int layer) {
         case K_TF_C2: case K_TF_C2_T: return param_off(c, layer, P_TF_C2W);
         case K_TF_C3: case K_TF_C3_T: return param_off(c, layer, P_TF_C3W);
         case K_TF_W2: case K_TF_W2_T: return param_off(c, layer, P_TF_W2);
+        case K_TF_W1_TN: return param_off(c, layer, P_TF_W1);
+        case K_INP_TN: return param_off(c, layer, P_INP_W);
     }
     return 0;
 }
@@ -123,6 +125,10 @@ NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the 
             const int tapp = p / pc, o = (p % pc) * 4 + (j & 3);
             return P[((int64_t)(nb * cg + o) * cg + m) * c.t_ks + (c.t_ks - 1 - tapp)];
         }
+        case K_TF_W1_TN:
+            return P[(int64_t)knat * H + m];  // W1[k][m]
+        case K_INP_TN:
+            return P[(int64_t)knat * H + m];  // Win[k][m]
         case K_TF_W2_T: {
             const int cg = c.FFN / c.t_groups, grp = mt >> 1, ci = (mt & 1) * 16 + l15;
             if (ci >= cg) return 0.f;

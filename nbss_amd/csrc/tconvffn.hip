@@ -83,6 +83,21 @@ NBSS_DEV void stage_frags(T* __restrict__ dst, const T* __restrict__ src, int nf
 template <class T>
 NBSS_DEV void lfrag(Frag<T>& f, const T* __restrict__ wl, int idx) { frag_load(f, wl + ((size_t)idx * 64 + lane_id()) * 8); }
 
+// LN(x) fragment k-step `ks` of one row, rebuilt on demand from x, the row statistics and gamma|beta in LDS
+template <class T>
+NBSS_DEV void u_frag_ks(Frag<T>& f, const T* __restrict__ xr, bool valid, float mean, float rstd, const float* __restrict__ lnp, int ks) {
+    const int c0 = ks * 32 + 8 * (lane_id() >> 4);
+    float v[8], gm[8], bt[8];
+    if (valid) load8(xr + c0, v);
+    else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    load8(lnp + c0, gm);
+    load8(lnp + TF_H + c0, bt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) frag_set(f, j, (v[j] - mean) * rstd * gm[j] + bt[j]);
+}
+
 // one grouped conv for the wave's strips: out[si][half] (C tiles: lane = frame, rows = 4 channels)
 template <class T>
 NBSS_DEV void conv_group(const T* __restrict__ Wc, const T* __restrict__ hin, int w, f32x4 (&out)[TF_NSW][2]) {
@@ -343,7 +358,7 @@ NBSS_DEV float sum_l15(float v) {
 template <class T>
 __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                            const T* __restrict__ W1, const T* __restrict__ Wc1, const T* __restrict__ Wc2,
-                                                           const T* __restrict__ Wc3, const T* __restrict__ W1t, const T* __restrict__ Wc1t,
+                                                           const T* __restrict__ Wc3, const T* __restrict__ W1tn, const T* __restrict__ Wc1t,
                                                            const T* __restrict__ Wc2t, const T* __restrict__ Wc3t, const T* __restrict__ W2t,
                                                            const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                            float* __restrict__ stats, TfOps<T> ops) {
@@ -356,7 +371,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     T* buf3 = buf2 + (size_t)(tp + 2) * TF_CG;
     float* red = reinterpret_cast<float*>(buf3 + (size_t)(tp + 2) * TF_CG);  // [8 waves][2]
     float* aff = red + 16;  // [576] per-workgroup sums: GN weight | GN bias | LN weight | LN bias
-    T* wl = reinterpret_cast<T*>(aff + TF_AFF);  // this group's weights: W1 c1 c2 c3 | W2^T c3^T c2^T c1^T W1^T, 6 fragments each
+    float* lnp = aff + TF_AFF;  // [2H] LayerNorm gamma | beta
+    T* wl = reinterpret_cast<T*>(lnp + 2 * TF_H);  // this group's weights: W1 c1 c2 c3 | W2^T c3^T c2^T c1^T W1^T, 6 fragments each
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
@@ -392,31 +408,31 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     // strips beyond the padded length do nothing but must still hit every barrier
     const bool wact = (w * TF_NSW) * 16 < tp;
 
-    Frag<T> u[TF_NSW][TF_KS], dyf[TF_NSW][TF_KS];
-    {
-        float gam[TF_KS][8], bet[TF_KS][8];
+    // Registers are the scarce resource of this kernel (the first version kept LN(x), dy and the du accumulators live across
+    // the group loop and spilled 416 B/lane: 78 % of the wave time was spent waiting on scratch reloads).  Now only the row
+    // statistics persist; LN(x) and dy fragments are re-read per group (L2/L1 hits) and du is formed after the loop.
+    for (int i = tid; i < 2 * TF_H; i += blockDim.x) lnp[i] = i < TF_H ? lnw[i] : lnb[i - TF_H];
+    float smean[TF_NSW], srstd[TF_NSW];
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si) {
+        float v[TF_KS][8], sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < TF_KS; ++ks) {
+            if (tv[si]) load8(xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4, v[ks]);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[ks][j];
+        }
+        smean[si] = wave_sum16(sum) * (1.0f / TF_H);
+        float q = 0.f;
 #pragma unroll
         for (int ks = 0; ks < TF_KS; ++ks)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                gam[ks][j] = lnw[ks * 32 + 8 * g4 + j];
-                bet[ks][j] = lnb[ks * 32 + 8 * g4 + j];
-            }
-#pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
-            ln_strip_tf<T>(xb + (size_t)tt[si] * TF_H, tv[si], gam, bet, u[si]);
-#pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) {
-                if (tv[si]) frag_load(dyf[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                else frag_zero(dyf[si][ks]);
-            }
-        }
+            for (int j = 0; j < 8; ++j) q += (v[ks][j] - smean[si]) * (v[ks][j] - smean[si]);
+        srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / TF_H) + 1e-5f);
     }
-    f32x4 du[TF_NSW][TF_H / 16];
-#pragma unroll
-    for (int si = 0; si < TF_NSW; ++si)
-#pragma unroll
-        for (int mt = 0; mt < TF_H / 16; ++mt) du[si][mt] = F32X4_ZERO;
 
     const int d0 = 4 * g4, d1 = 16 + 4 * g4;
     const bool v1 = g4 < 2;
@@ -432,26 +448,26 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         const T* wsl[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) wsl[i] = STAGE ? wl + (size_t)i * 6 * 512 : srcs[i] + (size_t)gr * 6 * 512;
-        const T* w1t_base = STAGE ? wl + 48 * 512 : W1t + (size_t)gr * 512;
-        const int w1t_stride = STAGE ? 512 : TF_G * 512;
         if (STAGE) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) stage_frags<T>(wl + (size_t)i * 6 * 512, srcs[i] + (size_t)gr * 6 * 512, 6);
-            for (int mt = 0; mt < TF_H / 16; ++mt) stage_frags<T>(wl + (48 + mt) * 512, W1t + (size_t)(mt * TF_G + gr) * 512, 1);
             lds_barrier();
         }
         // ---------------- forward recompute ----------------
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            Frag<T> a[TF_KS];
+        for (int si = 0; si < TF_NSW; ++si) {
+            a1[si][0] = F32X4_ZERO;
+            a1[si][1] = F32X4_ZERO;
 #pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) lfrag<T>(a[ks], wsl[0], half * 3 + ks);
+            for (int ks = 0; ks < TF_KS; ++ks) {
+                Frag<T> uf;
+                u_frag_ks<T>(uf, xb + (size_t)tt[si] * TF_H, tv[si], smean[si], srstd[si], lnp, ks);
 #pragma unroll
-            for (int si = 0; si < TF_NSW; ++si) {
-                f32x4 acc = F32X4_ZERO;
-#pragma unroll
-                for (int ks = 0; ks < TF_KS; ++ks) acc = mma(a[ks], u[si][ks], acc);
-                a1[si][half] = acc;
+                for (int half = 0; half < 2; ++half) {
+                    Frag<T> a;
+                    lfrag<T>(a, wsl[0], half * 3 + ks);
+                    a1[si][half] = mma(a, uf, a1[si][half]);
+                }
             }
         }
 #pragma unroll
@@ -543,16 +559,20 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         // ---------------- backward ----------------
         // dh5 = W2[:, group]^T dy ; da5 = dh5 * silu'(a5) -> buf3
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            Frag<T> a[TF_KS];
+        for (int si = 0; si < TF_NSW; ++si) {
+            ct[si][0] = F32X4_ZERO;
+            ct[si][1] = F32X4_ZERO;
 #pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) lfrag<T>(a[ks], wsl[4], half * 3 + ks);
+            for (int ks = 0; ks < TF_KS; ++ks) {
+                Frag<T> df;
+                if (tv[si]) frag_load(df, dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                else frag_zero(df);
 #pragma unroll
-            for (int si = 0; si < TF_NSW; ++si) {
-                f32x4 acc = F32X4_ZERO;
-#pragma unroll
-                for (int ks = 0; ks < TF_KS; ++ks) acc = mma(a[ks], dyf[si][ks], acc);
-                ct[si][half] = acc;
+                for (int half = 0; half < 2; ++half) {
+                    Frag<T> a;
+                    lfrag<T>(a, wsl[4], half * 3 + ks);
+                    ct[si][half] = mma(a, df, ct[si][half]);
+                }
             }
         }
 #pragma unroll
@@ -641,7 +661,6 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         lds_barrier();
         // dh1 = conv1^T(da2) ; da1 = dh1 * silu'(a1) ; du += W1[group]^T da1
         conv_group<T>(wsl[7], buf1, w, ct);
-        Frag<T> da1f[TF_NSW];
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
 #pragma unroll
@@ -650,16 +669,29 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a1[si][1][r]) : 0.f;
             }
             store_op<T>(ops.da1, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
-            frag_from_c2(da1f[si], ct[si][0], ct[si][1]);
-        }
-#pragma unroll
-        for (int mt = 0; mt < TF_H / 16; ++mt) {
-            Frag<T> a;
-            lfrag<T>(a, w1t_base + (size_t)mt * w1t_stride, 0);
-#pragma unroll
-            for (int si = 0; si < TF_NSW; ++si) du[si][mt] = mma(a, da1f[si], du[si][mt]);
         }
         lds_barrier();
+    }
+
+    // du = W1^T da1 over all FFN channels, from the [N][FFN] operand this workgroup has just written (the weight-gradient
+    // kernel reads the same buffer): a full barrier makes the stores of the other waves visible (never-read lines: no stale L1)
+    __syncthreads();
+    f32x4 du[TF_NSW][TF_H / 16];
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si) {
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) du[si][mt] = F32X4_ZERO;
+        for (int k6 = 0; k6 < TF_FFN / 32; ++k6) {
+            Frag<T> df;
+            if (tv[si]) frag_load(df, ops.da1 + (n0 + tt[si]) * TF_FFN + k6 * 32 + 8 * g4);
+            else frag_zero(df);
+#pragma unroll
+            for (int mt = 0; mt < TF_H / 16; ++mt) {
+                Frag<T> a;
+                wfrag_load(a, W1tn, mt, TF_FFN / 32, k6);
+                du[si][mt] = mma(a, df, du[si][mt]);
+            }
+        }
     }
 
     // ---------------- LayerNorm backward + residual, in registers ----------------
@@ -740,7 +772,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
                           float* stats, void* const* opsv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF) * sizeof(float) + (sizeof(T) == 2 ? (size_t)54 * 512 * sizeof(T) : 0);
+    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF + 2 * TF_H) * sizeof(float) + (sizeof(T) == 2 ? (size_t)48 * 512 * sizeof(T) : 0);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
     TfOps<T> ops;
@@ -751,7 +783,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_B, st);
     NBSS_LAUNCH((tconvffn_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
-                pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W1_T),
+                pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W1_TN),
                 pk + pack_off(c, layer, K_TF_C1_T), pk + pack_off(c, layer, K_TF_C2_T), pk + pack_off(c, layer, K_TF_C3_T),
                 pk + pack_off(c, layer, K_TF_W2_T), (const T*)x, (const T*)dy, (T*)dx, stats, ops);
     return NBSS_CHECK_LAUNCH();
