@@ -201,6 +201,17 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
     T* u = reinterpret_cast<T*>(smem);       // [FP][H]  LN(x), rows f+2
     T* dvb = u + (size_t)FP * FC_H;          // [FP][H]  dv, rows f+2
     float* aff = reinterpret_cast<float*>(dvb + (size_t)FP * FC_H);  // [3H] LN weight | LN bias | PReLU slope gradient sums
+    T* wl = reinterpret_cast<T*>(aff + 3 * FC_H);  // conv and transposed-conv weight fragments (2 x 16), shared by the 4 waves
+    constexpr bool STAGE_W = sizeof(T) == 2;  // the fp32 stream has no LDS room left: it keeps reading the packed buffer
+    const T* wc = STAGE_W ? wl : Wp;
+    const T* wct = STAGE_W ? wl + 16 * 512 : WpT;
+    if (STAGE_W) {
+        constexpr int VNW = 16 / sizeof(T);
+        for (int v = threadIdx.x; v < 16 * 512 / VNW; v += blockDim.x) {
+            *reinterpret_cast<u32x4*>(wl + (size_t)v * VNW) = *reinterpret_cast<const u32x4*>(Wp + (size_t)v * VNW);
+            *reinterpret_cast<u32x4*>(wl + 16 * 512 + (size_t)v * VNW) = *reinterpret_cast<const u32x4*>(WpT + (size_t)v * VNW);
+        }
+    }
     for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
     constexpr int VN = VecOf<T>::N;
     constexpr int VPR = FC_H / VN;
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
 #pragma unroll
             for (int ks = 0; ks < FC_KS; ++ks) {
                 Frag<T> a, bq;
-                wfrag_load(a, Wp, g, FC_KS, ks);
+                wfrag_load(a, wc, g, FC_KS, ks);
                 fconv_bfrag<T>(bq, u, f, g * FC_CG, ks);
                 acc = mma(a, bq, acc);
             }
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float*
 #pragma unroll
             for (int ks = 0; ks < FC_KS; ++ks) {
                 Frag<T> a, bq;
-                wfrag_load(a, WpT, g, FC_KS, ks);
+                wfrag_load(a, wct, g, FC_KS, ks);
                 fconv_bfrag<T>(bq, dvb, f, g * FC_CG, ks);
                 acc = mma(a, bq, acc);
             }
@@ -350,7 +361,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
                        float* stats, void* dv, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (mtf * 16 + 4) * FC_H * sizeof(T) + 3 * FC_H * sizeof(float);
+    const size_t lds = (size_t)2 * (mtf * 16 + 4) * FC_H * sizeof(T) + 3 * FC_H * sizeof(float) + (sizeof(T) == 2 ? (size_t)32 * 512 * sizeof(T) : 0);
     const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T>), lds);
