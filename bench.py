@@ -186,8 +186,14 @@ def main():
             per_launch = algorithmic_bytes(dominant, B)
             ach = per_launch / (ms / cnt * 1e-3)
             total_gpu_ms = sum(v[0] for v in prof.values())
+            traffic = None
+            tfile = ROOT / "profiles" / "pmc_traffic.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh), per launch
+            if tfile.exists():
+                tj = json.loads(tfile.read_text())
+                if tj.get("batch") == B and dominant in tj.get("kernels", {}):
+                    traffic = tj["kernels"][dominant]["hbm_bytes"]
             roof = {"bound": "hbm", "kernel": dominant, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                    "traffic": None, "avg_launch_us": ms / cnt * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": per_launch,
+                    "traffic": traffic, "avg_launch_us": ms / cnt * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": per_launch,
                     "share_of_gpu_time": prof[dominant][0] / total_gpu_ms if total_gpu_ms > 0 else None,
                     "step_algorithmic": {"bytes_per_utt": 204 * S_BYTES_BF16, "achieved_GBps": world * B * args.steps / dt * 204 * S_BYTES_BF16 / 1e9 / world,
                                          "frac_of_hbm_per_gpu": (B * args.steps / dt) * 204 * S_BYTES_BF16 / HBM_PEAK}}

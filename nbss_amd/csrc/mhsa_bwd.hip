@@ -50,6 +50,20 @@ NBSS_DEV void store_col24(T* __restrict__ base, int tp, int t, const f32x4& lo, 
 }
 
 // A fragment of a transposed [24][tp] array: rows d = half*16 + l15, K = 32 frames of k-step ks (permuted order)
+// bf16: the same operand straight from the ROW-MAJOR [tp][24] array through transposing LDS reads (no transposed copy,
+// no 16-way bank conflicts of the [24][tp] image: its rows are 512 B apart)
+NBSS_DEV void col_frag_tr(Frag<bf16_t>& f, const bf16_t* __restrict__ rowmajor, int half, int ks, bool hi_valid) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const bf16_t* p = rowmajor + (size_t)(ks * 32 + 4 * g4 + (l15 >> 2)) * MB_DH + half * 16 + 4 * (l15 & 3);
+    const u32x2 lo = lds_tr4_b16(p);
+    u32x2 hi = {0u, 0u};
+    if (hi_valid) hi = lds_tr4_b16(p + 16 * MB_DH);
+    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    f.v = __builtin_bit_cast(s16x8, v);
+    // rows d >= 24 of the second half-tile pick up neighbouring data: finite, and every consumer discards those rows
+}
+NBSS_DEV void col_frag_tr(Frag<float>&, const float*, int, int, bool) {}
+
 template <class T>
 NBSS_DEV void col_frag(Frag<T>& f, const T* __restrict__ base, int tp, int half, int ks, bool hi_valid) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
@@ -75,10 +89,11 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     T* Kr = Qr + (size_t)tp * MB_DH;
     T* Vr = Kr + (size_t)tp * MB_DH;
     T* dOr = Vr + (size_t)tp * MB_DH;
+    constexpr bool TR = sizeof(T) == 2;  // bf16: transposing LDS reads replace the transposed copies
     T* Qt = dOr + (size_t)tp * MB_DH;
     T* Kt = Qt + (size_t)tp * MB_DH;
     T* dOt = Kt + (size_t)tp * MB_DH;
-    float* m2s = reinterpret_cast<float*>(dOt + (size_t)tp * MB_DH);
+    float* m2s = reinterpret_cast<float*>(TR ? Qt : dOt + (size_t)tp * MB_DH);
     float* lis = m2s + tp;
     float* Dds = lis + tp;
     float* aff = Dds + tp;  // [2H] per-workgroup LN weight | bias gradient sums
@@ -194,16 +209,16 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 if (which == 0) {
                     frag_from_c2(qf[si], ct[si][0], ct[si][1]);
                     store_row24<T>(Qr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
-                    store_col24<T>(Qt, tp, t, ct[si][0], ct[si][1]);
+                    if (!TR) store_col24<T>(Qt, tp, t, ct[si][0], ct[si][1]);
                 } else if (which == 1) {
                     store_row24<T>(Kr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
-                    store_col24<T>(Kt, tp, t, ct[si][0], ct[si][1]);
+                    if (!TR) store_col24<T>(Kt, tp, t, ct[si][0], ct[si][1]);
                 } else if (which == 2) {
                     store_row24<T>(Vr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
                 } else {
                     frag_from_c2(dof[si], ct[si][0], ct[si][1]);
                     store_row24<T>(dOr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
-                    store_col24<T>(dOt, tp, t, ct[si][0], ct[si][1]);
+                    if (!TR) store_col24<T>(dOt, tp, t, ct[si][0], ct[si][1]);
                     // D = rowsum(dO * O) with the saved forward attention output
                     float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
                     if (tv[si]) {
@@ -278,7 +293,8 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         Frag<T> a;
-                        col_frag<T>(a, Kt, tp, half, ks, 2 * ks + 1 < nst);
+                        if (TR) col_frag_tr(a, Kr, half, ks, 2 * ks + 1 < nst);
+                        else col_frag<T>(a, Kt, tp, half, ks, 2 * ks + 1 < nst);
                         dq[half] = mma(a, dsf, dq[half]);
                     }
                 }
@@ -329,9 +345,11 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     Frag<T> a;
-                    col_frag<T>(a, dOt, tp, half, jp, 2 * jp + 1 < nst);
+                    if (TR) col_frag_tr(a, dOr, half, jp, 2 * jp + 1 < nst);
+                    else col_frag<T>(a, dOt, tp, half, jp, 2 * jp + 1 < nst);
                     dv[half] = mma(a, pf, dv[half]);
-                    col_frag<T>(a, Qt, tp, half, jp, 2 * jp + 1 < nst);
+                    if (TR) col_frag_tr(a, Qr, half, jp, 2 * jp + 1 < nst);
+                    else col_frag<T>(a, Qt, tp, half, jp, 2 * jp + 1 < nst);
                     dk[half] = mma(a, dsf, dk[half]);
                 }
             }
@@ -391,7 +409,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int tp = cdiv(c.T, 16) * 16;
     if (tp > 256) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)7 * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float);
+    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
