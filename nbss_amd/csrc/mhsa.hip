@@ -57,6 +57,13 @@ NBSS_DEV void ln_strip(const T* __restrict__ xr, bool valid, const float (&gam)[
         for (int j = 0; j < 8; ++j) frag_set(u[ks], j, (v[ks][j] - mean) * rstd * gam[ks][j] + bet[ks][j]);
 }
 
+// A operand of O^T = V^T P^T from the row-major bf16 V image [TP][24]: rows d = half*16 + l15, K = the 32 frames of k-step ks
+NBSS_DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* __restrict__ vr, int half, int ks) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    frag_load_tr(f, vr + (size_t)(ks * 32 + 4 * g4 + (l15 >> 2)) * MH_DH + half * 16 + 4 * (l15 & 3), MH_DH);
+}
+NBSS_DEV void v_frag_tr(Frag<float>&, const float*, int, int) {}
+
 template <class T, int HPP>
 __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
@@ -140,6 +147,11 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                             T* kr = Ks + ((size_t)hh * MH_TP + t) * MH_DH;
                             store4(kr + 4 * g4, ct[si][0][0], ct[si][0][1], ct[si][0][2], ct[si][0][3]);
                             if (g4 < 2) store4(kr + 16 + 4 * g4, ct[si][1][0], ct[si][1][1], ct[si][1][2], ct[si][1][3]);
+                        } else if (sizeof(T) == 2) {
+                            // bf16: V stays row-major like K; O^T = V^T P^T fetches its A operand through transposing LDS reads
+                            T* vr = Vt + ((size_t)hh * MH_TP + t) * MH_DH;
+                            store4(vr + 4 * g4, ct[si][0][0], ct[si][0][1], ct[si][0][2], ct[si][0][3]);
+                            if (g4 < 2) store4(vr + 16 + 4 * g4, ct[si][1][0], ct[si][1][1], ct[si][1][2], ct[si][1][3]);
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -199,20 +211,26 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                     if (2 * ks < nst) {
                         Frag<T> pf, a0, a1;
                         frag_from_c2(pf, sc[2 * ks], sc[2 * ks + 1]);
-                        const T* v0 = vh + (size_t)l15 * MH_TP + ks * 32 + 4 * g4;
-                        frag_load_lo(a0, v0);
-                        frag_load_hi(a0, v0 + 16);
-                        o0 = mma(a0, pf, o0);
-                        if (l15 < MH_DH - 16) {
-                            const T* v1 = vh + (size_t)(16 + l15) * MH_TP + ks * 32 + 4 * g4;
-                            frag_load_lo(a1, v1);
-                            frag_load_hi(a1, v1 + 16);
+                        if (sizeof(T) == 2) {
+                            v_frag_tr(a0, vh, 0, ks);
+                            v_frag_tr(a1, vh, 1, ks);  // rows d >= 24 pick up neighbouring (finite) data; zeroed below
                         } else {
-                            frag_zero(a1);
+                            const T* v0 = vh + (size_t)l15 * MH_TP + ks * 32 + 4 * g4;
+                            frag_load_lo(a0, v0);
+                            frag_load_hi(a0, v0 + 16);
+                            if (l15 < MH_DH - 16) {
+                                const T* v1 = vh + (size_t)(16 + l15) * MH_TP + ks * 32 + 4 * g4;
+                                frag_load_lo(a1, v1);
+                                frag_load_hi(a1, v1 + 16);
+                            } else {
+                                frag_zero(a1);
+                            }
                         }
+                        o0 = mma(a0, pf, o0);
                         o1 = mma(a1, pf, o1);
                     }
                 }
+                if (g4 >= 2) o1 = F32X4_ZERO;  // output rows d = 16 + 4 g4 + r >= dh are padding
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     o0[r] *= inv;
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
 template <class T, int HPP>
 static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
     if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T);
+    const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T) + 64;  // +64: the last transposing read overreaches its row by 16 B
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP>), lds);
     if (e) return e;
