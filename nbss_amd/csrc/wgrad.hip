@@ -356,6 +356,174 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr_kernel(WgradArgs a) {
     }
 }
 
+// Double-buffered variant of the transposing-read kernel: the 16-byte row pieces of chunk c+1 are requested into registers
+// before chunk c's MFMAs and written to the other LDS buffer afterwards, so HBM latency overlaps the contraction and there
+// is ONE barrier per chunk (buffer b is only rewritten after every wave has passed the next barrier).
+#define WG_MAXV 6  // 16-byte vectors a thread carries per chunk
+
+__global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
+    NBSS_LDS(smem);
+    typedef bf16_t T;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
+    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
+    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
+    const int tpg = mtiles * ntiles;
+    const bool per_group = gridDim.y > 1;
+    const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
+    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
+    const int lda = tr_ld(ncolsA), ldb = tr_ld(ncolsB);
+    const int img = WG_KC * lda + a.taps * WG_KC * ldb;  // elements per buffer
+    T* base = reinterpret_cast<T*>(smem);
+    for (int i = tid; i < img; i += WG_THREADS) reinterpret_cast<uint32_t*>(base)[i] = 0u;  // 2 buffers x img elements
+    float* lnp = reinterpret_cast<float*>(base + 2 * (size_t)img);  // [2 NB] LayerNorm gamma | beta of the X operand
+    if (a.stats)
+        for (int i = tid; i < 2 * a.NB; i += WG_THREADS) lnp[i] = i < a.NB ? a.gamma[i] : a.beta[i - a.NB];
+
+    f32x4 acc[WG_TPW];
+    float bsum[WG_TPW];
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) { acc[s] = F32X4_ZERO; bsum[s] = 0.f; }
+    const bool do_bias = a.dbias != nullptr;
+    const T* Ag = reinterpret_cast<const T*>(a.A);
+    const T* Bg = reinterpret_cast<const T*>(a.B);
+    const int pA = ncolsA / 8, pB = ncolsB / 8, center = a.taps / 2;
+    const int nvA = WG_KC * pA, nvec = nvA + a.taps * WG_KC * pB;
+    const int nchunks = cdiv(a.Ntok, WG_KC);
+    const int ntot = ngrp * tpg;
+    const bool shifted = a.taps > 1;
+
+    // per-slot offsets (elements, inside a buffer) of this lane's transposing reads
+    int oa[WG_TPW], ob[WG_TPW];
+    bool first_n[WG_TPW];
+    const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) {
+        const int tl = s * WG_WAVES + w;
+        oa[s] = 0; ob[s] = 0; first_n[s] = false;
+        if (tl < ntot) {
+            const int g = tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+            oa[s] = trow * lda + g * mg + mt * 16 + tcol;
+            int q0 = nt * 16 + tcol;
+            if (q0 >= nexp) q0 = 0;
+            ob[s] = WG_KC * lda + ((q0 / ng) * WG_KC + trow) * ldb + g * ng + q0 % ng;
+            first_n[s] = nt == 0;
+        }
+    }
+    // per-vector descriptors of this thread (chunk independent): row k, tap shift, global column, LDS offset
+    int vk[WG_MAXV], vd[WG_MAXV], vcol[WG_MAXV], vdst[WG_MAXV];
+    bool vA[WG_MAXV], vok[WG_MAXV];
+#pragma unroll
+    for (int u = 0; u < WG_MAXV; ++u) {
+        const int v = tid + u * WG_THREADS;
+        vok[u] = v < nvec;
+        vA[u] = v < nvA;
+        if (vA[u]) {
+            vk[u] = v / pA; vd[u] = 0;
+            vcol[u] = acols0 + 8 * (v % pA);
+            vdst[u] = vk[u] * lda + 8 * (v % pA);
+        } else {
+            const int v2 = vok[u] ? v - nvA : 0, tap = v2 / (WG_KC * pB), r2 = v2 % (WG_KC * pB);
+            vk[u] = r2 / pB; vd[u] = tap - center;
+            vcol[u] = bcols0 + 8 * (r2 % pB);
+            vdst[u] = WG_KC * lda + (tap * WG_KC + vk[u]) * ldb + 8 * (r2 % pB);
+        }
+    }
+    u32x4 pre[WG_MAXV];
+    float pmu[WG_MAXV], prs[WG_MAXV];
+    auto prefetch = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < WG_MAXV; ++u) {
+            pre[u] = (u32x4){0, 0, 0, 0};
+            pmu[u] = 0.f; prs[u] = 0.f;
+            if (!vok[u]) continue;
+            const int n = n0 + vk[u];
+            if (n >= a.Ntok) continue;
+            if (vA[u]) {
+                pre[u] = *reinterpret_cast<const u32x4*>(Ag + (size_t)n * a.lda + vcol[u]);
+            } else {
+                bool ok = true;
+                if (shifted) {
+                    const int pos = a.shift_dim == 0 ? n % a.T : (n / a.T) % a.F, lim = a.shift_dim == 0 ? a.T : a.F;
+                    ok = pos + vd[u] >= 0 && pos + vd[u] < lim;
+                }
+                if (ok) {
+                    const size_t ns = (size_t)((long)n + (long)vd[u] * a.shift_stride);
+                    pre[u] = *reinterpret_cast<const u32x4*>(Bg + ns * a.ldb + vcol[u]);
+                    if (a.stats) { pmu[u] = a.stats[2 * ns]; prs[u] = a.stats[2 * ns + 1]; }
+                }
+            }
+        }
+    };
+    auto stash = [&](T* buf) {
+#pragma unroll
+        for (int u = 0; u < WG_MAXV; ++u) {
+            if (!vok[u]) continue;
+            u32x4 x = pre[u];
+            if (!vA[u] && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
+                float gm[8], bt[8];
+                load8(lnp + vcol[u], gm);
+                load8(lnp + a.NB + vcol[u], bt);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = prs[u] != 0.f ? (f[e] - pmu[u]) * prs[u] * gm[e] + bt[e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+            }
+            *reinterpret_cast<u32x4*>(buf + vdst[u]) = x;
+        }
+    };
+
+    int ch = blockIdx.x;
+    if (ch < nchunks) prefetch(ch * WG_KC);
+    lds_barrier();  // zero fill done
+    int b = 0;
+    for (; ch < nchunks; ch += gridDim.x) {
+        T* buf = base + (size_t)b * img;
+        stash(buf);
+        lds_barrier();
+        if (ch + (int)gridDim.x < nchunks) prefetch((ch + gridDim.x) * WG_KC);
+#pragma unroll
+        for (int s = 0; s < WG_TPW; ++s) {
+            if (s * WG_WAVES + w < ntot) {
+                Frag<T> fa, fb;
+                frag_load_tr(fa, buf + oa[s], lda);
+                frag_load_tr(fb, buf + ob[s], ldb);
+                acc[s] = mma(fa, fb, acc[s]);
+                if (do_bias && first_n[s]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[s] += frag_get(fa, j);
+                }
+            }
+        }
+        b ^= 1;
+    }
+
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) {
+        const int tl = s * WG_WAVES + w;
+        if (tl < ntot) {
+            const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+            const int q = nt * 16 + l15;
+            if (q < nexp) {
+                const int tap = q / ng, i = q % ng;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 16 + 4 * g4 + r;
+                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
+                }
+            }
+            if (do_bias && nt == 0) {
+                const float tsum = wave_sum16(bsum[s]);
+                const int m = mt * 16 + l15;
+                if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
+            }
+        }
+    }
+}
+
 template <class T>
 static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
@@ -371,9 +539,23 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     // a staging block must not straddle a group: the per-group widths have to be multiples of the block width
     const bool cw8 = mg % 8 == 0 && ng % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && sizeof(T) == 2;
     const int nchunks = cdiv(a.Ntok, WG_KC);
-    if (sizeof(T) == 2 && mg % 8 == 0 && ng % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
-        const int ncA = all ? a.MA : mg, ncB = all ? a.NB : ng;
+    const int ncA = all ? a.MA : mg, ncB = all ? a.NB : ng;
+    // transposing-read kernels: whole rows are copied in 16-byte pieces (staged widths % 8) and tiles are addressed in
+    // 4-channel pieces (group widths % 4, checked by the caller)
+    if (sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
         const size_t lds_tr = ((size_t)WG_KC * tr_ld(ncA) + (size_t)a.taps * WG_KC * tr_ld(ncB)) * 2;
+        const int nvec = WG_KC * (ncA / 8) + a.taps * WG_KC * (ncB / 8);
+        if (2 * lds_tr + 2 * (size_t)a.NB * sizeof(float) <= 158 * 1024 && nvec <= WG_MAXV * WG_THREADS) {  // double-buffered, register-prefetched variant
+            int xb = 256 / ybl;
+            if (xb < 16) xb = 16;
+            if (xb > nchunks) xb = nchunks;
+            ProfScope ps(PK_WGRAD, st);
+            const size_t lds2 = 2 * lds_tr + 2 * (size_t)a.NB * sizeof(float);
+            int e2 = NBSS_SET_MAX_LDS(wgrad_tr2_kernel, lds2);
+            if (e2) return e2;
+            NBSS_LAUNCH(wgrad_tr2_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds2, st, a);
+            return NBSS_CHECK_LAUNCH();
+        }
         if (lds_tr <= 120 * 1024) {
             int xb = 256 / ybl;  // one workgroup per CU: doubling it (2 per CU) cost 16.6 -> 18.9 ms/step (more flush atomics, less work each)
             if (xb < 16) xb = 16;
