@@ -391,6 +391,7 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     if ((e = affine_reduce_launch(part, c.B * c.T, sg, G, st))) return e;
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
     WgradArgs a;
+    a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = c.T; a.shift_dim = 1; a.groups = c.f_groups; a.taps = c.f_ks;
     a.A = dv; a.lda = FC_H; a.MA = FC_H; a.B = x; a.ldb = FC_H; a.NB = FC_H;

@@ -398,6 +398,7 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     sg.off[1] = param_off(c, layer, P_FULL_LN_B); sg.cnt[1] = FL_H;
     if ((e = affine_reduce_launch(part, c.B * cdiv(c.T, FL_TT), sg, G, st))) return e;
     WgradArgs a;
+    a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
     a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.taps = 1;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;

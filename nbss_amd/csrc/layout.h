@@ -179,17 +179,25 @@ NBSS_HD int64_t pack_total(const nbss_cfg& c) {
     return pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + pack_numel(c, K_DEC_T) + (int64_t)c.L * pack_layer_numel(c);
 }
 
+// wgrad partial tiles: 256 workgroups x 112 tiles x (256 accumulators + 16 bias sums) floats
+#define WGPART_BYTES ((size_t)256 * 112 * 272 * sizeof(float))
 // backward workspace (caller-provided): per-token LN statistics + the widest set of wgrad operands
 NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
-    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + 256;
+    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) + 256;
 }
 // per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands
 NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz);
+}
+
+// per-workgroup partial dW tiles of the wgrad kernels live behind those
+NBSS_HD size_t ws_wgpart_offset(const nbss_cfg& c) {
+    const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
+    return ws_part_offset(c) + ws_align(nwg * 576 * sizeof(float));
 }
 
 NBSS_HD int check_cfg(const nbss_cfg& c) {

@@ -437,6 +437,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     sg.off[1] = param_off(c, layer, P_MH_LN_B); sg.cnt[1] = MB_H;
     if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
     WgradArgs a;
+    a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
     // out_proj: dWo[H][H] = dy^T O ; dbo = colsum(dy)

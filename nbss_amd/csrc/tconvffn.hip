@@ -143,6 +143,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
     T* hb = ha + (TF_TP + 2) * TF_CG;                      // [TP+2][24]
     float* red = reinterpret_cast<float*>(hb + (TF_TP + 2) * TF_CG);  // [8 waves][2]
     T* wl = reinterpret_cast<T*>(red + 16);  // this group's weights: W1 | conv1 | conv2 | conv3 | W2, 6 fragments each
+    float* prm = reinterpret_cast<float*>(wl + 30 * 512);  // [7][FFN]: b1 cb1 cb2 cb3 gnw gnb b2 (per-lane global reads of these sat in every dependency chain)
     const int T_ = c.T;
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -150,14 +151,26 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
     T* yb = y + (size_t)bf * T_ * TF_H;
     const float* lnw = lp.p[P_TF_LN_W];
     const float* lnb = lp.p[P_TF_LN_B];
-    const float* b1 = lp.p[P_TF_B1];
-    const float* cb1 = lp.p[P_TF_C1B];
-    const float* cb2 = lp.p[P_TF_C2B];
-    const float* cb3 = lp.p[P_TF_C3B];
-    const float* gnw = lp.p[P_TF_GN_W];
-    const float* gnb = lp.p[P_TF_GN_B];
-    const float* b2 = lp.p[P_TF_B2];
+    const float* b1_g = lp.p[P_TF_B1];
+    const float* b1 = prm + 0 * TF_FFN;
+    const float* cb1_g = lp.p[P_TF_C1B];
+    const float* cb1 = prm + 1 * TF_FFN;
+    const float* cb2_g = lp.p[P_TF_C2B];
+    const float* cb2 = prm + 2 * TF_FFN;
+    const float* cb3_g = lp.p[P_TF_C3B];
+    const float* cb3 = prm + 3 * TF_FFN;
+    const float* gnw_g = lp.p[P_TF_GN_W];
+    const float* gnw = prm + 4 * TF_FFN;
+    const float* gnb_g = lp.p[P_TF_GN_B];
+    const float* gnb = prm + 5 * TF_FFN;
+    const float* b2_g = lp.p[P_TF_B2];
+    const float* b2 = prm + 6 * TF_FFN;
 
+    for (int i = tid; i < TF_FFN; i += blockDim.x) {
+        prm[i] = b1_g[i]; prm[TF_FFN + i] = cb1_g[i]; prm[2 * TF_FFN + i] = cb2_g[i]; prm[3 * TF_FFN + i] = cb3_g[i];
+        prm[4 * TF_FFN + i] = gnw_g[i]; prm[5 * TF_FFN + i] = gnb_g[i];
+        if (i < TF_H) prm[6 * TF_FFN + i] = b2_g[i];
+    }
     // halo rows (t = -1 and t = TP) are never written by the strips: zero them once
     if (tid < TF_CG) {
         store1(ha + tid, 0.f);
@@ -372,7 +385,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     float* red = reinterpret_cast<float*>(buf3 + (size_t)(tp + 2) * TF_CG);  // [8 waves][2]
     float* aff = red + 16;  // [576] per-workgroup sums: GN weight | GN bias | LN weight | LN bias
     float* lnp = aff + TF_AFF;  // [2H] LayerNorm gamma | beta
-    T* wl = reinterpret_cast<T*>(lnp + 2 * TF_H);  // this group's weights: W1 c1 c2 c3 | W2^T c3^T c2^T c1^T W1^T, 6 fragments each
+    float* prm = lnp + 2 * TF_H;  // [6][FFN]: b1 cb1 cb2 cb3 gnw gnb
+    T* wl = reinterpret_cast<T*>(prm + 6 * TF_FFN);  // this group's weights: W1 c1 c2 c3 | W2^T c3^T c2^T c1^T W1^T, 6 fragments each
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
@@ -381,12 +395,18 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     T* dxb = dx + n0 * TF_H;
     const float* lnw = lp.p[P_TF_LN_W];
     const float* lnb = lp.p[P_TF_LN_B];
-    const float* b1 = lp.p[P_TF_B1];
-    const float* cb1 = lp.p[P_TF_C1B];
-    const float* cb2 = lp.p[P_TF_C2B];
-    const float* cb3 = lp.p[P_TF_C3B];
-    const float* gnw = lp.p[P_TF_GN_W];
-    const float* gnb = lp.p[P_TF_GN_B];
+    const float* b1_g = lp.p[P_TF_B1];
+    const float* b1 = prm + 0 * TF_FFN;
+    const float* cb1_g = lp.p[P_TF_C1B];
+    const float* cb1 = prm + 1 * TF_FFN;
+    const float* cb2_g = lp.p[P_TF_C2B];
+    const float* cb2 = prm + 2 * TF_FFN;
+    const float* cb3_g = lp.p[P_TF_C3B];
+    const float* cb3 = prm + 3 * TF_FFN;
+    const float* gnw_g = lp.p[P_TF_GN_W];
+    const float* gnw = prm + 4 * TF_FFN;
+    const float* gnb_g = lp.p[P_TF_GN_B];
+    const float* gnb = prm + 5 * TF_FFN;
 
     for (int i = tid; i < TF_AFF; i += blockDim.x) aff[i] = 0.f;
     if (tid < TF_CG) {
@@ -412,6 +432,10 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     // the group loop and spilled 416 B/lane: 78 % of the wave time was spent waiting on scratch reloads).  Now only the row
     // statistics persist; LN(x) and dy fragments are re-read per group (L2/L1 hits) and du is formed after the loop.
     for (int i = tid; i < 2 * TF_H; i += blockDim.x) lnp[i] = i < TF_H ? lnw[i] : lnb[i - TF_H];
+    for (int i = tid; i < TF_FFN; i += blockDim.x) {
+        prm[i] = b1_g[i]; prm[TF_FFN + i] = cb1_g[i]; prm[2 * TF_FFN + i] = cb2_g[i]; prm[3 * TF_FFN + i] = cb3_g[i];
+        prm[4 * TF_FFN + i] = gnw_g[i]; prm[5 * TF_FFN + i] = gnb_g[i];
+    }
     float smean[TF_NSW], srstd[TF_NSW];
 #pragma unroll
     for (int si = 0; si < TF_NSW; ++si) {
@@ -438,6 +462,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     const bool v1 = g4 < 2;
     const float cnt = (float)(TF_CG * T_);
 
+    lds_barrier();  // lnp / prm / halo rows are in place
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
         f32x4 a1[TF_NSW][2], a2[TF_NSW][2], a3h[TF_NSW][2], a5[TF_NSW][2], ct[TF_NSW][2];
@@ -772,7 +797,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
                           float* stats, void* const* opsv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF + 2 * TF_H) * sizeof(float) + (sizeof(T) == 2 ? (size_t)48 * 512 * sizeof(T) : 0);
+    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF + 2 * TF_H + 6 * TF_FFN) * sizeof(float) + (sizeof(T) == 2 ? (size_t)48 * 512 * sizeof(T) : 0);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
     TfOps<T> ops;
@@ -810,6 +835,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     sg.off[3] = param_off(c, layer, P_TF_LN_B); sg.cnt[3] = TF_H;
     if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
     WgradArgs a;
+    a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
@@ -837,7 +863,7 @@ template <class T>
 static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + 16 * sizeof(float) + (size_t)30 * 512 * sizeof(T);
+    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + 7 * TF_FFN) * sizeof(float) + (size_t)30 * 512 * sizeof(T);
     const T* pk = (const T*)packed;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_F, st);

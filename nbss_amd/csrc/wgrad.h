@@ -18,6 +18,9 @@ struct WgradArgs {
     float* dW;       // [MA][NB/groups][taps], accumulated with atomicAdd
     float* dbias;    // optional [MA]: column sums of dY
     int Ntok, F, T;
+    float* part = nullptr;  // optional scratch (layout.h: ws_wgpart_offset / WGPART_BYTES): per-workgroup partial tiles + a reduce pass replace
+                            // the 256-deep same-address atomicAdd flush (31% of the kernel's time when measured)
+    int dbg = 0;  // NBSS_WG_DEBUG probe bits (tools/wgrad_probe.sh): 1 no flush, 2 no MFMA/reads, 4 no global loads, 8 no LDS stash
 };
 
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);

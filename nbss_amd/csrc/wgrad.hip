@@ -19,6 +19,7 @@
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
+#include <cstdlib>
 #include "prof.h"
 
 #define WG_KC 32
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
             pmu[u] = 0.f; prs[u] = 0.f;
             if (!vok[u]) continue;
             const int n = n0 + vk[u];
-            if (n >= a.Ntok) continue;
+            if (n >= a.Ntok || (a.dbg & 4)) continue;
             if (vA[u]) {
                 pre[u] = *reinterpret_cast<const u32x4*>(Ag + (size_t)n * a.lda + vcol[u]);
             } else {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
     auto stash = [&](T* buf) {
 #pragma unroll
         for (int u = 0; u < WG_MAXV; ++u) {
-            if (!vok[u]) continue;
+            if (!vok[u] || (a.dbg & 8)) continue;
             u32x4 x = pre[u];
             if (!vA[u] && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
                 float f[8];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
         if (ch + (int)gridDim.x < nchunks) prefetch((ch + gridDim.x) * WG_KC);
 #pragma unroll
         for (int s = 0; s < WG_TPW; ++s) {
-            if (s * WG_WAVES + w < ntot) {
+            if (s * WG_WAVES + w < ntot && !(a.dbg & 2)) {
                 Frag<T> fa, fb;
                 frag_load_tr(fa, buf + oa[s], lda);
                 frag_load_tr(fb, buf + ob[s], ldb);
@@ -501,10 +502,28 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
         b ^= 1;
     }
 
+    if (a.part) {  // partial tiles in fragment order (coalesced 256-byte stores); wgrad_reduce_kernel folds them into dW
+        const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        float* pt = a.part + wg * ntot * 256;
+        float* pbias = a.part + (size_t)gridDim.y * gridDim.x * ntot * 256 + wg * ntot * 16;
+#pragma unroll
+        for (int s = 0; s < WG_TPW; ++s) {
+            const int tl = s * WG_WAVES + w;
+            if (tl < ntot && !(a.dbg & 1)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[s][r];
+                if (do_bias && first_n[s]) {
+                    const float tsum = wave_sum16(bsum[s]);
+                    if (g4 == 0) pbias[tl * 16 + l15] = tsum;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < WG_TPW; ++s) {
         const int tl = s * WG_WAVES + w;
-        if (tl < ntot) {
+        if (tl < ntot && !(a.dbg & 1)) {
             const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
             const int q = nt * 16 + l15;
             if (q < nexp) {
@@ -521,6 +540,43 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
                 if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
             }
         }
+    }
+}
+
+// Second pass of the two-stage flush: block (tile, slice, y) sums its slice of the x-blocks' partial tiles and adds the result
+// to dW (WG_RSL atomicAdds per element instead of one per workgroup).
+#define WG_RSL 8
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb) {
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
+    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
+    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
+    const int tpg = mtiles * ntiles;
+    const bool per_group = gridDim.z > 1;
+    const int ntot = (per_group ? 1 : a.groups) * tpg;
+    const int tl = blockIdx.x, y = blockIdx.z;
+    const int x0 = (int)((long)xb * blockIdx.y / gridDim.y), x1 = (int)((long)xb * (blockIdx.y + 1) / gridDim.y);
+    const float* pt = a.part + ((size_t)y * xb * ntot + tl) * 256 + tid;
+    const size_t xs = (size_t)ntot * 256;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int x = x0;
+    for (; x + 4 <= x1; x += 4) {
+        s0 += pt[(size_t)x * xs]; s1 += pt[(size_t)(x + 1) * xs]; s2 += pt[(size_t)(x + 2) * xs]; s3 += pt[(size_t)(x + 3) * xs];
+    }
+    for (; x < x1; ++x) s0 += pt[(size_t)x * xs];
+    const float sum = (s0 + s1) + (s2 + s3);
+    const int g = (per_group ? y : 0) + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+    const int q = nt * 16 + l15;
+    if (q < nexp) {
+        const int tap = q / ng, i = q % ng, m = mt * 16 + 4 * g4 + r;
+        if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, sum);
+    }
+    if (a.dbias && nt == 0 && tid < 16) {
+        const float* pbias = a.part + (size_t)gridDim.z * xb * ntot * 256 + ((size_t)y * xb * ntot + tl) * 16 + tid;
+        float b = 0.f;
+        for (int xx = x0; xx < x1; ++xx) b += pbias[(size_t)xx * ntot * 16];
+        const int m = mt * 16 + tid;
+        if (m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, b);
     }
 }
 
@@ -553,8 +609,16 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             const size_t lds2 = 2 * lds_tr + 2 * (size_t)a.NB * sizeof(float);
             int e2 = NBSS_SET_MAX_LDS(wgrad_tr2_kernel, lds2);
             if (e2) return e2;
-            NBSS_LAUNCH(wgrad_tr2_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds2, st, a);
-            return NBSS_CHECK_LAUNCH();
+            const int ntot2 = (all ? a.groups : 1) * tpg;
+            WgradArgs a2 = a;
+            if ((size_t)ybl * xb * ntot2 * 272 * sizeof(float) > WGPART_BYTES) a2.part = nullptr;
+            NBSS_LAUNCH(wgrad_tr2_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds2, st, a2);
+            if ((e2 = NBSS_CHECK_LAUNCH())) return e2;
+            if (a2.part && !(a2.dbg & 1)) {
+                NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot2, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a2, xb);
+                return NBSS_CHECK_LAUNCH();
+            }
+            return NBSS_OK;
         }
         if (lds_tr <= 120 * 1024) {
             int xb = 256 / ybl;  // one workgroup per CU: doubling it (2 per CU) cost 16.6 -> 18.9 ms/step (more flush atomics, less work each)
@@ -583,7 +647,10 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     return NBSS_CHECK_LAUNCH();
 }
 
-int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st) {
+int wgrad_launch(const WgradArgs& a0, int dtype, hipStream_t st) {
+    static const int dbg = getenv("NBSS_WG_DEBUG") ? atoi(getenv("NBSS_WG_DEBUG")) : 0;
+    WgradArgs a = a0;
+    a.dbg = dbg;
     if (a.MA % a.groups || a.NB % a.groups) return NBSS_EINVAL;
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     if (mg % 4 || ng % 4) return NBSS_EUNSUPPORTED;
