@@ -84,6 +84,14 @@ NBSS_DEV void lds_barrier() {
 
 NBSS_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 NBSS_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+// same value, but known to the compiler as wave-uniform: index arithmetic derived from it stays in SGPRs
+NBSS_DEV int wave_id_u() {
+#ifdef NBSS_EMU
+    return (int)(threadIdx.x >> 6);
+#else
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+}
 
 NBSS_DEV float wave_sum16(float v) {  // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
     v += __shfl_xor(v, 16);

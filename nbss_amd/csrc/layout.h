@@ -179,8 +179,8 @@ NBSS_HD int64_t pack_total(const nbss_cfg& c) {
     return pack_numel(c, K_ENC) + pack_numel(c, K_DEC) + pack_numel(c, K_DEC_T) + (int64_t)c.L * pack_layer_numel(c);
 }
 
-// wgrad partial tiles: 256 workgroups x 112 tiles x (256 accumulators + 16 bias sums) floats
-#define WGPART_BYTES ((size_t)256 * 112 * 272 * sizeof(float))
+// wgrad partial tiles: up to 512 workgroups x 112 tiles x (256 accumulators + 16 bias sums) floats
+#define WGPART_BYTES ((size_t)512 * 112 * 272 * sizeof(float))
 // backward workspace (caller-provided): per-token LN statistics + the widest set of wgrad operands
 NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {

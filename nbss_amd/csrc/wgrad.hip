@@ -224,10 +224,11 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
 // bf16 fast path: ROW-MAJOR LDS images + transposing LDS reads (ds_read_b64_tr_b16).  Staging is a plain 16-byte copy
 // (global row -> LDS row, one image per tap with out-of-range rows zeroed); an MFMA operand with K = tokens is two
 // transposing reads of a 4-token x 16-channel block each.  No register transposes, no scalar LDS writes.
-// Row stride = (cols + pad) with stride/2 dwords == 8 (mod 64): the 8 rows a 32-lane service group touches tile all 64 banks.
+// Row stride = (cols + pad) elements with stride == 16 (mod 32), i.e. an odd multiple of 32 bytes: the 8 rows x 32 bytes a 32-lane
+// service group touches then tile all 64 banks.
 NBSS_HD int tr_ld(int cols) {
     int ld = cols + 16;
-    while (ld % 128 != 16) ld += 8;
+    while (ld % 32 != 16) ld += 8;
     return ld;
 }
 
@@ -543,10 +544,202 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
     }
 }
 
+// Third generation: 64-token chunks and ONE shared X image for all taps of a T-conv.  Chunks of a tapped problem are aligned to
+// (b,f) rows — tokens t0-h .. t0+63+h of one row, zero outside [0,T) — so tap d is just a row offset of d in the image and X is
+// fetched and written to LDS once instead of once per tap (tr2: 6 vectors per thread per 32 tokens; here 6 per 64).  Tiles are
+// ordered nt-major so the bias column sums only exist in the first slots of a wave.
+#define W3_KC 64
+#define W3_MAXV 7
+#define W3_BS 3  // slots that can hold nt == 0 tiles (ngrp * mtiles <= 8 * W3_BS)
+
+template <int NBUF>
+__global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kernel(WgradArgs a) {
+    NBSS_LDS(smem);
+    typedef bf16_t T;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id_u();
+    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
+    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
+    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
+    const bool per_group = gridDim.y > 1;
+    const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
+    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
+    const int lda = tr_ld(ncolsA), ldb = tr_ld(ncolsB);
+    const int h = a.taps / 2, rowsB = W3_KC + 2 * h;
+    const int imgA = W3_KC * lda, img = imgA + rowsB * ldb;  // elements per buffer
+    T* base = reinterpret_cast<T*>(smem);
+    for (int i = tid; i < NBUF * img / 2; i += WG_THREADS) reinterpret_cast<uint32_t*>(base)[i] = 0u;
+    float* lnp = reinterpret_cast<float*>(base + (size_t)NBUF * img);  // [2 NB] LayerNorm gamma | beta of the X operand
+    if (a.stats)
+        for (int i = tid; i < 2 * a.NB; i += WG_THREADS) lnp[i] = i < a.NB ? a.gamma[i] : a.beta[i - a.NB];
+
+    f32x4 acc[WG_TPW];
+    float bsum[W3_BS];
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
+#pragma unroll
+    for (int s = 0; s < W3_BS; ++s) bsum[s] = 0.f;
+    const bool do_bias = a.dbias != nullptr;
+    const T* Ag = reinterpret_cast<const T*>(a.A);
+    const T* Bg = reinterpret_cast<const T*>(a.B);
+    const int pA = ncolsA / 8, pB = ncolsB / 8;
+    const int nvA = W3_KC * pA, nvec = nvA + rowsB * pB;
+    const int nfirst = ngrp * mtiles, ntot = nfirst * ntiles;  // tile tl = nt * nfirst + (g * mtiles + mt)
+
+    // per-slot offsets (elements, inside a buffer) of this lane's transposing reads
+    int oa[WG_TPW], ob[WG_TPW];
+    const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) {
+        const int tl = s * WG_WAVES + w;
+        oa[s] = 0; ob[s] = 0;
+        if (tl < ntot) {
+            const int nt = tl / nfirst, gm = tl % nfirst, g = gm / mtiles, mt = gm % mtiles;
+            oa[s] = trow * lda + g * mg + mt * 16 + tcol;
+            int q0 = nt * 16 + tcol;
+            if (q0 >= nexp) q0 = 0;  // padding columns of the last tile: any valid address, discarded at the flush
+            ob[s] = imgA + (q0 / ng + trow) * ldb + g * ng + q0 % ng;  // tap = q0 / ng: image row k + tap holds token k + tap - h
+        }
+    }
+    // per-vector descriptors of this thread (chunk independent): chunk-relative row, global element offset, LDS offset
+    int vkk[W3_MAXV], vgo[W3_MAXV], vdst[W3_MAXV];
+    bool vA[W3_MAXV], vok[W3_MAXV];
+#pragma unroll
+    for (int u = 0; u < W3_MAXV; ++u) {
+        const int v = tid + u * WG_THREADS;
+        vok[u] = v < nvec;
+        vA[u] = v < nvA;
+        if (vA[u]) {
+            const int k = v / pA, c8 = v % pA;
+            vkk[u] = k; vgo[u] = k * a.lda + acols0 + 8 * c8; vdst[u] = k * lda + 8 * c8;
+        } else {
+            const int v2 = vok[u] ? v - nvA : 0, j = v2 / pB, c8 = v2 % pB;
+            vkk[u] = j - h; vgo[u] = (j - h) * a.ldb + bcols0 + 8 * c8; vdst[u] = imgA + j * ldb + 8 * c8;
+        }
+    }
+    const int cpr = cdiv(a.T, W3_KC);
+    const int nchunks = a.taps > 1 ? (a.Ntok / a.T) * cpr : cdiv(a.Ntok, W3_KC);
+    u32x4 pre[W3_MAXV];
+    float pmu[W3_MAXV], prs[W3_MAXV];
+    auto prefetch = [&](int ch) {
+        long nbase;
+        int lo, lim;  // chunk-relative rows lo <= k < lim exist
+        if (a.taps > 1) {
+            const int row = ch / cpr, t0 = (ch % cpr) * W3_KC;
+            nbase = (long)row * a.T + t0; lo = -t0; lim = a.T - t0;
+        } else {
+            nbase = (long)ch * W3_KC; lo = 0; lim = a.Ntok - (int)nbase;
+        }
+        const T* Ab = Ag + nbase * a.lda;
+        const T* Bb = Bg + nbase * a.ldb;
+        const float* sb = a.stats ? a.stats + 2 * nbase : nullptr;
+#pragma unroll
+        for (int u = 0; u < W3_MAXV; ++u) {
+            pre[u] = (u32x4){0, 0, 0, 0};
+            pmu[u] = 0.f; prs[u] = 0.f;
+            if (!vok[u] || vkk[u] < lo || vkk[u] >= lim || (a.dbg & 4)) continue;
+            pre[u] = *reinterpret_cast<const u32x4*>((vA[u] ? Ab : Bb) + vgo[u]);
+            if (!vA[u] && sb) { pmu[u] = sb[2 * vkk[u]]; prs[u] = sb[2 * vkk[u] + 1]; }
+        }
+    };
+    auto stash = [&](T* buf) {
+#pragma unroll
+        for (int u = 0; u < W3_MAXV; ++u) {
+            if (!vok[u] || (a.dbg & 8)) continue;
+            u32x4 x = pre[u];
+            if (!vA[u] && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
+                float gm[8], bt[8];
+                const int col = vgo[u] - vkk[u] * a.ldb;
+                load8(lnp + col, gm);
+                load8(lnp + a.NB + col, bt);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = prs[u] != 0.f ? (f[e] - pmu[u]) * prs[u] * gm[e] + bt[e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+            }
+            *reinterpret_cast<u32x4*>(buf + vdst[u]) = x;
+        }
+    };
+
+    int ch = blockIdx.x;
+    if (ch < nchunks) prefetch(ch);
+    lds_barrier();  // zero fill done
+    int b = 0;
+    for (; ch < nchunks; ch += gridDim.x) {
+        T* buf = base + (size_t)b * img;
+        stash(buf);
+        lds_barrier();
+        if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
+#pragma unroll
+        for (int s = 0; s < WG_TPW; ++s) {
+            const int tl = s * WG_WAVES + w;
+            if (tl < ntot && !(a.dbg & 2)) {
+#pragma unroll
+                for (int kh = 0; kh < W3_KC / 32; ++kh) {
+                    Frag<T> fa, fb;
+                    frag_load_tr(fa, buf + oa[s] + kh * 32 * lda, lda);
+                    frag_load_tr(fb, buf + ob[s] + kh * 32 * ldb, ldb);
+                    acc[s] = mma(fa, fb, acc[s]);
+                    if (s < W3_BS && do_bias && tl < nfirst) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[s < W3_BS ? s : 0] += frag_get(fa, j);
+                    }
+                }
+            }
+        }
+        if (NBUF == 1) lds_barrier();
+        else b ^= 1;
+    }
+
+    if (a.dbg & 1) return;
+    if (a.part) {  // partial tiles in fragment order (coalesced 256-byte stores); wgrad_reduce_kernel folds them into dW
+        const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        float* pt = a.part + wg * ntot * 256;
+        float* pbias = a.part + (size_t)gridDim.y * gridDim.x * ntot * 256 + wg * ntot * 16;
+#pragma unroll
+        for (int s = 0; s < WG_TPW; ++s) {
+            const int tl = s * WG_WAVES + w;
+            if (tl < ntot) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[s][r];
+                if (s < W3_BS && do_bias && tl < nfirst) {
+                    const float tsum = wave_sum16(bsum[s < W3_BS ? s : 0]);
+                    if (g4 == 0) pbias[tl * 16 + l15] = tsum;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < WG_TPW; ++s) {
+        const int tl = s * WG_WAVES + w;
+        if (tl < ntot) {
+            const int nt = tl / nfirst, gm = tl % nfirst, g = g_lo + gm / mtiles, mt = gm % mtiles;
+            const int q = nt * 16 + l15;
+            if (q < nexp) {
+                const int tap = q / ng, i = q % ng;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 16 + 4 * g4 + r;
+                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
+                }
+            }
+            if (s < W3_BS && do_bias && nt == 0) {
+                const float tsum = wave_sum16(bsum[s < W3_BS ? s : 0]);
+                const int m = mt * 16 + l15;
+                if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
+            }
+        }
+    }
+}
+
+
 // Second pass of the two-stage flush: block (tile, slice, y) sums its slice of the x-blocks' partial tiles and adds the result
 // to dW (WG_RSL atomicAdds per element instead of one per workgroup).
 #define WG_RSL 8
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb, int nt_major) {
     const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
@@ -565,7 +758,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb) 
     }
     for (; x < x1; ++x) s0 += pt[(size_t)x * xs];
     const float sum = (s0 + s1) + (s2 + s3);
-    const int g = (per_group ? y : 0) + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
+    int g, mt, nt;
+    if (nt_major) {  // wgrad_tr3_kernel: tl = nt * nfirst + g * mtiles + mt
+        const int nfirst = ntot / ntiles, gm = tl % nfirst;
+        nt = tl / nfirst; g = gm / mtiles; mt = gm % mtiles;
+    } else {
+        const int rem = tl % tpg;
+        g = tl / tpg; mt = rem / ntiles; nt = rem % ntiles;
+    }
+    if (per_group) g += y;
     const int q = nt * 16 + l15;
     if (q < nexp) {
         const int tap = q / ng, i = q % ng, m = mt * 16 + 4 * g4 + r;
@@ -599,6 +800,37 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     // transposing-read kernels: whole rows are copied in 16-byte pieces (staged widths % 8) and tiles are addressed in
     // 4-channel pieces (group widths % 4, checked by the caller)
     if (sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
+        // 64-token chunks, one X image for all taps: dense problems and T-convs
+        const int h3 = a.taps / 2, nfirst3 = (all ? a.groups : 1) * mtiles;
+        const size_t img3 = ((size_t)W3_KC * tr_ld(ncA) + (size_t)(W3_KC + 2 * h3) * tr_ld(ncB)) * 2;
+        const int nvec3 = W3_KC * (ncA / 8) + (W3_KC + 2 * h3) * (ncB / 8);
+        static const int nbuf3 = getenv("NBSS_WG_NBUF") ? atoi(getenv("NBSS_WG_NBUF")) : 2;
+        if ((a.taps == 1 || (a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0)) && nvec3 <= W3_MAXV * WG_THREADS &&
+            nfirst3 <= WG_WAVES * W3_BS && nbuf3 * img3 + 2 * (size_t)a.NB * sizeof(float) <= (nbuf3 == 1 ? 80 : 158) * 1024) {
+            const int nch3 = a.taps > 1 ? (a.Ntok / a.T) * cdiv(a.T, W3_KC) : cdiv(a.Ntok, W3_KC);
+            int xb = (nbuf3 == 1 ? 512 : 256) / ybl;
+            if (xb < 16) xb = 16;
+            if (xb > nch3) xb = nch3;
+            ProfScope ps(PK_WGRAD, st);
+            const size_t lds3 = nbuf3 * img3 + 2 * (size_t)a.NB * sizeof(float);
+            const int ntot3 = nfirst3 * ntiles;
+            WgradArgs a3 = a;
+            if ((size_t)ybl * xb * ntot3 * 272 * sizeof(float) > WGPART_BYTES) a3.part = nullptr;
+            int e3;
+            if (nbuf3 == 1) {
+                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<1>, lds3))) return e3;
+                NBSS_LAUNCH(wgrad_tr3_kernel<1>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
+            } else {
+                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<2>, lds3))) return e3;
+                NBSS_LAUNCH(wgrad_tr3_kernel<2>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
+            }
+            if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
+            if (a3.part && !(a3.dbg & 1)) {
+                NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot3, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a3, xb, 1);
+                return NBSS_CHECK_LAUNCH();
+            }
+            return NBSS_OK;
+        }
         const size_t lds_tr = ((size_t)WG_KC * tr_ld(ncA) + (size_t)a.taps * WG_KC * tr_ld(ncB)) * 2;
         const int nvec = WG_KC * (ncA / 8) + a.taps * WG_KC * (ncB / 8);
         if (2 * lds_tr + 2 * (size_t)a.NB * sizeof(float) <= 158 * 1024 && nvec <= WG_MAXV * WG_THREADS) {  // double-buffered, register-prefetched variant
@@ -615,7 +847,7 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             NBSS_LAUNCH(wgrad_tr2_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds2, st, a2);
             if ((e2 = NBSS_CHECK_LAUNCH())) return e2;
             if (a2.part && !(a2.dbg & 1)) {
-                NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot2, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a2, xb);
+                NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot2, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a2, xb, 0);
                 return NBSS_CHECK_LAUNCH();
             }
             return NBSS_OK;
