@@ -7,6 +7,7 @@ also wrap the host-emulator flavour of the same C ABI, which only tests/ may do.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 NBSS_F32, NBSS_BF16 = 0, 1
@@ -107,7 +108,9 @@ _HIP = None
 
 
 def hip_lib_path() -> Path:
-    return Path(__file__).resolve().parent / "lib" / "libnbss_hip.so"
+    # NBSS_HIP_FLAVOUR=phase selects the diagnostic build with in-kernel phase timers (tools/phase_prof.py); same kernels
+    flavour = os.environ.get("NBSS_HIP_FLAVOUR", "")
+    return Path(__file__).resolve().parent / "lib" / ("libnbss_hip_phase.so" if flavour == "phase" else "libnbss_hip.so")
 
 
 def hip() -> Lib:

@@ -7,13 +7,7 @@
 #define BK_MT 6   // H / 16
 
 // sum over the 16 lanes that share (lane >> 4): per-channel reduction over the 16 frames of a strip
-NBSS_DEV float sum_l15_(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-}
+NBSS_DEV float sum_l15_(float v) { return row_sum16(v); }
 
 NBSS_DEV void load_ln_affine(const float* __restrict__ lnw, const float* __restrict__ lnb, float (&gam)[BK_KS][8], float (&bet)[BK_KS][8]) {
     const int g4 = lane_id() >> 4;

@@ -103,11 +103,27 @@ NBSS_DEV float wave_max16(float v) {
     v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
-NBSS_DEV float wave_sum64(float v) {
+// sum over the 16 lanes of a row (lanes sharing l>>4), result in every lane.  DPP row operations (quad swaps, half-mirror, mirror)
+// run in the VALU; __shfl_xor compiles to ds_bpermute_b32, which queues behind the workgroup's real LDS traffic.
+NBSS_DEV float row_sum16(float v) {
+#ifdef NBSS_EMU
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
     v += __shfl_xor(v, 4);
     v += __shfl_xor(v, 8);
+    return v;
+#else
+#define NBSS_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    NBSS_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    NBSS_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    NBSS_DPP_ADD(0x141);  // row_half_mirror
+    NBSS_DPP_ADD(0x140);  // row_mirror
+#undef NBSS_DPP_ADD
+    return v;
+#endif
+}
+NBSS_DEV float wave_sum64(float v) {
+    v = row_sum16(v);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;

@@ -80,6 +80,59 @@ NBSS_DEV void stage_frags(T* __restrict__ dst, const T* __restrict__ src, int nf
     for (int v = threadIdx.x; v < nfrag * 512 / VN; v += blockDim.x)
         *reinterpret_cast<u32x4*>(dst + (size_t)v * VN) = *reinterpret_cast<const u32x4*>(src + (size_t)v * VN);
 }
+// Batched variants for the group loops: every 16-byte load of the group's fragments is in flight before the first LDS write
+// (one call of stage_frags per weight costs one exposed L2 latency each: 4 us per group when measured with phase timers).
+template <class T>
+struct StageSrcs {  // named members, not an array: a select between array elements becomes a per-lane scratch load
+    const T *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
+    template <int I>
+    NBSS_DEV const T* get() const {
+        if constexpr (I == 0) return p0;
+        else if constexpr (I == 1) return p1;
+        else if constexpr (I == 2) return p2;
+        else if constexpr (I == 3) return p3;
+        else if constexpr (I == 4) return p4;
+        else if constexpr (I == 5) return p5;
+        else if constexpr (I == 6) return p6;
+        else return p7;
+    }
+};
+template <class T, int NSRC, int I>
+NBSS_DEV void stage_load1(u32x4& r, const StageSrcs<T>& srcs, size_t goff) {
+    constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN;  // vectors per source (6 fragments)
+    constexpr int s0 = (I * 512) / VPS < NSRC ? (I * 512) / VPS : NSRC - 1;  // round I touches at most 3 consecutive sources
+    const int v = (int)threadIdx.x + I * 512;
+    int off = v - s0 * VPS;
+    const T* p = srcs.template get<s0>();
+    if constexpr (s0 + 1 < NSRC) {
+        const T* q = srcs.template get<s0 + 1>();
+        if (off >= VPS) { p = q; off -= VPS; }
+    }
+    if constexpr (s0 + 2 < NSRC) {
+        const T* q = srcs.template get<s0 + 2>();
+        if (off >= VPS) { p = q; off -= VPS; }
+    }
+    if (v < NSRC * VPS) r = *reinterpret_cast<const u32x4*>(p + goff + (size_t)off * VN);
+}
+template <class T, int NSRC, int I, int NV>
+NBSS_DEV void stage_loads(u32x4 (&r)[NV], const StageSrcs<T>& srcs, size_t goff) {
+    if constexpr (I < NV) {
+        stage_load1<T, NSRC, I>(r[I], srcs, goff);
+        stage_loads<T, NSRC, I + 1, NV>(r, srcs, goff);
+    }
+}
+template <class T, int NSRC>
+NBSS_DEV void stage_group(T* __restrict__ wl, const StageSrcs<T>& srcs, size_t goff) {
+    constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN;
+    constexpr int NV = (NSRC * VPS + 511) / 512;
+    u32x4 r[NV];
+    stage_loads<T, NSRC, 0, NV>(r, srcs, goff);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = (int)threadIdx.x + i * 512;
+        if (v < NSRC * VPS) *reinterpret_cast<u32x4*>(wl + (size_t)v * VN) = r[i];
+    }
+}
 template <class T>
 NBSS_DEV void lfrag(Frag<T>& f, const T* __restrict__ wl, int idx) { frag_load(f, wl + ((size_t)idx * 64 + lane_id()) * 8); }
 
@@ -216,11 +269,22 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         f32x4 ct[TF_NSW][2];
         // the group's 30 weight fragments go through LDS once per workgroup (8 waves share them; the packed buffer is
         // regularly evicted from L2 by the activation traffic, and per-wave global fragment loads sat in every MFMA chain)
-        stage_frags<T>(wl, W1 + (size_t)gr * 6 * 512, 6);
-        stage_frags<T>(wl + 6 * 512, Wc1 + (size_t)gr * 6 * 512, 6);
-        stage_frags<T>(wl + 12 * 512, Wc2 + (size_t)gr * 6 * 512, 6);
-        stage_frags<T>(wl + 18 * 512, Wc3 + (size_t)gr * 6 * 512, 6);
-        for (int mt = 0; mt < TF_H / 16; ++mt) stage_frags<T>(wl + (24 + mt) * 512, W2 + (size_t)(mt * TF_G + gr) * 512, 1);
+        {
+            constexpr int VN = 16 / sizeof(T), VPF = 512 / VN;  // vectors per fragment
+            const StageSrcs<T> srcs = {W1, Wc1, Wc2, Wc3, nullptr, nullptr, nullptr, nullptr};
+            u32x4 r2[(6 * VPF + 511) / 512];
+#pragma unroll
+            for (int i = 0; i < (6 * VPF + 511) / 512; ++i) {  // W2: one fragment per output tile, strided by the group count
+                const int v = tid + i * 512, mt = v / VPF, off = v % VPF;
+                if (v < 6 * VPF) r2[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)(mt * TF_G + gr) * 512 + (size_t)off * VN);
+            }
+            stage_group<T, 4>(wl, srcs, (size_t)gr * 6 * 512);
+#pragma unroll
+            for (int i = 0; i < (6 * VPF + 511) / 512; ++i) {
+                const int v = tid + i * 512;
+                if (v < 6 * VPF) *reinterpret_cast<u32x4*>(wl + 24 * 512 + (size_t)v * VN) = r2[i];
+            }
+        }
         lds_barrier();
         // (a) h1 = SiLU(W1_g LN(x) + b1_g) -> ha
 #pragma unroll
@@ -345,28 +409,26 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
 // gradients are NOT formed here: the kernel emits the (activation, pre-activation-gradient) pairs of
 // the five linear maps as [B,F,T,FFN] tensors and wgrad.hip contracts them over all tokens.
 // LayerNorm / GroupNorm affine gradients are reduced in-kernel (shuffle + atomicAdd).
+#define TF_OPS_GM(T) (sizeof(T) == 2)
 template <class T>
 struct TfOps {  // wgrad operands, each [B*F*T][FFN]
     T *h1, *h2, *h4, *h5, *da1, *da2, *da3, *da5;
 };
 
 template <class T>
-NBSS_DEV void store_op(T* __restrict__ op, size_t n, bool valid, int cbase, const f32x4& lo, const f32x4& hi) {
+NBSS_DEV void store_op(T* __restrict__ op, size_t n, bool valid, int gr, size_t ntok, const f32x4& lo, const f32x4& hi) {
     if (!valid) return;
     const int g4 = lane_id() >> 4;
-    T* r = op + n * TF_FFN + cbase;
+    // bf16 stream: group-major operands [G][N][24] — the 16 frames of a strip write 768 contiguous bytes.  Token-major rows
+    // ([N][FFN], 48-byte pieces of a 384-byte row per group) made every store a partial-line write: the kernel fetched 1 GB
+    // from HBM per launch (FETCH_SIZE) for 0.2 GB of algorithmic reads.  The fp32 stream keeps [N][FFN] (generic wgrad kernel).
+    T* r = TF_OPS_GM(T) ? op + ((size_t)gr * ntok + n) * TF_CG : op + n * TF_FFN + gr * TF_CG;
     store4(r + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
     if (g4 < 2) store4(r + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
 }
 
 // sum over the 16 lanes that share (lane>>4): per-channel reduction over the frames of a strip
-NBSS_DEV float sum_l15(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-}
+NBSS_DEV float sum_l15(float v) { return row_sum16(v); }
 
 template <class T>
 __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
@@ -387,6 +449,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     float* lnp = aff + TF_AFF;  // [2H] LayerNorm gamma | beta
     float* prm = lnp + 2 * TF_H;  // [6][FFN]: b1 cb1 cb2 cb3 gnw gnb
     T* wl = reinterpret_cast<T*>(prm + 6 * TF_FFN);  // this group's weights: W1 c1 c2 c3 | W2^T c3^T c2^T c1^T W1^T, 6 fragments each
+    PHASE_BEGIN(wl + (sizeof(T) == 2 ? 48 * 512 : 0));
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
@@ -461,8 +524,10 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     const int d0 = 4 * g4, d1 = 16 + 4 * g4;
     const bool v1 = g4 < 2;
     const float cnt = (float)(TF_CG * T_);
+    const size_t ntok = (size_t)c.B * c.F * T_;
 
     lds_barrier();  // lnp / prm / halo rows are in place
+    PHASE(0);
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
         f32x4 a1[TF_NSW][2], a2[TF_NSW][2], a3h[TF_NSW][2], a5[TF_NSW][2], ct[TF_NSW][2];
@@ -473,25 +538,51 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         const T* wsl[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) wsl[i] = STAGE ? wl + (size_t)i * 6 * 512 : srcs[i] + (size_t)gr * 6 * 512;
-        if (STAGE) {
+        // Every global read of the group is issued here, ahead of the group's operand stores: loads and stores share vmcnt on
+        // gfx9, so a load issued after a store cannot complete before that store is acknowledged (the three phases that read
+        // x, dy and the weights behind stores were 43 % of the wave time).
+        Frag<T> xr[TF_NSW][TF_KS], dr[TF_NSW][TF_KS];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) stage_frags<T>(wl + (size_t)i * 6 * 512, srcs[i] + (size_t)gr * 6 * 512, 6);
+        for (int si = 0; si < TF_NSW; ++si)
+#pragma unroll
+            for (int ks = 0; ks < TF_KS; ++ks) {
+                if (tv[si]) {
+                    frag_load(xr[si][ks], xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                } else {
+                    frag_zero(xr[si][ks]);
+                    frag_zero(dr[si][ks]);
+                }
+            }
+        if (STAGE) {
+            const StageSrcs<T> ss = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
+            stage_group<T, 8>(wl, ss, (size_t)gr * 6 * 512);
             lds_barrier();
         }
+        PHASE(1);
         // ---------------- forward recompute ----------------
+        f32x4 dh5[TF_NSW][2];  // W2[:, group]^T dy, formed now (dy is in registers) and used once a5 exists
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
             a1[si][0] = F32X4_ZERO;
             a1[si][1] = F32X4_ZERO;
+            dh5[si][0] = F32X4_ZERO;
+            dh5[si][1] = F32X4_ZERO;
 #pragma unroll
             for (int ks = 0; ks < TF_KS; ++ks) {
                 Frag<T> uf;
-                u_frag_ks<T>(uf, xb + (size_t)tt[si] * TF_H, tv[si], smean[si], srstd[si], lnp, ks);
+                float gm[8], bt[8];
+                load8(lnp + ks * 32 + 8 * g4, gm);
+                load8(lnp + TF_H + ks * 32 + 8 * g4, bt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) frag_set(uf, j, tv[si] ? (frag_get(xr[si][ks], j) - smean[si]) * srstd[si] * gm[j] + bt[j] : bt[j]);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     Frag<T> a;
                     lfrag<T>(a, wsl[0], half * 3 + ks);
                     a1[si][half] = mma(a, uf, a1[si][half]);
+                    lfrag<T>(a, wsl[4], half * 3 + ks);
+                    dh5[si][half] = mma(a, dr[si][ks], dh5[si][half]);
                 }
             }
         }
@@ -505,9 +596,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][1][r] = v1 ? silu_f(a1[si][1][r]) : 0.f;
             }
             store_rows<T>(buf0, tt[si], tv[si], ct[si][0], ct[si][1]);
-            store_op<T>(ops.h1, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.h1, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(2);
         lds_barrier();
+        PHASE(3);
         conv_group<T>(wsl[1], buf0, w, a2);
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
@@ -519,9 +612,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][1][r] = v1 ? silu_f(a2[si][1][r]) : 0.f;
             }
             store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
-            store_op<T>(ops.h2, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.h2, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(4);
         lds_barrier();
+        PHASE(5);
         conv_group<T>(wsl[2], buf1, w, a3h);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -541,7 +636,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             red[2 * w] = s1;
             red[2 * w + 1] = s2;
         }
+        PHASE(6);
         lds_barrier();
+        PHASE(7);
         float ts1 = 0.f, ts2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -566,9 +663,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][1][r] = v1 ? silu_f(a3h[si][1][r] * gw1[r] + gnb[cbase + d1 + r]) : 0.f;
             }
             store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
-            store_op<T>(ops.h4, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.h4, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(8);
         lds_barrier();
+        PHASE(9);
         conv_group<T>(wsl[3], buf2, w, a5);
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
@@ -579,38 +678,24 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][0][r] = silu_f(a5[si][0][r]);
                 ct[si][1][r] = v1 ? silu_f(a5[si][1][r]) : 0.f;
             }
-            store_op<T>(ops.h5, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.h5, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(10);
         // ---------------- backward ----------------
         // dh5 = W2[:, group]^T dy ; da5 = dh5 * silu'(a5) -> buf3
 #pragma unroll
         for (int si = 0; si < TF_NSW; ++si) {
-            ct[si][0] = F32X4_ZERO;
-            ct[si][1] = F32X4_ZERO;
-#pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) {
-                Frag<T> df;
-                if (tv[si]) frag_load(df, dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                else frag_zero(df);
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    Frag<T> a;
-                    lfrag<T>(a, wsl[4], half * 3 + ks);
-                    ct[si][half] = mma(a, df, ct[si][half]);
-                }
-            }
-        }
-#pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ct[si][0][r] *= dsilu_f(a5[si][0][r]);
-                ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a5[si][1][r]) : 0.f;
+                ct[si][0][r] = dh5[si][0][r] * dsilu_f(a5[si][0][r]);
+                ct[si][1][r] = v1 ? dh5[si][1][r] * dsilu_f(a5[si][1][r]) : 0.f;
             }
             store_rows<T>(buf3, tt[si], tv[si], ct[si][0], ct[si][1]);
-            store_op<T>(ops.da5, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.da5, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(11);
         lds_barrier();
+        PHASE(12);
         // dh4 = conv3^T(da5) ; dn3 = dh4 * silu'(n3) ; GroupNorm backward -> da3 -> buf2
         conv_group<T>(wsl[5], buf3, w, ct);
         float sa = 0.f, sb = 0.f;
@@ -646,12 +731,14 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         }
         sa = wave_sum64(sa);
         sb = wave_sum64(sb);
+        PHASE(13);
         lds_barrier();  // red is free again (everyone has read the forward statistics)
         if (lane == 0) {
             red[2 * w] = sa;
             red[2 * w + 1] = sb;
         }
         lds_barrier();
+        PHASE(14);
         float tsa = 0.f, tsb = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -668,9 +755,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][1][r] = v1 ? rstd * (gw1[r] * ct[si][1][r] - tsa - a3h[si][1][r] * tsb) : 0.f;
             }
             store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
-            store_op<T>(ops.da3, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.da3, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(15);
         lds_barrier();
+        PHASE(16);
         // dh2 = conv2^T(da3) ; da2 = dh2 * silu'(a2) -> buf1
         conv_group<T>(wsl[6], buf2, w, ct);
 #pragma unroll
@@ -681,9 +770,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a2[si][1][r]) : 0.f;
             }
             store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
-            store_op<T>(ops.da2, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.da2, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(17);
         lds_barrier();
+        PHASE(18);
         // dh1 = conv1^T(da2) ; da1 = dh1 * silu'(a1) ; du += W1[group]^T da1
         conv_group<T>(wsl[7], buf1, w, ct);
 #pragma unroll
@@ -693,14 +784,17 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][0][r] *= dsilu_f(a1[si][0][r]);
                 ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a1[si][1][r]) : 0.f;
             }
-            store_op<T>(ops.da1, n0 + tt[si], tv[si], cbase, ct[si][0], ct[si][1]);
+            store_op<T>(ops.da1, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
+        PHASE(19);
         lds_barrier();
+        PHASE(20);
     }
 
     // du = W1^T da1 over all FFN channels, from the [N][FFN] operand this workgroup has just written (the weight-gradient
     // kernel reads the same buffer): a full barrier makes the stores of the other waves visible (never-read lines: no stale L1)
     __syncthreads();
+    PHASE(21);
     f32x4 du[TF_NSW][TF_H / 16];
 #pragma unroll
     for (int si = 0; si < TF_NSW; ++si) {
@@ -708,7 +802,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         for (int mt = 0; mt < TF_H / 16; ++mt) du[si][mt] = F32X4_ZERO;
         for (int k6 = 0; k6 < TF_FFN / 32; ++k6) {
             Frag<T> df;
-            if (tv[si]) frag_load(df, ops.da1 + (n0 + tt[si]) * TF_FFN + k6 * 32 + 8 * g4);
+            const int ch = k6 * 32 + 8 * g4;  // 8-channel pieces never straddle a 24-channel group
+            if (tv[si]) frag_load(df, TF_OPS_GM(T) ? ops.da1 + ((size_t)(ch / TF_CG) * ntok + n0 + tt[si]) * TF_CG + ch % TF_CG
+                                                   : ops.da1 + (n0 + tt[si]) * TF_FFN + ch);
             else frag_zero(df);
 #pragma unroll
             for (int mt = 0; mt < TF_H / 16; ++mt) {
@@ -719,6 +815,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         }
     }
 
+    PHASE(22);
     // ---------------- LayerNorm backward + residual, in registers ----------------
     float dlw[TF_H / 16][4], dlb[TF_H / 16][4];
 #pragma unroll
@@ -788,16 +885,20 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 atomicAdd(aff + 2 * TF_FFN + TF_H + 16 * mt + 4 * g4 + r, b);
             }
         }
+    PHASE(23);
     lds_barrier();
     for (int i = tid; i < TF_AFF; i += blockDim.x) part[(size_t)blockIdx.x * TF_AFF + i] = aff[i];
+    PHASE(24);
+    PHASE_END();
 }
+PHASE_READER(nbss_phase_read_tconvffn_bwd)
 
 template <class T>
 static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                           float* stats, void* const* opsv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF + 2 * TF_H + 6 * TF_FFN) * sizeof(float) + (sizeof(T) == 2 ? (size_t)48 * 512 * sizeof(T) : 0);
+    const size_t lds = (size_t)4 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + TF_AFF + 2 * TF_H + 6 * TF_FFN) * sizeof(float) + (sizeof(T) == 2 ? (size_t)48 * 512 * sizeof(T) : 0) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
     TfOps<T> ops;
@@ -840,7 +941,10 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
+    const bool gm = c.dtype == NBSS_BF16;  // TF_OPS_GM: operands are [G][N][24]
+    const int ogw = gm ? TF_CG : 0, ogs = gm ? (int)(N * TF_CG) : 0;
     a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = ops[3]; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
+    a.b_gw = ogw; a.b_gs = ogs;
     a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
     if ((e = wgrad_launch(a, c.dtype, st))) return e;
     // the three grouped k=3 convs
@@ -849,11 +953,13 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     for (int k = 0; k < 3; ++k) {
         a.A = ops[convA[k]]; a.lda = TF_FFN; a.MA = TF_FFN; a.B = ops[convB[k]]; a.ldb = TF_FFN; a.NB = TF_FFN;
         a.groups = c.t_groups; a.taps = c.t_ks;
+        a.a_gw = ogw; a.a_gs = ogs; a.b_gw = ogw; a.b_gs = ogs;
         a.dW = G + param_off(c, layer, convW[k]); a.dbias = G + param_off(c, layer, convBias[k]);
         if ((e = wgrad_launch(a, c.dtype, st))) return e;
     }
     // W1: dW1[FFN][H] = da1^T LN(x) ; db1 = colsum(da1)
     a.A = ops[4]; a.lda = TF_FFN; a.MA = TF_FFN; a.B = x; a.ldb = TF_H; a.NB = TF_H; a.groups = 1; a.taps = 1;
+    a.a_gw = ogw; a.a_gs = ogs; a.b_gw = 0; a.b_gs = 0;
     a.stats = stats; a.gamma = lp.p[P_TF_LN_W]; a.beta = lp.p[P_TF_LN_B];
     a.dW = G + param_off(c, layer, P_TF_W1); a.dbias = G + param_off(c, layer, P_TF_B1);
     return wgrad_launch(a, c.dtype, st);

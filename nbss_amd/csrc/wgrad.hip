@@ -602,6 +602,7 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
     }
     // per-vector descriptors of this thread (chunk independent): chunk-relative row, global element offset, LDS offset
     int vkk[W3_MAXV], vgo[W3_MAXV], vdst[W3_MAXV];
+    const int rsA = a.a_gw ? a.a_gw : a.lda, rsB = a.b_gw ? a.b_gw : a.ldb;  // global row strides
     bool vA[W3_MAXV], vok[W3_MAXV];
 #pragma unroll
     for (int u = 0; u < W3_MAXV; ++u) {
@@ -609,11 +610,11 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
         vok[u] = v < nvec;
         vA[u] = v < nvA;
         if (vA[u]) {
-            const int k = v / pA, c8 = v % pA;
-            vkk[u] = k; vgo[u] = k * a.lda + acols0 + 8 * c8; vdst[u] = k * lda + 8 * c8;
+            const int k = v / pA, c8 = v % pA, col = acols0 + 8 * c8;
+            vkk[u] = k; vgo[u] = k * rsA + (a.a_gw ? (col / a.a_gw) * a.a_gs + col % a.a_gw : col); vdst[u] = k * lda + 8 * c8;
         } else {
-            const int v2 = vok[u] ? v - nvA : 0, j = v2 / pB, c8 = v2 % pB;
-            vkk[u] = j - h; vgo[u] = (j - h) * a.ldb + bcols0 + 8 * c8; vdst[u] = imgA + j * ldb + 8 * c8;
+            const int v2 = vok[u] ? v - nvA : 0, j = v2 / pB, c8 = v2 % pB, col = bcols0 + 8 * c8;
+            vkk[u] = j - h; vgo[u] = (j - h) * rsB + (a.b_gw ? (col / a.b_gw) * a.b_gs + col % a.b_gw : col); vdst[u] = imgA + j * ldb + 8 * c8;
         }
     }
     const int cpr = cdiv(a.T, W3_KC);
@@ -629,8 +630,8 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
         } else {
             nbase = (long)ch * W3_KC; lo = 0; lim = a.Ntok - (int)nbase;
         }
-        const T* Ab = Ag + nbase * a.lda;
-        const T* Bb = Bg + nbase * a.ldb;
+        const T* Ab = Ag + nbase * rsA;
+        const T* Bb = Bg + nbase * rsB;
         const float* sb = a.stats ? a.stats + 2 * nbase : nullptr;
 #pragma unroll
         for (int u = 0; u < W3_MAXV; ++u) {
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
                 float gm[8], bt[8];
-                const int col = vgo[u] - vkk[u] * a.ldb;
+                const int col = vgo[u] - vkk[u] * rsB;  // (LayerNorm operands are always plain row-major)
                 load8(lnp + col, gm);
                 load8(lnp + a.NB + col, bt);
 #pragma unroll
@@ -805,7 +806,8 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
         const size_t img3 = ((size_t)W3_KC * tr_ld(ncA) + (size_t)(W3_KC + 2 * h3) * tr_ld(ncB)) * 2;
         const int nvec3 = W3_KC * (ncA / 8) + (W3_KC + 2 * h3) * (ncB / 8);
         static const int nbuf3 = getenv("NBSS_WG_NBUF") ? atoi(getenv("NBSS_WG_NBUF")) : 2;
-        if ((a.taps == 1 || (a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0)) && nvec3 <= W3_MAXV * WG_THREADS &&
+        const bool gm_ok = (!a.a_gw || (a.a_gw % 8 == 0 && mg % a.a_gw == 0) || a.a_gw % mg == 0) && (!a.b_gw || !a.stats);
+        if (gm_ok && (a.taps == 1 || (a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0)) && nvec3 <= W3_MAXV * WG_THREADS &&
             nfirst3 <= WG_WAVES * W3_BS && nbuf3 * img3 + 2 * (size_t)a.NB * sizeof(float) <= (nbuf3 == 1 ? 80 : 158) * 1024) {
             const int nch3 = a.taps > 1 ? (a.Ntok / a.T) * cdiv(a.T, W3_KC) : cdiv(a.Ntok, W3_KC);
             int xb = (nbuf3 == 1 ? 512 : 256) / ybl;
@@ -831,6 +833,7 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             }
             return NBSS_OK;
         }
+        if (a.a_gw || a.b_gw) return NBSS_EUNSUPPORTED;  // group-major operands: wgrad_tr3_kernel only
         const size_t lds_tr = ((size_t)WG_KC * tr_ld(ncA) + (size_t)a.taps * WG_KC * tr_ld(ncB)) * 2;
         const int nvec = WG_KC * (ncA / 8) + a.taps * WG_KC * (ncB / 8);
         if (2 * lds_tr + 2 * (size_t)a.NB * sizeof(float) <= 158 * 1024 && nvec <= WG_MAXV * WG_THREADS) {  // double-buffered, register-prefetched variant
@@ -863,6 +866,7 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             return NBSS_CHECK_LAUNCH();
         }
     }
+    if (a.a_gw || a.b_gw) return NBSS_EUNSUPPORTED;
     int xbl = 384 / ybl;  // 1-2 resident workgroups (8-16 waves) per CU; every x-block ends with one atomicAdd per output element
     if (xbl < 16) xbl = 16;
     if (xbl > nchunks) xbl = nchunks;
