@@ -164,6 +164,15 @@ NBSS_DEV float load1(const bf16_t* p) { return bf2f(*p); }
 NBSS_DEV float round_to(float v, const float*) { return v; }
 NBSS_DEV float round_to(float v, const bf16_t*) { return bf2f(f2bf(v)); }
 
+NBSS_DEV void store8(float* p, const float (&o)[8]) {
+    store4(p, o[0], o[1], o[2], o[3]);
+    store4(p + 4, o[4], o[5], o[6], o[7]);
+}
+NBSS_DEV void store8(bf16_t* p, const float (&o)[8]) {  // one 16-byte store
+    u32x4 v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(p) = v;
+}
+
 // ---- MFMA fragments ---------------------------------------------------------------------
 template <class T> struct Frag;
 template <> struct Frag<bf16_t> { s16x8 v; };

@@ -13,6 +13,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include <cstdlib>
 
 #define FC_H 96
 #define FC_G 8
@@ -174,205 +175,281 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
 
 
 // ---------------------------------------------------------------------------------------------
-// Backward (data gradient): one workgroup = one (b,t) frame with the whole F axis in LDS.  Here a
-// wave owns frequency tiles (16 rows of F) and walks all 8 groups, so a lane ends up holding all 96
-// channels of "its" frequency (12g + 4(l>>4) + r, lanes 48..63 idle in the epilogues) and PReLU',
-// the transposed conv and the LayerNorm backward run without leaving registers.  The conv weight
-// gradient is contracted by wgrad.hip from dv (emitted here) and LN(x).
+// Backward (data gradient): one workgroup (8 waves) = one (b, TT frames) slab with the whole F axis in LDS.
+// The work alternates between two decompositions so that every global access is a 16-byte piece of a full row:
+//   row phases   (0, 3): a wave owns (frequency tile, frame) units in the B-fragment layout (lane = frequency row, 8 channels
+//                        per k-step): LayerNorm forward / backward, residual, x and dy stay in registers in between
+//   group phases (1, 2): wave g owns conv group g for ALL tiles, its 4 weight fragments (conv and transposed conv) live in
+//                        registers, operands come from the LDS images with the +-2 row halo
+// dv (for the conv weight gradient, wgrad.hip) is copied out of LDS as full rows.  The first version (one frame per 4-wave
+// workgroup, weights through LDS, per-group 8-byte global accesses, a per-thread serial LayerNorm) ran at 0.38 TB/s.
+#define FC_LD 104  // LDS row length: 208-byte rows put 16 consecutive rows on distinct 16-byte bank slots
+#define FC_BW 8    // waves per workgroup = conv groups
+
 template <class T>
-NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int f, int ch0, int ks) {
+NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int rstride, int f, int ch0, int ks) {
     const int g4 = lane_id() >> 4;
-    const int p0 = ks * 8 + 2 * g4, p1 = p0 + 1;
-    frag_load_lo(bq, u + (size_t)(f + p0 / 3) * FC_H + ch0 + (p0 % 3) * 4);
-    if (p1 < 15) frag_load_hi(bq, u + (size_t)(f + p1 / 3) * FC_H + ch0 + (p1 % 3) * 4);
+    const int p0 = ks * 8 + 2 * g4, p1 = p0 + 1;  // piece p -> tap p/3, channels (p%3)*4..+3 ; image row = f + tap
+    frag_load_lo(bq, u + (size_t)(f + p0 / 3) * rstride + ch0 + (p0 % 3) * 4);
+    if (p1 < 15) frag_load_hi(bq, u + (size_t)(f + p1 / 3) * rstride + ch0 + (p1 % 3) * 4);
     else frag_zero_hi(bq);
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                                        const float* __restrict__ cb, const float* __restrict__ slope, float* __restrict__ part,
-                                                        const T* __restrict__ Wp,
-                                                        const T* __restrict__ WpT, const T* __restrict__ x, const T* __restrict__ dy,
-                                                        T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout) {
+template <class T, int TT>
+__global__ __launch_bounds__(512, (sizeof(T) == 2 && TT == 1) ? 4 : 2)
+void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ cb,
+                      const float* __restrict__ slope, float* __restrict__ part, const T* __restrict__ Wp, const T* __restrict__ WpT,
+                      const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout) {
     NBSS_LDS(smem);
-    const int F = c.F, T_ = c.T;
-    const int b = blockIdx.x / T_, t = blockIdx.x % T_;
-    const int mtf = cdiv(F, 16), FP = mtf * 16 + 4;
-    T* u = reinterpret_cast<T*>(smem);       // [FP][H]  LN(x), rows f+2
-    T* dvb = u + (size_t)FP * FC_H;          // [FP][H]  dv, rows f+2
-    float* aff = reinterpret_cast<float*>(dvb + (size_t)FP * FC_H);  // [3H] LN weight | LN bias | PReLU slope gradient sums
-    T* wl = reinterpret_cast<T*>(aff + 3 * FC_H);  // conv and transposed-conv weight fragments (2 x 16), shared by the 4 waves
-    constexpr bool STAGE_W = sizeof(T) == 2;  // the fp32 stream has no LDS room left: it keeps reading the packed buffer
-    const T* wc = STAGE_W ? wl : Wp;
-    const T* wct = STAGE_W ? wl + 16 * 512 : WpT;
-    if (STAGE_W) {
-        constexpr int VNW = 16 / sizeof(T);
-        for (int v = threadIdx.x; v < 16 * 512 / VNW; v += blockDim.x) {
-            *reinterpret_cast<u32x4*>(wl + (size_t)v * VNW) = *reinterpret_cast<const u32x4*>(Wp + (size_t)v * VNW);
-            *reinterpret_cast<u32x4*>(wl + 16 * 512 + (size_t)v * VNW) = *reinterpret_cast<const u32x4*>(WpT + (size_t)v * VNW);
-        }
-    }
-    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
-    constexpr int VN = VecOf<T>::N;
-    constexpr int VPR = FC_H / VN;
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
-    const bool cvalid = g4 < 3;  // lanes 48..63 hold the 4 padding rows of every 12-channel group
+    const int F = c.F, T_ = c.T, ntt = cdiv(T_, TT);
+    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
+    const int mtf = cdiv(F, 16), FP = mtf * 16 + 4, ntile = mtf * TT;
+    constexpr int ROW = TT * FC_LD;  // elements per frequency row of an image
+    T* u = reinterpret_cast<T*>(smem);          // [FP][TT][LD]  LN(x) (phases 0-1), then du (phases 2-3); image row f+2
+    T* dvb = u + (size_t)FP * ROW;               // [FP][TT][LD]  dy (phase 0), then dv in place
+    float* aff = reinterpret_cast<float*>(dvb + (size_t)FP * ROW);  // [3H] LN weight | LN bias | PReLU slope gradient sums
+    float* lnp = aff + 3 * FC_H;                 // [2H] gamma | beta
+    PHASE_BEGIN(lnp + 2 * FC_H);
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
 
-    for (int i = tid; i < FP * VPR; i += nthr) {
-        const int rr = i / VPR, off = (i % VPR) * VN, f = rr - 2;
-        if (f >= 0 && f < F) vec_copy(u + (size_t)rr * FC_H + off, x + (((size_t)b * F + f) * T_ + t) * FC_H + off);
-        else vec_zero(u + (size_t)rr * FC_H + off);
-        vec_zero(dvb + (size_t)rr * FC_H + off);
-    }
-    lds_barrier();
-    for (int f = tid; f < F; f += nthr) ln_row_inplace(u + (size_t)(f + 2) * FC_H, lnw, lnb);
-    lds_barrier();
-
-    float dsl[FC_G][4];
+    Frag<T> af[FC_KS], at[FC_KS];
 #pragma unroll
-    for (int g = 0; g < FC_G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dsl[g][r] = 0.f;
+    for (int ks = 0; ks < FC_KS; ++ks) {
+        wfrag_load(af[ks], Wp, w, FC_KS, ks);
+        wfrag_load(at[ks], WpT, w, FC_KS, ks);
+    }
+    for (int i = tid; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
+    for (int i = tid; i < 2 * FC_H; i += blockDim.x) lnp[i] = i < FC_H ? lnw[i] : lnb[i - FC_H];
+    for (int i = tid; i < 4 * ROW; i += blockDim.x) {  // halo rows (f = -2, -1, 16 mtf, 16 mtf + 1) of both images
+        const int hr = i / ROW, rr = hr < 2 ? hr : mtf * 16 + hr, off = i % ROW;
+        store1(u + (size_t)rr * ROW + off, 0.f);
+        store1(dvb + (size_t)rr * ROW + off, 0.f);
+    }
 
-    // ---- conv forward recompute, PReLU', dv ----
-    for (int ft = w; ft < mtf; ft += nw) {
-        const int f = ft * 16 + l15;
-        const bool fvalid = f < F;
+    // ---- phase 0 (rows): x, dy -> registers; LayerNorm -> u; dy -> dvb; row statistics out ----
+    // A wave keeps x, dy and the statistics of its FIRST unit in registers until phase 3; further units (F = 129 leaves one
+    // frequency row for a ninth tile) are re-read from global there, so the register footprint is that of one unit.
+    auto row_load = [&](int ti, Frag<T> (&xq)[BK_KS], Frag<T> (&dq)[BK_KS]) {
+        const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15, t = t0 + tt;
+        const bool valid = f < F && t < T_;
         const size_t n = ((size_t)b * F + f) * T_ + t;
 #pragma unroll
-        for (int g = 0; g < FC_G; ++g) {
-            f32x4 acc = F32X4_ZERO;
-#pragma unroll
-            for (int ks = 0; ks < FC_KS; ++ks) {
-                Frag<T> a, bq;
-                wfrag_load(a, wc, g, FC_KS, ks);
-                fconv_bfrag<T>(bq, u, f, g * FC_CG, ks);
-                acc = mma(a, bq, acc);
-            }
-            if (fvalid && cvalid) {
-                const int ch = g * FC_CG + 4 * g4;
-                float dyv[4], dv[4];
-                load4(dy + n * FC_H + ch, dyv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[r] + cb[ch + r];
-                    dv[r] = v > 0.f ? dyv[r] : slope[ch + r] * dyv[r];
-                    if (v <= 0.f) dsl[g][r] += dyv[r] * v;
-                }
-                store4(dvb + (size_t)(f + 2) * FC_H + ch, dv[0], dv[1], dv[2], dv[3]);
-                store4(dvout + n * FC_H + ch, dv[0], dv[1], dv[2], dv[3]);
+        for (int ks = 0; ks < BK_KS; ++ks) {
+            if (valid) {
+                frag_load(xq[ks], x + n * FC_H + ks * 32 + 8 * g4);
+                frag_load(dq[ks], dy + n * FC_H + ks * 32 + 8 * g4);
+            } else {
+                frag_zero(xq[ks]);
+                frag_zero(dq[ks]);
             }
         }
-    }
-    lds_barrier();
-
-    // ---- transposed conv -> du, LayerNorm backward, residual ----
-    float dlw[FC_G][4], dlb[FC_G][4];
-#pragma unroll
-    for (int g = 0; g < FC_G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dlw[g][r] = dlb[g][r] = 0.f;
-    for (int ft = w; ft < mtf; ft += nw) {
-        const int f = ft * 16 + l15;
-        const bool valid = f < F && cvalid;
-        const size_t n = ((size_t)b * F + f) * T_ + t;
-        f32x4 du[FC_G];
-#pragma unroll
-        for (int g = 0; g < FC_G; ++g) {
-            f32x4 acc = F32X4_ZERO;
-#pragma unroll
-            for (int ks = 0; ks < FC_KS; ++ks) {
-                Frag<T> a, bq;
-                wfrag_load(a, wct, g, FC_KS, ks);
-                fconv_bfrag<T>(bq, dvb, f, g * FC_CG, ks);
-                acc = mma(a, bq, acc);
-            }
-            du[g] = acc;
-        }
-        float xv[FC_G][4];
+    };
+    auto row_stats = [&](const Frag<T> (&xq)[BK_KS], float& mean, float& rstd) {
         float sum = 0.f;
 #pragma unroll
-        for (int g = 0; g < FC_G; ++g) {
-            if (valid) load4(x + n * FC_H + g * FC_CG + 4 * g4, xv[g]);
-            else xv[g][0] = xv[g][1] = xv[g][2] = xv[g][3] = 0.f;
+        for (int ks = 0; ks < BK_KS; ++ks)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum += xv[g][r];
-        }
-        const float mean = wave_sum16(sum) * (1.0f / FC_H);
+            for (int j = 0; j < 8; ++j) sum += frag_get(xq[ks], j);
+        mean = wave_sum16(sum) * (1.0f / FC_H);
         float q = 0.f;
 #pragma unroll
-        for (int g = 0; g < FC_G; ++g)
+        for (int ks = 0; ks < BK_KS; ++ks)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xv[g][r] = valid ? xv[g][r] - mean : 0.f;
-                q += xv[g][r] * xv[g][r];
+            for (int j = 0; j < 8; ++j) {
+                const float d = frag_get(xq[ks], j) - mean;
+                q += d * d;
             }
-        const float rstd = rsqrtf(wave_sum16(q) * (1.0f / FC_H) + 1e-5f);
-        if (f < F && g4 == 0) {
+        rstd = rsqrtf(wave_sum16(q) * (1.0f / FC_H) + 1e-5f);
+    };
+    auto row_fwd = [&](int ti, const Frag<T> (&xq)[BK_KS], const Frag<T> (&dq)[BK_KS], float mean, float rstd) {
+        const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15, t = t0 + tt;
+        const bool valid = f < F && t < T_;
+        if (valid && g4 == 0) {
+            const size_t n = ((size_t)b * F + f) * T_ + t;
             stats[n * 2] = mean;
             stats[n * 2 + 1] = rstd;
         }
-        float m1 = 0.f, m2 = 0.f;
+        T* ur = u + (size_t)(f + 2) * ROW + tt * FC_LD;
+        T* dr_ = dvb + (size_t)(f + 2) * ROW + tt * FC_LD;
 #pragma unroll
-        for (int g = 0; g < FC_G; ++g)
+        for (int ks = 0; ks < BK_KS; ++ks) {
+            const int c0 = ks * 32 + 8 * g4;
+            float gm[8], bt[8], o[8], d[8];
+            load8(lnp + c0, gm);
+            load8(lnp + FC_H + c0, bt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = valid ? (frag_get(xq[ks], j) - mean) * rstd * gm[j] + bt[j] : 0.f;
+                d[j] = frag_get(dq[ks], j);
+            }
+            store8(ur + c0, o);
+            store8(dr_ + c0, d);
+        }
+    };
+    Frag<T> xr[BK_KS], dr[BK_KS];
+    float rmean = 0.f, rrstd = 0.f;
+    if (w < ntile) row_load(w, xr, dr);
+    lds_barrier();  // lnp
+    if (w < ntile) {
+        row_stats(xr, rmean, rrstd);
+        row_fwd(w, xr, dr, rmean, rrstd);
+    }
+    for (int ti = w + FC_BW; ti < ntile; ti += FC_BW) {
+        Frag<T> xq[BK_KS], dq[BK_KS];
+        float mean, rstd;
+        row_load(ti, xq, dq);
+        row_stats(xq, mean, rstd);
+        row_fwd(ti, xq, dq, mean, rstd);
+    }
+    PHASE(0);
+    lds_barrier();
+    PHASE(1);
+
+    // ---- phase 1 (groups): conv forward recompute, PReLU', dv in place of dy ----
+    const int ch = w * FC_CG + 4 * g4;  // this lane's 4 channels of group w (g4 == 3: padding rows)
+    const bool cvalid = g4 < 3;
+    float cbv[4] = {0.f, 0.f, 0.f, 0.f}, slv[4] = {0.f, 0.f, 0.f, 0.f}, dsl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cvalid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cbv[r] = cb[ch + r]; slv[r] = slope[ch + r]; }
+    }
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15;
+        f32x4 acc = F32X4_ZERO;
+#pragma unroll
+        for (int ks = 0; ks < FC_KS; ++ks) {
+            Frag<T> bq;
+            fconv_bfrag<T>(bq, u + tt * FC_LD, ROW, f, w * FC_CG, ks);
+            acc = mma(af[ks], bq, acc);
+        }
+        if (cvalid) {
+            T* pd = dvb + (size_t)(f + 2) * ROW + tt * FC_LD + ch;
+            float dyv[4], dv[4];
+            load4(pd, dyv);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                xv[g][r] *= rstd;
-                const float dv = valid ? du[g][r] : 0.f;
-                dlw[g][r] += dv * xv[g][r];
-                dlb[g][r] += dv;
-                du[g][r] = valid ? dv * lnw[g * FC_CG + 4 * g4 + r] : 0.f;
-                m1 += du[g][r];
-                m2 += du[g][r] * xv[g][r];
+                const float v = acc[r] + cbv[r];
+                dv[r] = v > 0.f ? dyv[r] : slv[r] * dyv[r];
+                if (v <= 0.f) dsl[r] += dyv[r] * v;
             }
+            store4(pd, dv[0], dv[1], dv[2], dv[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float s2 = row_sum16(dsl[r]);
+        if (l15 == 0 && cvalid) atomicAdd(aff + 2 * FC_H + ch + r, s2);
+    }
+    PHASE(2);
+    lds_barrier();
+    PHASE(3);
+
+    // ---- phase 2 (groups): transposed conv -> du into the u image; dv rows -> global ----
+    for (int ti = 0; ti < ntile; ++ti) {
+        const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15;
+        f32x4 acc = F32X4_ZERO;
+#pragma unroll
+        for (int ks = 0; ks < FC_KS; ++ks) {
+            Frag<T> bq;
+            fconv_bfrag<T>(bq, dvb + tt * FC_LD, ROW, f, w * FC_CG, ks);
+            acc = mma(at[ks], bq, acc);
+        }
+        if (cvalid) store4(u + (size_t)(f + 2) * ROW + tt * FC_LD + ch, acc[0], acc[1], acc[2], acc[3]);
+    }
+    {
+        constexpr int VN = VecOf<T>::N, VPR = FC_H / VN;
+        for (int i = tid; i < F * TT * VPR; i += blockDim.x) {
+            const int f = i / (TT * VPR), rem = i % (TT * VPR), tt = rem / VPR, off = (rem % VPR) * VN;
+            if (t0 + tt < T_) vec_copy(dvout + (((size_t)b * F + f) * T_ + t0 + tt) * FC_H + off, dvb + (size_t)(f + 2) * ROW + tt * FC_LD + off);
+        }
+    }
+    PHASE(4);
+    lds_barrier();
+    PHASE(5);
+
+    // ---- phase 3 (rows): LayerNorm backward + residual from registers (x, dy) and the du image ----
+    // two sweeps over the row (sums, then outputs) that re-read du from LDS instead of keeping 48 intermediates alive: the
+    // kernel has to stay under 128 VGPRs for two workgroups per CU
+    auto row_bwd = [&](int ti, const Frag<T> (&xq)[BK_KS], const Frag<T> (&dq)[BK_KS], float mean, float rstd0) {
+        const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15, t = t0 + tt;
+        const bool valid = f < F && t < T_;
+        const size_t n = ((size_t)b * F + f) * T_ + t;
+        const T* ur = u + (size_t)(f + 2) * ROW + tt * FC_LD;
+        const float rstd = valid ? rstd0 : 0.f;
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < BK_KS; ++ks) {
+            const int c0 = ks * 32 + 8 * g4;
+            float duv[8], gm[8];
+            load8(ur + c0, duv);
+            load8(lnp + c0, gm);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dv = valid ? duv[j] : 0.f;
+                const float xh = (frag_get(xq[ks], j) - mean) * rstd;
+                const float a = row_sum16(dv * xh), bb = row_sum16(dv);
+                if (l15 == 0) {
+                    atomicAdd(aff + c0 + j, a);
+                    atomicAdd(aff + FC_H + c0 + j, bb);
+                }
+                m1 += dv * gm[j];
+                m2 += dv * gm[j] * xh;
+            }
+        }
         m1 = wave_sum16(m1) * (1.0f / FC_H);
         m2 = wave_sum16(m2) * (1.0f / FC_H);
         if (valid) {
 #pragma unroll
-            for (int g = 0; g < FC_G; ++g) {
-                const int ch = g * FC_CG + 4 * g4;
-                float dyv[4], o[4];
-                load4(dy + n * FC_H + ch, dyv);
+            for (int ks = 0; ks < BK_KS; ++ks) {
+                const int c0 = ks * 32 + 8 * g4;
+                float duv[8], gm[8], o[8];
+                load8(ur + c0, duv);
+                load8(lnp + c0, gm);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = dyv[r] + rstd * (du[g][r] - m1 - xv[g][r] * m2);
-                store4(dx + n * FC_H + ch, o[0], o[1], o[2], o[3]);
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (frag_get(xq[ks], j) - mean) * rstd;
+                    o[j] = frag_get(dq[ks], j) + rstd * (duv[j] * gm[j] - m1 - xh * m2);
+                }
+                store8(dx + n * FC_H + c0, o);
             }
         }
+    };
+    if (w < ntile) row_bwd(w, xr, dr, rmean, rrstd);
+    for (int ti = w + FC_BW; ti < ntile; ti += FC_BW) {
+        Frag<T> xq[BK_KS], dq[BK_KS];
+        float mean, rstd;
+        row_load(ti, xq, dq);
+        row_stats(xq, mean, rstd);
+        row_bwd(ti, xq, dq, mean, rstd);
     }
-#pragma unroll
-    for (int g = 0; g < FC_G; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = sum_l15_(dlw[g][r]), bb = sum_l15_(dlb[g][r]), s2 = sum_l15_(dsl[g][r]);
-            if (l15 == 0 && cvalid) {
-                const int ch = g * FC_CG + 4 * g4 + r;
-                atomicAdd(aff + ch, a);
-                atomicAdd(aff + FC_H + ch, bb);
-                atomicAdd(aff + 2 * FC_H + ch, s2);
-            }
-        }
+    PHASE(6);
     lds_barrier();
     for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) part[(size_t)blockIdx.x * 3 * FC_H + i] = aff[i];
+    PHASE(7);
+    PHASE_END();
 }
+PHASE_READER(nbss_phase_read_fconv_bwd)
 
-template <class T>
+template <class T, int TT>
 static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                        float* stats, void* dv, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (mtf * 16 + 4) * FC_H * sizeof(T) + 3 * FC_H * sizeof(float) + (sizeof(T) == 2 ? (size_t)32 * 512 * sizeof(T) : 0);
+    const size_t lds = (size_t)2 * (mtf * 16 + 4) * TT * FC_LD * sizeof(T) + 5 * FC_H * sizeof(float) + PHASE_LDS_BYTES;
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T>), lds);
+    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T, TT>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.T), block(256);
+    dim3 grid(c.B * cdiv(c.T, TT)), block(512);
     ProfScope ps(PK_FCONV_B, st);
-    NBSS_LAUNCH((fconv_bwd_kernel<T>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
+    NBSS_LAUNCH((fconv_bwd_kernel<T, TT>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
                 P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), part, pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
                 pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv);
     return NBSS_CHECK_LAUNCH();
 }
+
+#define FC_BWD_TT 2  // frames per workgroup of the bf16 backward (measured: 2 frames, one workgroup per CU beats 1 frame, two per CU by 2.2x in wave time)
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                    void* ws, hipStream_t st) {
@@ -380,15 +457,18 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     float* stats = (float*)ws;
     void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    int e = c.dtype == NBSS_BF16 ? fconv_bwd_t<bf16_t>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-                                 : fconv_bwd_t<float>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
+    static const int tt_bf16 = getenv("NBSS_FCONV_BWD_TT") ? atoi(getenv("NBSS_FCONV_BWD_TT")) : FC_BWD_TT;
+    int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : tt_bf16 == 2       ? fconv_bwd_t<bf16_t, 2>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+                                 : fconv_bwd_t<bf16_t, 1>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
     if (e) return e;
+    const int nwg = c.dtype == NBSS_BF16 ? c.B * cdiv(c.T, tt_bf16 == 2 ? 2 : 1) : c.B * c.T;
     AffSegs sg;
     sg.n = 3;
     sg.off[0] = param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); sg.cnt[0] = FC_H;
     sg.off[1] = param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B); sg.cnt[1] = FC_H;
     sg.off[2] = param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU); sg.cnt[2] = FC_H;
-    if ((e = affine_reduce_launch(part, c.B * c.T, sg, G, st))) return e;
+    if ((e = affine_reduce_launch(part, nwg, sg, G, st))) return e;
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));

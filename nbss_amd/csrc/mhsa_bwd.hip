@@ -98,6 +98,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     float* Dds = lis + tp;
     float* aff = Dds + tp;  // [2H] per-workgroup LN weight | bias gradient sums
     float* lnp = aff + 2 * MB_H;  // [2H] LayerNorm gamma | beta
+    PHASE_BEGIN(lnp + 2 * MB_H + 16);
     for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) aff[i] = 0.f;
     const int bf = blockIdx.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / MB_H) + 1e-5f);
     }
     lds_barrier();  // lnp is read below
+    PHASE(0);
 
     for (int head = 0; head < MB_HEADS; ++head) {
         Frag<T> qf[MB_NSW], dof[MB_NSW];
@@ -232,8 +234,10 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                     if (g4 == 0) Dds[t] = Dv[si];
                 }
             }
+            PHASE(1 + which);
         }
         lds_barrier();
+        PHASE(5);
 
         // ---------------- pass 1: query strips -> dQ ----------------
 #pragma unroll
@@ -306,7 +310,9 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
             }
             if (tv[si]) store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + head * MB_DH, dq[0], dq[1]);
         }
+        PHASE(6);
         lds_barrier();
+        PHASE(7);
 
         // ---------------- pass 2: key strips -> dK, dV ----------------
 #pragma unroll
@@ -363,12 +369,15 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + 2 * MB_H + head * MB_DH, dv[0], dv[1]);
             }
         }
+        PHASE(8);
         lds_barrier();
+        PHASE(9);
     }
 
     // du = Win^T dqkv from the [N][3H] operand this workgroup has just written (full barrier: the other waves' stores are
     // complete, and these lines were never read before, so no stale L1 copies exist)
     __syncthreads();
+    PHASE(10);
     f32x4 du[MB_NSW][BK_MT];
 #pragma unroll
     for (int si = 0; si < MB_NSW; ++si) {
@@ -387,6 +396,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         }
     }
 
+    PHASE(11);
     // ---------------- LayerNorm backward + residual ----------------
     float dlw[BK_MT][4], dlb[BK_MT][4];
 #pragma unroll
@@ -400,8 +410,11 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     }
     ln_affine_flush(dlw, dlb, aff, aff + MB_H);
     lds_barrier();
+    PHASE(12);
     for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) part[(size_t)blockIdx.x * 2 * MB_H + i] = aff[i];
+    PHASE_END();
 }
+PHASE_READER(nbss_phase_read_mhsa_bwd)
 
 template <class T>
 static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, const void* osave,
@@ -409,7 +422,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int tp = cdiv(c.T, 16) * 16;
     if (tp > 256) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64;
+    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
