@@ -98,7 +98,16 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     float* Dds = lis + tp;
     float* aff = Dds + tp;  // [2H] per-workgroup LN weight | bias gradient sums
     float* lnp = aff + 2 * MB_H;  // [2H] LayerNorm gamma | beta
-    PHASE_BEGIN(lnp + 2 * MB_H + 16);
+    // bf16: every weight fragment of the module lives in LDS for the whole kernel (in_proj 72 + out_proj^T 24 fragments, 96 KB;
+    // replaced by the 54 fragments of in_proj^T for the du phase) — per-wave global fragment reads sat behind the dqkv stores
+    T* wl = reinterpret_cast<T*>(lnp + 2 * MB_H);
+    constexpr int WL_FR = TR ? 96 : 0;
+    PHASE_BEGIN(wl + (size_t)WL_FR * 512);
+    const size_t ntok = (size_t)c.B * c.F * T_;
+    if (TR) {
+        for (int v = threadIdx.x; v < 72 * 64; v += blockDim.x) reinterpret_cast<u32x4*>(wl)[v] = reinterpret_cast<const u32x4*>(Win)[v];
+        for (int v = threadIdx.x; v < 24 * 64; v += blockDim.x) reinterpret_cast<u32x4*>(wl + 72 * 512)[v] = reinterpret_cast<const u32x4*>(WoutT)[v];
+    }
     for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) aff[i] = 0.f;
     const int bf = blockIdx.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -146,10 +155,48 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     lds_barrier();  // lnp is read below
     PHASE(0);
 
+    // dqkv operand of the in_proj weight gradient.  bf16: group-major [12 (q|k|v x head)][N][24], a strip writes 768 contiguous
+    // bytes (48-byte pieces of 576-byte token rows were partial-line writes); fp32: token-major [N][3H]
+    auto dqkv_row = [&](int grp, size_t n) -> T* {
+        return TR ? dqkv + ((size_t)grp * ntok + n) * MB_DH : dqkv + n * (3 * MB_H) + grp * MB_DH;
+    };
     for (int head = 0; head < MB_HEADS; ++head) {
         Frag<T> qf[MB_NSW], dof[MB_NSW];
         float Dv[MB_NSW];
         // ---------------- stage A: Q', K, V, dO of this head ----------------
+        // all global reads of the head first (x, dy, saved O), ahead of this head's dqkv stores in the vmcnt queue
+        Frag<T> uf[MB_NSW][MB_KS], dr[MB_NSW][MB_KS];
+        float o0[MB_NSW][4], o1[MB_NSW][4];
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                if (tv[si]) {
+                    frag_load(uf[si][ks], xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
+                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
+                } else {
+                    frag_zero(uf[si][ks]);
+                    frag_zero(dr[si][ks]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o0[si][r] = o1[si][r] = 0.f;
+            if (tv[si]) {
+                load4(ob + (size_t)tt[si] * MB_H + head * MB_DH + 4 * g4, o0[si]);
+                if (g4 < 2) load4(ob + (size_t)tt[si] * MB_H + head * MB_DH + 16 + 4 * g4, o1[si]);
+            }
+        }
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si)
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {  // LN(x) in place of x (rebuilt per head from the row statistics)
+                float gm[8], bt[8];
+                load8(lnp + ks * 32 + 8 * g4, gm);
+                load8(lnp + MB_H + ks * 32 + 8 * g4, bt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    frag_set(uf[si][ks], j, tv[si] ? (frag_get(uf[si][ks], j) - smean[si]) * srstd[si] * gm[j] + bt[j] : bt[j]);
+            }
 #pragma unroll
         for (int which = 0; which < 4; ++which) {  // 0 q, 1 k, 2 v, 3 dO
             f32x4 ct[MB_NSW][2];
@@ -160,31 +207,16 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 Frag<T> a[2];
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    if (which < 3) wfrag_load(a[half], Win, (which * MB_HEADS + head) * 2 + half, MB_KS, ks);
+                    const int fi = which < 3 ? ((which * MB_HEADS + head) * 2 + half) * MB_KS + ks : 72 + (head * 2 + half) * MB_KS + ks;
+                    if (TR) frag_load(a[half], wl + ((size_t)fi * 64 + lane) * 8);
+                    else if (which < 3) wfrag_load(a[half], Win, (which * MB_HEADS + head) * 2 + half, MB_KS, ks);
                     else wfrag_load(a[half], WoutT, head * 2 + half, MB_KS, ks);
                 }
 #pragma unroll
                 for (int si = 0; si < MB_NSW; ++si) {
                     if (!sact[si]) continue;
-                    Frag<T> opf;
-                    const int c0 = ks * 32 + 8 * g4;
-                    if (which < 3) {  // LN(x), rebuilt from x + row statistics + gamma|beta in LDS
-                        float v[8], gm[8], bt[8];
-                        if (tv[si]) load8(xb + (size_t)tt[si] * MB_H + c0, v);
-                        else
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-                        load8(lnp + c0, gm);
-                        load8(lnp + MB_H + c0, bt);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) frag_set(opf, j, (v[j] - smean[si]) * srstd[si] * gm[j] + bt[j]);
-                    } else if (tv[si]) {
-                        frag_load(opf, dyb + (size_t)tt[si] * MB_H + c0);
-                    } else {
-                        frag_zero(opf);
-                    }
-                    ct[si][0] = mma(a[0], opf, ct[si][0]);
-                    ct[si][1] = mma(a[1], opf, ct[si][1]);
+                    ct[si][0] = mma(a[0], which < 3 ? uf[si][ks] : dr[si][ks], ct[si][0]);
+                    ct[si][1] = mma(a[1], which < 3 ? uf[si][ks] : dr[si][ks], ct[si][1]);
                 }
             }
             float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -222,14 +254,9 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                     store_row24<T>(dOr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
                     if (!TR) store_col24<T>(dOt, tp, t, ct[si][0], ct[si][1]);
                     // D = rowsum(dO * O) with the saved forward attention output
-                    float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (tv[si]) {
-                        load4(ob + (size_t)t * MB_H + head * MB_DH + 4 * g4, o0);
-                        if (g4 < 2) load4(ob + (size_t)t * MB_H + head * MB_DH + 16 + 4 * g4, o1);
-                    }
                     float dsum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dsum += round_to(ct[si][0][r], x) * o0[r] + round_to(ct[si][1][r], x) * o1[r];
+                    for (int r = 0; r < 4; ++r) dsum += round_to(ct[si][0][r], x) * o0[si][r] + round_to(ct[si][1][r], x) * o1[si][r];
                     Dv[si] = wave_sum16(dsum);
                     if (g4 == 0) Dds[t] = Dv[si];
                 }
@@ -308,7 +335,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 dq[0][r] *= rs_dh;
                 dq[1][r] *= rs_dh;
             }
-            if (tv[si]) store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + head * MB_DH, dq[0], dq[1]);
+            if (tv[si]) store_row24<T>(dqkv_row(0 * MB_HEADS + head, n0 + tt[si]), dq[0], dq[1]);
         }
         PHASE(6);
         lds_barrier();
@@ -365,8 +392,8 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 dk[1][r] *= 0.6931471805599453f;
             }
             if (tv[si]) {
-                store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + MB_H + head * MB_DH, dk[0], dk[1]);
-                store_row24<T>(dqkv + (n0 + tt[si]) * (3 * MB_H) + 2 * MB_H + head * MB_DH, dv[0], dv[1]);
+                store_row24<T>(dqkv_row(1 * MB_HEADS + head, n0 + tt[si]), dk[0], dk[1]);
+                store_row24<T>(dqkv_row(2 * MB_HEADS + head, n0 + tt[si]), dv[0], dv[1]);
             }
         }
         PHASE(8);
@@ -378,20 +405,30 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     // complete, and these lines were never read before, so no stale L1 copies exist)
     __syncthreads();
     PHASE(10);
+    if (TR) {  // in_proj^T fragments (54) replace the forward weights in LDS; everyone is past the head loop
+        for (int v = threadIdx.x; v < 54 * 64; v += blockDim.x) reinterpret_cast<u32x4*>(wl)[v] = reinterpret_cast<const u32x4*>(WinT)[v];
+        lds_barrier();
+    }
     f32x4 du[MB_NSW][BK_MT];
 #pragma unroll
     for (int si = 0; si < MB_NSW; ++si) {
 #pragma unroll
         for (int mt = 0; mt < BK_MT; ++mt) du[si][mt] = F32X4_ZERO;
+        Frag<T> df[3 * MB_H / 32];
+#pragma unroll
+        for (int k9 = 0; k9 < 3 * MB_H / 32; ++k9) {  // all nine loads in flight together
+            const int ch = k9 * 32 + 8 * g4;  // 8-channel pieces never straddle a 24-channel group
+            if (tv[si]) frag_load(df[k9], dqkv_row(ch / MB_DH, n0 + tt[si]) + ch % MB_DH);
+            else frag_zero(df[k9]);
+        }
+#pragma unroll
         for (int k9 = 0; k9 < 3 * MB_H / 32; ++k9) {
-            Frag<T> df;
-            if (tv[si]) frag_load(df, dqkv + (n0 + tt[si]) * (3 * MB_H) + k9 * 32 + 8 * g4);
-            else frag_zero(df);
 #pragma unroll
             for (int mt = 0; mt < BK_MT; ++mt) {
                 Frag<T> a;
-                wfrag_load(a, WinT, mt, 3 * MB_H / 32, k9);
-                du[si][mt] = mma(a, df, du[si][mt]);
+                if (TR) frag_load(a, wl + ((size_t)(mt * (3 * MB_H / 32) + k9) * 64 + lane) * 8);
+                else wfrag_load(a, WinT, mt, 3 * MB_H / 32, k9);
+                du[si][mt] = mma(a, df[k9], du[si][mt]);
             }
         }
     }
@@ -422,7 +459,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int tp = cdiv(c.T, 16) * 16;
     if (tp > 256) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + PHASE_LDS_BYTES;
+    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + (sizeof(T) == 2 ? (size_t)96 * 512 * sizeof(T) : 0) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
@@ -460,6 +497,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     if ((e = wgrad_launch(a, c.dtype, st))) return e;
     // in_proj: dWin[3H][H] = dqkv^T LN(x) ; dbin = colsum(dqkv)
     a.A = dqkv; a.lda = 3 * MB_H; a.MA = 3 * MB_H; a.B = x; a.ldb = MB_H; a.NB = MB_H;
+    if (c.dtype == NBSS_BF16) { a.a_gw = MB_DH; a.a_gs = (int)(N * MB_DH); }  // group-major dqkv
     a.stats = stats; a.gamma = lp.p[P_MH_LN_W]; a.beta = lp.p[P_MH_LN_B];
     a.dW = G + param_off(c, layer, P_INP_W); a.dbias = G + param_off(c, layer, P_INP_B);
     return wgrad_launch(a, c.dtype, st);
