@@ -299,10 +299,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 }
             sum = wave_sum16(sum);
             const float inv = 1.0f / sum;
-            if (g4 == 0) {
-                m2s[tt[si]] = mx;
-                lis[tt[si]] = inv;
-            }
+            if (g4 == 0) m2s[tt[si]] = tv[si] ? mx + log2f(sum) : 1e30f;  // p = exp2(s - (m + log2 l)); padding frames: p = 0
 #pragma unroll
             for (int j = 0; j < MB_NT; ++j) {
                 if (j < nst) {
@@ -342,58 +339,81 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         PHASE(7);
 
         // ---------------- pass 2: key strips -> dK, dV ----------------
+        // The query-side operands of a tile pair (Q', dO rows, their transposes, the row statistics) are fetched once and used
+        // for both key strips of the wave: 22 LDS instructions per pair instead of 80.
+        {
+            Frag<T> kf[MB_NSW], vf[MB_NSW];
+            f32x4 dk[MB_NSW][2], dv[MB_NSW][2];
 #pragma unroll
-        for (int si = 0; si < MB_NSW; ++si) {
-            if (!sact[si]) continue;
-            Frag<T> kf, vf;
-            row_pieces<T>(kf, Kr + (size_t)tt[si] * MB_DH);
-            row_pieces<T>(vf, Vr + (size_t)tt[si] * MB_DH);
-            f32x4 dk[2] = {F32X4_ZERO, F32X4_ZERO}, dv[2] = {F32X4_ZERO, F32X4_ZERO};
+            for (int si = 0; si < MB_NSW; ++si) {
+                row_pieces<T>(kf[si], Kr + (size_t)tt[si] * MB_DH);
+                row_pieces<T>(vf[si], Vr + (size_t)tt[si] * MB_DH);
+                dk[si][0] = dk[si][1] = dv[si][0] = dv[si][1] = F32X4_ZERO;
+            }
             for (int jp = 0; jp < nkp; ++jp) {
-                f32x4 pt[2], dst[2];
+                Frag<T> qa[2], doa[2], aq[2], ado[2];
+                f32x4 mls[2], ddv[2];
+                const bool hi_valid = 2 * jp + 1 < nst;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int jj = 2 * jp + e;
                     if (jj < nst) {
-                        Frag<T> qa, doa;
-                        row_pieces<T>(qa, Qr + (size_t)(jj * 16 + l15) * MB_DH);
-                        row_pieces<T>(doa, dOr + (size_t)(jj * 16 + l15) * MB_DH);
-                        const f32x4 s = mma(qa, kf, F32X4_ZERO);
-                        const f32x4 dp = mma(doa, vf, F32X4_ZERO);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int tq = jj * 16 + 4 * g4 + r;
-                            const float p = (tq < T_ && tv[si]) ? exp2f(s[r] - m2s[tq]) * lis[tq] : 0.f;
-                            pt[e][r] = p;
-                            dst[e][r] = p * (dp[r] - Dds[tq]);
-                        }
+                        row_pieces<T>(qa[e], Qr + (size_t)(jj * 16 + l15) * MB_DH);
+                        row_pieces<T>(doa[e], dOr + (size_t)(jj * 16 + l15) * MB_DH);
+                        mls[e] = *reinterpret_cast<const f32x4*>(m2s + jj * 16 + 4 * g4);
+                        ddv[e] = *reinterpret_cast<const f32x4*>(Dds + jj * 16 + 4 * g4);
                     } else {
-                        pt[e] = F32X4_ZERO;
-                        dst[e] = F32X4_ZERO;
+                        frag_zero(qa[e]);
+                        frag_zero(doa[e]);
+                        mls[e] = (f32x4){1e30f, 1e30f, 1e30f, 1e30f};
+                        ddv[e] = F32X4_ZERO;
                     }
                 }
-                Frag<T> pf, dsf;
-                frag_from_c2(pf, pt[0], pt[1]);
-                frag_from_c2(dsf, dst[0], dst[1]);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    Frag<T> a;
-                    if (TR) col_frag_tr(a, dOr, half, jp, 2 * jp + 1 < nst);
-                    else col_frag<T>(a, dOt, tp, half, jp, 2 * jp + 1 < nst);
-                    dv[half] = mma(a, pf, dv[half]);
-                    if (TR) col_frag_tr(a, Qr, half, jp, 2 * jp + 1 < nst);
-                    else col_frag<T>(a, Qt, tp, half, jp, 2 * jp + 1 < nst);
-                    dk[half] = mma(a, dsf, dk[half]);
+                    if (TR) {
+                        col_frag_tr(ado[half], dOr, half, jp, hi_valid);
+                        col_frag_tr(aq[half], Qr, half, jp, hi_valid);
+                    } else {
+                        col_frag<T>(ado[half], dOt, tp, half, jp, hi_valid);
+                        col_frag<T>(aq[half], Qt, tp, half, jp, hi_valid);
+                    }
+                }
+#pragma unroll
+                for (int si = 0; si < MB_NSW; ++si) {
+                    if (!sact[si]) continue;
+                    f32x4 pt[2], dst[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x4 sq = mma(qa[e], kf[si], F32X4_ZERO);
+                        const f32x4 dp = mma(doa[e], vf[si], F32X4_ZERO);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = exp2f(sq[r] - mls[e][r]);
+                            pt[e][r] = p;
+                            dst[e][r] = p * (dp[r] - ddv[e][r]);
+                        }
+                    }
+                    Frag<T> pf, dsf;
+                    frag_from_c2(pf, pt[0], pt[1]);
+                    frag_from_c2(dsf, dst[0], dst[1]);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        dv[si][half] = mma(ado[half], pf, dv[si][half]);
+                        dk[si][half] = mma(aq[half], dsf, dk[si][half]);
+                    }
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dk[0][r] *= 0.6931471805599453f;  // Q' carries log2(e)/sqrt(dh): dk = dS^T q / sqrt(dh) = dS^T Q' ln2
-                dk[1][r] *= 0.6931471805599453f;
-            }
-            if (tv[si]) {
-                store_row24<T>(dqkv_row(1 * MB_HEADS + head, n0 + tt[si]), dk[0], dk[1]);
-                store_row24<T>(dqkv_row(2 * MB_HEADS + head, n0 + tt[si]), dv[0], dv[1]);
+            for (int si = 0; si < MB_NSW; ++si) {
+                if (!sact[si] || !tv[si]) continue;  // (keys beyond T only ever produced their own, discarded, columns)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dk[si][0][r] *= 0.6931471805599453f;  // Q' carries log2(e)/sqrt(dh): dk = dS^T q / sqrt(dh) = dS^T Q' ln2
+                    dk[si][1][r] *= 0.6931471805599453f;
+                }
+                store_row24<T>(dqkv_row(1 * MB_HEADS + head, n0 + tt[si]), dk[si][0], dk[si][1]);
+                store_row24<T>(dqkv_row(2 * MB_HEADS + head, n0 + tt[si]), dv[si][0], dv[si][1]);
             }
         }
         PHASE(8);
