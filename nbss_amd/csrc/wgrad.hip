@@ -548,12 +548,15 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
 // (b,f) rows — tokens t0-h .. t0+63+h of one row, zero outside [0,T) — so tap d is just a row offset of d in the image and X is
 // fetched and written to LDS once instead of once per tap (tr2: 6 vectors per thread per 32 tokens; here 6 per 64).  Tiles are
 // ordered nt-major so the bias column sums only exist in the first slots of a wave.
-#define W3_KC 64
+// F-convs (taps along F = a stride of T tokens) use the same kernel with chunks of KC/2 frequencies x 2 adjacent frames of one
+// batch item: image row 2 fo + tt holds token (f0 + fo, t0 + tt), a tap is a row offset of 2, and every global access is a
+// 16-byte piece of a 384-byte (2-frame) run.
 #define W3_MAXV 7
 #define W3_BS 3  // slots that can hold nt == 0 tiles (ngrp * mtiles <= 8 * W3_BS)
 
-template <int NBUF>
-__global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kernel(WgradArgs a) {
+template <int W3_KC>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
+    constexpr int NBUF = 2;
     NBSS_LDS(smem);
     typedef bf16_t T;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id_u();
@@ -564,7 +567,9 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
     const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
     const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
     const int lda = tr_ld(ncolsA), ldb = tr_ld(ncolsB);
-    const int h = a.taps / 2, rowsB = W3_KC + 2 * h;
+    const bool fmode = a.taps > 1 && a.shift_dim == 1;
+    const int rs = fmode ? 2 : 1;  // image rows per tap step
+    const int h = a.taps / 2, rowsB = W3_KC + 2 * h * rs;
     const int imgA = W3_KC * lda, img = imgA + rowsB * ldb;  // elements per buffer
     T* base = reinterpret_cast<T*>(smem);
     for (int i = tid; i < NBUF * img / 2; i += WG_THREADS) reinterpret_cast<uint32_t*>(base)[i] = 0u;
@@ -597,11 +602,12 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
             oa[s] = trow * lda + g * mg + mt * 16 + tcol;
             int q0 = nt * 16 + tcol;
             if (q0 >= nexp) q0 = 0;  // padding columns of the last tile: any valid address, discarded at the flush
-            ob[s] = imgA + (q0 / ng + trow) * ldb + g * ng + q0 % ng;  // tap = q0 / ng: image row k + tap holds token k + tap - h
+            ob[s] = imgA + ((q0 / ng) * rs + trow) * ldb + g * ng + q0 % ng;  // tap = q0 / ng: image row k + tap rs holds the token tap - h steps away
         }
     }
     // per-vector descriptors of this thread (chunk independent): chunk-relative row, global element offset, LDS offset
-    int vkk[W3_MAXV], vgo[W3_MAXV], vdst[W3_MAXV];
+    int vkk[W3_MAXV], vtok[W3_MAXV], vgo[W3_MAXV], vdst[W3_MAXV];
+    bool vt1[W3_MAXV];  // second frame of an F-mode pair
     const int rsA = a.a_gw ? a.a_gw : a.lda, rsB = a.b_gw ? a.b_gw : a.ldb;  // global row strides
     bool vA[W3_MAXV], vok[W3_MAXV];
 #pragma unroll
@@ -611,20 +617,27 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
         vA[u] = v < nvA;
         if (vA[u]) {
             const int k = v / pA, c8 = v % pA, col = acols0 + 8 * c8;
-            vkk[u] = k; vgo[u] = k * rsA + (a.a_gw ? (col / a.a_gw) * a.a_gs + col % a.a_gw : col); vdst[u] = k * lda + 8 * c8;
+            vkk[u] = fmode ? k / 2 : k; vt1[u] = fmode && (k & 1); vtok[u] = fmode ? (k / 2) * a.T + (k & 1) : k;
+            vgo[u] = vtok[u] * rsA + (a.a_gw ? (col / a.a_gw) * a.a_gs + col % a.a_gw : col); vdst[u] = k * lda + 8 * c8;
         } else {
             const int v2 = vok[u] ? v - nvA : 0, j = v2 / pB, c8 = v2 % pB, col = bcols0 + 8 * c8;
-            vkk[u] = j - h; vgo[u] = (j - h) * rsB + (a.b_gw ? (col / a.b_gw) * a.b_gs + col % a.b_gw : col); vdst[u] = imgA + j * ldb + 8 * c8;
+            vkk[u] = fmode ? j / 2 - h : j - h; vt1[u] = fmode && (j & 1); vtok[u] = fmode ? (j / 2 - h) * a.T + (j & 1) : j - h;
+            vgo[u] = vtok[u] * rsB + (a.b_gw ? (col / a.b_gw) * a.b_gs + col % a.b_gw : col); vdst[u] = imgA + j * ldb + 8 * c8;
         }
     }
     const int cpr = cdiv(a.T, W3_KC);
-    const int nchunks = a.taps > 1 ? (a.Ntok / a.T) * cpr : cdiv(a.Ntok, W3_KC);
+    const int nfc = cdiv(a.F, W3_KC / 2), ntp = cdiv(a.T, 2);  // F mode: frequency chunks and frame pairs per batch item
+    const int nchunks = fmode ? (a.Ntok / (a.F * a.T)) * ntp * nfc : a.taps > 1 ? (a.Ntok / a.T) * cpr : cdiv(a.Ntok, W3_KC);
     u32x4 pre[W3_MAXV];
     float pmu[W3_MAXV], prs[W3_MAXV];
     auto prefetch = [&](int ch) {
         long nbase;
-        int lo, lim;  // chunk-relative rows lo <= k < lim exist
-        if (a.taps > 1) {
+        int lo, lim;  // chunk-relative rows (F mode: frequencies) lo <= k < lim exist
+        bool t1ok = true;  // F mode: the second frame of the pair exists
+        if (fmode) {
+            const int bb = ch / (ntp * nfc), rem = ch % (ntp * nfc), t0 = 2 * (rem / nfc), f0 = (rem % nfc) * (W3_KC / 2);
+            nbase = ((long)bb * a.F + f0) * a.T + t0; lo = -f0; lim = a.F - f0; t1ok = t0 + 1 < a.T;
+        } else if (a.taps > 1) {
             const int row = ch / cpr, t0 = (ch % cpr) * W3_KC;
             nbase = (long)row * a.T + t0; lo = -t0; lim = a.T - t0;
         } else {
@@ -637,9 +650,9 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
         for (int u = 0; u < W3_MAXV; ++u) {
             pre[u] = (u32x4){0, 0, 0, 0};
             pmu[u] = 0.f; prs[u] = 0.f;
-            if (!vok[u] || vkk[u] < lo || vkk[u] >= lim || (a.dbg & 4)) continue;
+            if (!vok[u] || vkk[u] < lo || vkk[u] >= lim || (vt1[u] && !t1ok) || (a.dbg & 4)) continue;
             pre[u] = *reinterpret_cast<const u32x4*>((vA[u] ? Ab : Bb) + vgo[u]);
-            if (!vA[u] && sb) { pmu[u] = sb[2 * vkk[u]]; prs[u] = sb[2 * vkk[u] + 1]; }
+            if (!vA[u] && sb) { pmu[u] = sb[2 * vtok[u]]; prs[u] = sb[2 * vtok[u] + 1]; }
         }
     };
     auto stash = [&](T* buf) {
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(WG_THREADS, NBUF == 1 ? 4 : 2) void wgrad_tr3_kerne
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
                 float gm[8], bt[8];
-                const int col = vgo[u] - vkk[u] * rsB;  // (LayerNorm operands are always plain row-major)
+                const int col = vgo[u] - vtok[u] * rsB;  // (LayerNorm operands are always plain row-major)
                 load8(lnp + col, gm);
                 load8(lnp + a.NB + col, bt);
 #pragma unroll
@@ -801,30 +814,31 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     // transposing-read kernels: whole rows are copied in 16-byte pieces (staged widths % 8) and tiles are addressed in
     // 4-channel pieces (group widths % 4, checked by the caller)
     if (sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
-        // 64-token chunks, one X image for all taps: dense problems and T-convs
-        const int h3 = a.taps / 2, nfirst3 = (all ? a.groups : 1) * mtiles;
-        const size_t img3 = ((size_t)W3_KC * tr_ld(ncA) + (size_t)(W3_KC + 2 * h3) * tr_ld(ncB)) * 2;
-        const int nvec3 = W3_KC * (ncA / 8) + (W3_KC + 2 * h3) * (ncB / 8);
-        static const int nbuf3 = getenv("NBSS_WG_NBUF") ? atoi(getenv("NBSS_WG_NBUF")) : 2;
-        const bool gm_ok = (!a.a_gw || (a.a_gw % 8 == 0 && mg % a.a_gw == 0) || a.a_gw % mg == 0) && (!a.b_gw || !a.stats);
-        if (gm_ok && (a.taps == 1 || (a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0)) && nvec3 <= W3_MAXV * WG_THREADS &&
-            nfirst3 <= WG_WAVES * W3_BS && nbuf3 * img3 + 2 * (size_t)a.NB * sizeof(float) <= (nbuf3 == 1 ? 80 : 158) * 1024) {
-            const int nch3 = a.taps > 1 ? (a.Ntok / a.T) * cdiv(a.T, W3_KC) : cdiv(a.Ntok, W3_KC);
-            int xb = (nbuf3 == 1 ? 512 : 256) / ybl;
+        // 64-token chunks, one X image for all taps: dense problems, T-convs and (96-row chunks of 48 frequencies x 2 frames) F-convs
+        const bool fmode3 = a.taps > 1 && a.shift_dim == 1 && a.shift_stride == a.T && a.Ntok % (a.F * a.T) == 0;
+        const bool tmode3 = a.taps > 1 && a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0;
+        const int kc3 = fmode3 ? 96 : 64, h3 = a.taps / 2, rowsB3 = kc3 + 2 * h3 * (fmode3 ? 2 : 1), nfirst3 = (all ? a.groups : 1) * mtiles;
+        const size_t img3 = ((size_t)kc3 * tr_ld(ncA) + (size_t)rowsB3 * tr_ld(ncB)) * 2;
+        const int nvec3 = kc3 * (ncA / 8) + rowsB3 * (ncB / 8);
+        const bool gm_ok = (!a.a_gw || a.a_gw % 8 == 0) && (!a.b_gw || (a.b_gw % 8 == 0 && !a.stats));
+        if (gm_ok && (a.taps == 1 || tmode3 || fmode3) && nvec3 <= W3_MAXV * WG_THREADS && nfirst3 <= WG_WAVES * W3_BS &&
+            2 * img3 + 2 * (size_t)a.NB * sizeof(float) <= 158 * 1024) {
+            const int nch3 = fmode3 ? (a.Ntok / (a.F * a.T)) * cdiv(a.T, 2) * cdiv(a.F, kc3 / 2) : tmode3 ? (a.Ntok / a.T) * cdiv(a.T, kc3) : cdiv(a.Ntok, kc3);
+            int xb = 256 / ybl;
             if (xb < 16) xb = 16;
             if (xb > nch3) xb = nch3;
             ProfScope ps(PK_WGRAD, st);
-            const size_t lds3 = nbuf3 * img3 + 2 * (size_t)a.NB * sizeof(float);
+            const size_t lds3 = 2 * img3 + 2 * (size_t)a.NB * sizeof(float);
             const int ntot3 = nfirst3 * ntiles;
             WgradArgs a3 = a;
             if ((size_t)ybl * xb * ntot3 * 272 * sizeof(float) > WGPART_BYTES) a3.part = nullptr;
             int e3;
-            if (nbuf3 == 1) {
-                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<1>, lds3))) return e3;
-                NBSS_LAUNCH(wgrad_tr3_kernel<1>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
+            if (fmode3) {
+                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<96>, lds3))) return e3;
+                NBSS_LAUNCH(wgrad_tr3_kernel<96>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
             } else {
-                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<2>, lds3))) return e3;
-                NBSS_LAUNCH(wgrad_tr3_kernel<2>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
+                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<64>, lds3))) return e3;
+                NBSS_LAUNCH(wgrad_tr3_kernel<64>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
             }
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
             if (a3.part && !(a3.dbg & 1)) {
