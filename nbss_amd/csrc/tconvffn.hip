@@ -122,16 +122,23 @@ NBSS_DEV void stage_loads(u32x4 (&r)[NV], const StageSrcs<T>& srcs, size_t goff)
     }
 }
 template <class T, int NSRC>
-NBSS_DEV void stage_group(T* __restrict__ wl, const StageSrcs<T>& srcs, size_t goff) {
-    constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN;
-    constexpr int NV = (NSRC * VPS + 511) / 512;
+struct StageRegs {
+    static constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN, NV = (NSRC * VPS + 511) / 512;
     u32x4 r[NV];
-    stage_loads<T, NSRC, 0, NV>(r, srcs, goff);
+    NBSS_DEV void load(const StageSrcs<T>& srcs, size_t goff) { stage_loads<T, NSRC, 0, NV>(r, srcs, goff); }
+    NBSS_DEV void store(T* __restrict__ wl) const {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = (int)threadIdx.x + i * 512;
-        if (v < NSRC * VPS) *reinterpret_cast<u32x4*>(wl + (size_t)v * VN) = r[i];
+        for (int i = 0; i < NV; ++i) {
+            const int v = (int)threadIdx.x + i * 512;
+            if (v < NSRC * VPS) *reinterpret_cast<u32x4*>(wl + (size_t)v * VN) = r[i];
+        }
     }
+};
+template <class T, int NSRC>
+NBSS_DEV void stage_group(T* __restrict__ wl, const StageSrcs<T>& srcs, size_t goff) {
+    StageRegs<T, NSRC> sr;
+    sr.load(srcs, goff);
+    sr.store(wl);
 }
 template <class T>
 NBSS_DEV void lfrag(Frag<T>& f, const T* __restrict__ wl, int idx) { frag_load(f, wl + ((size_t)idx * 64 + lane_id()) * 8); }
@@ -195,8 +202,8 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
     T* ha = reinterpret_cast<T*>(smem);                    // [TP+2][24]
     T* hb = ha + (TF_TP + 2) * TF_CG;                      // [TP+2][24]
     float* red = reinterpret_cast<float*>(hb + (TF_TP + 2) * TF_CG);  // [8 waves][2]
-    T* wl = reinterpret_cast<T*>(red + 16);  // this group's weights: W1 | conv1 | conv2 | conv3 | W2, 6 fragments each
-    float* prm = reinterpret_cast<float*>(wl + 30 * 512);  // [7][FFN]: b1 cb1 cb2 cb3 gnw gnb b2 (per-lane global reads of these sat in every dependency chain)
+    T* wl0 = reinterpret_cast<T*>(red + 16);  // 2 x this group's weights: W1 | conv1 | conv2 | conv3 | W2, 6 fragments each
+    float* prm = reinterpret_cast<float*>(wl0 + (sizeof(T) == 2 ? 2 : 1) * 30 * 512);  // [7][FFN]: b1 cb1 cb2 cb3 gnw gnb b2 (per-lane global reads of these sat in every dependency chain)
     const int T_ = c.T;
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -264,28 +271,41 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
     const int d0 = 4 * g4, d1 = 16 + 4 * g4;
     const bool v1 = g4 < 2;  // second tile holds channels 16..23 only
 
+    constexpr int FVN = 16 / sizeof(T), FVPF = 512 / FVN, FNV2 = (6 * FVPF + 511) / 512;  // W2: 6 strided fragments
+    StageRegs<T, 4> fw;
+    u32x4 fw2[FNV2];
+    const StageSrcs<T> fsrc = {W1, Wc1, Wc2, Wc3, nullptr, nullptr, nullptr, nullptr};
+    auto fwd_wloads = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < FNV2; ++i) {  // W2: one fragment per output tile, strided by the group count
+            const int v = tid + i * 512, mt = v / FVPF, off = v % FVPF;
+            if (v < 6 * FVPF) fw2[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)(mt * TF_G + g) * 512 + (size_t)off * FVN);
+        }
+        fw.load(fsrc, (size_t)g * 6 * 512);
+    };
+    auto fwd_wstore = [&](T* dst) {
+        fw.store(dst);
+#pragma unroll
+        for (int i = 0; i < FNV2; ++i) {
+            const int v = tid + i * 512;
+            if (v < 6 * FVPF) *reinterpret_cast<u32x4*>(dst + 24 * 512 + (size_t)v * FVN) = fw2[i];
+        }
+    };
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
         f32x4 ct[TF_NSW][2];
         // the group's 30 weight fragments go through LDS once per workgroup (8 waves share them; the packed buffer is
-        // regularly evicted from L2 by the activation traffic, and per-wave global fragment loads sat in every MFMA chain)
-        {
-            constexpr int VN = 16 / sizeof(T), VPF = 512 / VN;  // vectors per fragment
-            const StageSrcs<T> srcs = {W1, Wc1, Wc2, Wc3, nullptr, nullptr, nullptr, nullptr};
-            u32x4 r2[(6 * VPF + 511) / 512];
-#pragma unroll
-            for (int i = 0; i < (6 * VPF + 511) / 512; ++i) {  // W2: one fragment per output tile, strided by the group count
-                const int v = tid + i * 512, mt = v / VPF, off = v % VPF;
-                if (v < 6 * VPF) r2[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)(mt * TF_G + gr) * 512 + (size_t)off * VN);
-            }
-            stage_group<T, 4>(wl, srcs, (size_t)gr * 6 * 512);
-#pragma unroll
-            for (int i = 0; i < (6 * VPF + 511) / 512; ++i) {
-                const int v = tid + i * 512;
-                if (v < 6 * VPF) *reinterpret_cast<u32x4*>(wl + 24 * 512 + (size_t)v * VN) = r2[i];
-            }
+        // regularly evicted from L2 by the activation traffic, and per-wave global fragment loads sat in every MFMA chain).
+        // Two LDS buffers: group g+1's fragments are requested here and written to the other buffer at the end of group g.
+        // (the fp32 stream has LDS room for one buffer only and stages at the top of every group)
+        constexpr bool DB = sizeof(T) == 2;
+        T* wl = wl0 + (size_t)(DB ? (gr & 1) : 0) * 30 * 512;
+        if (!DB || gr == 0) {
+            fwd_wloads(gr);
+            fwd_wstore(wl);
+            lds_barrier();
         }
-        lds_barrier();
+        if (DB && gr + 1 < TF_G) fwd_wloads(gr + 1);
         // (a) h1 = SiLU(W1_g LN(x) + b1_g) -> ha
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -383,7 +403,8 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
 #pragma unroll
             for (int si = 0; si < TF_NSW; ++si) yacc[si][mt] = mma(a, h5[si], yacc[si][mt]);
         }
-        lds_barrier();  // ha / hb / red are rewritten by the next group
+        if (DB && gr + 1 < TF_G) fwd_wstore(wl0 + (size_t)((gr + 1) & 1) * 30 * 512);  // last read two barriers ago
+        lds_barrier();  // ha / hb / red are rewritten by the next group; the other weight buffer is complete
     }
 
 #pragma unroll
@@ -526,6 +547,25 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     const float cnt = (float)(TF_CG * T_);
     const size_t ntok = (size_t)c.B * c.F * T_;
 
+    // loop-carried prefetch registers: raw x / dy fragments of the wave's strips and this thread's share of the group's weights
+    Frag<T> xr[TF_NSW][TF_KS], dr[TF_NSW][TF_KS];
+    StageRegs<T, 8> wreg;
+    const StageSrcs<T> wsrc = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
+    auto group_loads = [&](int g) {
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si)
+#pragma unroll
+            for (int ks = 0; ks < TF_KS; ++ks) {
+                if (tv[si]) {
+                    frag_load(xr[si][ks], xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                } else {
+                    frag_zero(xr[si][ks]);
+                    frag_zero(dr[si][ks]);
+                }
+            }
+        if (sizeof(T) == 2) wreg.load(wsrc, (size_t)g * 6 * 512);
+    };
     lds_barrier();  // lnp / prm / halo rows are in place
     PHASE(0);
     for (int gr = 0; gr < TF_G; ++gr) {
@@ -541,22 +581,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         // Every global read of the group is issued here, ahead of the group's operand stores: loads and stores share vmcnt on
         // gfx9, so a load issued after a store cannot complete before that store is acknowledged (the three phases that read
         // x, dy and the weights behind stores were 43 % of the wave time).
-        Frag<T> xr[TF_NSW][TF_KS], dr[TF_NSW][TF_KS];
-#pragma unroll
-        for (int si = 0; si < TF_NSW; ++si)
-#pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) {
-                if (tv[si]) {
-                    frag_load(xr[si][ks], xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                } else {
-                    frag_zero(xr[si][ks]);
-                    frag_zero(dr[si][ks]);
-                }
-            }
+        // (Issuing them one phase earlier still, before the last conv phase of the previous group, spilled 20 registers and
+        // was slower: 6.7 vs 6.3 ms/step.)
+        group_loads(gr);
         if (STAGE) {
-            const StageSrcs<T> ss = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
-            stage_group<T, 8>(wl, ss, (size_t)gr * 6 * 512);
+            wreg.store(wl);
             lds_barrier();
         }
         PHASE(1);
@@ -969,7 +998,7 @@ template <class T>
 static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + 7 * TF_FFN) * sizeof(float) + (size_t)30 * 512 * sizeof(T);
+    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + 7 * TF_FFN) * sizeof(float) + (size_t)(sizeof(T) == 2 ? 2 : 1) * 30 * 512 * sizeof(T);
     const T* pk = (const T*)packed;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_F, st);
