@@ -72,6 +72,11 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
     NBSS_LDS(smem);
     T* Ks = reinterpret_cast<T*>(smem);              // [HPP][TP][DH]
     T* Vt = Ks + HPP * MH_TP * MH_DH;                // [HPP][DH][TP]
+    // bf16 (all heads in one pass): weight fragments go through a 48-fragment LDS window — Q|K in_proj rows first, then
+    // V in_proj | out_proj — instead of per-wave global fragment reads (the ISA had ~60 exposed vmcnt waits between MFMAs)
+    constexpr bool WLDS = sizeof(T) == 2 && HPP == MH_HEADS;
+    T* wl = Vt + HPP * MH_TP * MH_DH + 32;           // [48][512]
+    float* prm = reinterpret_cast<float*>(wl + (WLDS ? 48 * 512 : 0));  // [3H in_proj bias | H out_proj bias | 2H LN gamma, beta]
     const int T_ = c.T, nst = cdiv(T_, 16);
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -81,12 +86,26 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
 
     float gam[MH_KS][8], bet[MH_KS][8];
 #pragma unroll
-    for (int ks = 0; ks < MH_KS; ++ks)
+    for (int ks = 0; ks < MH_KS; ++ks) {
+        load8(lnw + ks * 32 + 8 * g4, gam[ks]);
+        load8(lnb + ks * 32 + 8 * g4, bet[ks]);
+    }
+    u32x4 wr[6];  // this thread's share of a 48-fragment weight window
+    auto wwin_load = [&](const T* s0, const T* s1) {  // two runs of 24 fragments (1536 16-byte vectors) each
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            gam[ks][j] = lnw[ks * 32 + 8 * g4 + j];
-            bet[ks][j] = lnb[ks * 32 + 8 * g4 + j];
+        for (int i = 0; i < 6; ++i) {
+            const int v = tid + i * 512;
+            wr[i] = *reinterpret_cast<const u32x4*>((v < 1536 ? s0 : s1 - 1536 * 8) + (size_t)v * 8);
         }
+    };
+    auto wwin_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) reinterpret_cast<u32x4*>(wl)[tid + i * 512] = wr[i];
+    };
+    if (WLDS) {
+        wwin_load(Win, Win + 24 * 512);  // Q rows | K rows (24 fragments each: 4 heads x 2 halves x 3 k-steps)
+        for (int i = tid; i < 4 * MH_H; i += blockDim.x) prm[i] = i < 3 * MH_H ? bin[i] : bout[i - 3 * MH_H];
+    }
 
     for (int pass = 0; pass < MH_HEADS / HPP; ++pass) {
         // (all 16 strips are always projected, so every K / V^T entry is (re)written each pass and
@@ -102,8 +121,18 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                 const int t = (w * MH_NSW + si) * 16 + l15;
                 ln_strip<T>(xb + (size_t)t * MH_H, t < T_, gam, bet, u[si]);
             }
+            if (WLDS) {
+                wwin_store();
+                lds_barrier();
+                wwin_load(Win + 48 * 512, Wout);  // V rows | out_proj: in flight during the Q and K projections
+            }
 #pragma unroll
             for (int which = 0; which < 3; ++which) {
+                if (WLDS && which == 2) {
+                    lds_barrier();  // everyone is done with the Q|K window
+                    wwin_store();
+                    lds_barrier();
+                }
 #pragma unroll
                 for (int hh = 0; hh < HPP; ++hh) {
                     const int head = pass * HPP + hh;
@@ -112,7 +141,10 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                     for (int half = 0; half < 2; ++half) {
                         Frag<T> a[MH_KS];
 #pragma unroll
-                        for (int ks = 0; ks < MH_KS; ++ks) wfrag_load(a[ks], Win, (which * MH_HEADS + head) * 2 + half, MH_KS, ks);
+                        for (int ks = 0; ks < MH_KS; ++ks) {
+                            if (WLDS) frag_load(a[ks], wl + ((size_t)(((which & 1) * MH_HEADS + head) * 2 + half) * MH_KS + ks) * 512 + lane * 8);
+                            else wfrag_load(a[ks], Win, (which * MH_HEADS + head) * 2 + half, MH_KS, ks);
+                        }
 #pragma unroll
                         for (int si = 0; si < MH_NSW; ++si) {
                             f32x4 acc = F32X4_ZERO;
@@ -125,8 +157,9 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                     float b0[4], b1[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        b0[r] = bin[which * MH_H + head * MH_DH + 4 * g4 + r];
-                        b1[r] = (16 + 4 * g4 + r < MH_DH) ? bin[which * MH_H + head * MH_DH + 16 + 4 * g4 + r] : 0.f;
+                        const float* bsrc = WLDS ? prm : bin;
+                        b0[r] = bsrc[which * MH_H + head * MH_DH + 4 * g4 + r];
+                        b1[r] = (16 + 4 * g4 + r < MH_DH) ? bsrc[which * MH_H + head * MH_DH + 16 + 4 * g4 + r] : 0.f;
                     }
 #pragma unroll
                     for (int si = 0; si < MH_NSW; ++si) {
@@ -249,29 +282,40 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
         }
 
         // ---- stage C: output projection (+bias, +residual) --------------------------------------
+        // the residual rows are requested up front (one wait instead of one per output tile)
+        float rv[MH_NSW][MH_H / 16][4];
+#pragma unroll
+        for (int si = 0; si < MH_NSW; ++si) {
+            const int t = (w * MH_NSW + si) * 16 + l15;
+#pragma unroll
+            for (int mt = 0; mt < MH_H / 16; ++mt) {
+                if (t < T_) load4((pass == 0 ? xb : yb) + (size_t)t * MH_H + 16 * mt + 4 * g4, rv[si][mt]);
+                else rv[si][mt][0] = rv[si][mt][1] = rv[si][mt][2] = rv[si][mt][3] = 0.f;
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MH_H / 16; ++mt) {
             Frag<T> a[HPP];
 #pragma unroll
-            for (int hh = 0; hh < HPP; ++hh) wfrag_load(a[hh], Wout, mt, MH_HEADS, pass * HPP + hh);
+            for (int hh = 0; hh < HPP; ++hh) {
+                if (WLDS) frag_load(a[hh], wl + ((size_t)24 + mt * MH_HEADS + hh) * 512 + lane * 8);
+                else wfrag_load(a[hh], Wout, mt, MH_HEADS, pass * HPP + hh);
+            }
             const int ch = 16 * mt + 4 * g4;
+            float bo[4] = {0.f, 0.f, 0.f, 0.f};
+            if (pass == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bo[r] = WLDS ? prm[3 * MH_H + ch + r] : bout[ch + r];
+            }
 #pragma unroll
             for (int si = 0; si < MH_NSW; ++si) {
                 const int t = (w * MH_NSW + si) * 16 + l15;
                 f32x4 acc = F32X4_ZERO;
 #pragma unroll
                 for (int hh = 0; hh < HPP; ++hh) acc = mma(a[hh], of[si][hh], acc);
-                if (t < T_) {
-                    float rv[4];
-                    if (pass == 0) {
-                        load4(xb + (size_t)t * MH_H + ch, rv);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rv[r] += bout[ch + r];
-                    } else {
-                        load4(yb + (size_t)t * MH_H + ch, rv);
-                    }
-                    store4(yb + (size_t)t * MH_H + ch, rv[0] + acc[0], rv[1] + acc[1], rv[2] + acc[2], rv[3] + acc[3]);
-                }
+                if (t < T_)
+                    store4(yb + (size_t)t * MH_H + ch, rv[si][mt][0] + bo[0] + acc[0], rv[si][mt][1] + bo[1] + acc[1], rv[si][mt][2] + bo[2] + acc[2],
+                           rv[si][mt][3] + bo[3] + acc[3]);
             }
         }
     }
@@ -280,7 +324,8 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
 template <class T, int HPP>
 static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
     if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T) + 64;  // +64: the last transposing read overreaches its row by 16 B
+    // +64: the last transposing read overreaches its row by 16 B; bf16: 48-fragment weight window + biases
+    const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T) + 64 + (sizeof(T) == 2 && HPP == MH_HEADS ? (size_t)48 * 512 * sizeof(T) + 4 * MH_H * sizeof(float) : 0);
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP>), lds);
     if (e) return e;

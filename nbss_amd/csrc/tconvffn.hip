@@ -547,25 +547,6 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
     const float cnt = (float)(TF_CG * T_);
     const size_t ntok = (size_t)c.B * c.F * T_;
 
-    // loop-carried prefetch registers: raw x / dy fragments of the wave's strips and this thread's share of the group's weights
-    Frag<T> xr[TF_NSW][TF_KS], dr[TF_NSW][TF_KS];
-    StageRegs<T, 8> wreg;
-    const StageSrcs<T> wsrc = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
-    auto group_loads = [&](int g) {
-#pragma unroll
-        for (int si = 0; si < TF_NSW; ++si)
-#pragma unroll
-            for (int ks = 0; ks < TF_KS; ++ks) {
-                if (tv[si]) {
-                    frag_load(xr[si][ks], xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                } else {
-                    frag_zero(xr[si][ks]);
-                    frag_zero(dr[si][ks]);
-                }
-            }
-        if (sizeof(T) == 2) wreg.load(wsrc, (size_t)g * 6 * 512);
-    };
     lds_barrier();  // lnp / prm / halo rows are in place
     PHASE(0);
     for (int gr = 0; gr < TF_G; ++gr) {
@@ -583,8 +564,23 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         // x, dy and the weights behind stores were 43 % of the wave time).
         // (Issuing them one phase earlier still, before the last conv phase of the previous group, spilled 20 registers and
         // was slower: 6.7 vs 6.3 ms/step.)
-        group_loads(gr);
+        Frag<T> xr[TF_NSW][TF_KS], dr[TF_NSW][TF_KS];
+        StageRegs<T, 8> wreg;
+#pragma unroll
+        for (int si = 0; si < TF_NSW; ++si)
+#pragma unroll
+            for (int ks = 0; ks < TF_KS; ++ks) {
+                if (tv[si]) {
+                    frag_load(xr[si][ks], xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
+                } else {
+                    frag_zero(xr[si][ks]);
+                    frag_zero(dr[si][ks]);
+                }
+            }
         if (STAGE) {
+            const StageSrcs<T> wsrc = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
+            wreg.load(wsrc, (size_t)gr * 6 * 512);
             wreg.store(wl);
             lds_barrier();
         }
