@@ -20,9 +20,11 @@
 #define FL_TT 8
 #define FL_KS (FL_H / 32)
 #define FL_MT (FL_H / 16)
+#define FL_KSF_MAX 5  // ceil(160 / 32): layout.h check_cfg caps F at 160
+#define FL_THREADS 512  // 8 waves: one workgroup per CU (256 slabs), so the waves of a workgroup are all the latency hiding there is
 
 template <class T>
-__global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+__global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bs, const float* __restrict__ bfull,
                                                        const float* __restrict__ bu, const T* __restrict__ Wsq,
                                                        const T* __restrict__ Wfull, const T* __restrict__ Wusq,
@@ -102,12 +104,18 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
     for (int task = w; task < FL_SQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
-        for (int ks = 0; ks < ksf; ++ks) {
-            Frag<T> a, bq;
-            wfrag_load(a, Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
-            if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
-            else frag_zero(bq);
-            acc = mma(a, bq, acc);
+        Frag<T> a[FL_KSF_MAX];  // all k-step fragments of the tile requested together (F <= 160: at most 5)
+#pragma unroll
+        for (int ks = 0; ks < FL_KSF_MAX; ++ks)
+            if (ks < ksf) wfrag_load(a[ks], Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
+#pragma unroll
+        for (int ks = 0; ks < FL_KSF_MAX; ++ks) {
+            if (ks < ksf) {
+                Frag<T> bq;
+                if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+                else frag_zero(bq);
+                acc = mma(a[ks], bq, acc);
+            }
         }
         if (l15 < FL_TT) {
 #pragma unroll
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void full_fwd_kernel(nbss_cfg c, const float* 
 #define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
 
 template <class T>
-__global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
+__global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
@@ -223,12 +231,18 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     for (int task = w; task < FL_SQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
-        for (int ks = 0; ks < ksf; ++ks) {
-            Frag<T> a, bq;
-            wfrag_load(a, Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
-            if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
-            else frag_zero(bq);
-            acc = mma(a, bq, acc);
+        Frag<T> a[FL_KSF_MAX];  // all k-step fragments of the tile requested together (F <= 160: at most 5)
+#pragma unroll
+        for (int ks = 0; ks < FL_KSF_MAX; ++ks)
+            if (ks < ksf) wfrag_load(a[ks], Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
+#pragma unroll
+        for (int ks = 0; ks < FL_KSF_MAX; ++ks) {
+            if (ks < ksf) {
+                Frag<T> bq;
+                if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+                else frag_zero(bq);
+                acc = mma(a[ks], bq, acc);
+            }
         }
         if (l15 < FL_TT) {
 #pragma unroll
@@ -297,12 +311,18 @@ __global__ __launch_bounds__(256) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     for (int task = w; task < FL_SQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
-        for (int ks = 0; ks < ksf; ++ks) {
-            Frag<T> a, bq;
-            wfrag_load(a, WfullT + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
-            if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
-            else frag_zero(bq);
-            acc = mma(a, bq, acc);
+        Frag<T> a[FL_KSF_MAX];  // all k-step fragments of the tile requested together (F <= 160: at most 5)
+#pragma unroll
+        for (int ks = 0; ks < FL_KSF_MAX; ++ks)
+            if (ks < ksf) wfrag_load(a[ks], WfullT + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
+#pragma unroll
+        for (int ks = 0; ks < FL_KSF_MAX; ++ks) {
+            if (ks < ksf) {
+                Frag<T> bq;
+                if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+                else frag_zero(bq);
+                acc = mma(a[ks], bq, acc);
+            }
         }
         if (l15 < FL_TT) {
 #pragma unroll
@@ -361,7 +381,7 @@ static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T>), lds);
     if (e) return e;
-    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
+    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
     ProfScope ps(PK_FULL_B, st);
     NBSS_LAUNCH((full_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
                 pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
@@ -428,7 +448,7 @@ static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T>), lds);
     if (e) return e;
-    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(256);
+    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
     ProfScope ps(PK_FULL_F, st);
     NBSS_LAUNCH((full_fwd_kernel<T>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
