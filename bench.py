@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU per step")
+    # 31: the row kernels launch one workgroup per (utterance, frequency) = 129 B workgroups on 256 CUs, one resident per CU;
+    # B = 31 is 15.6 waves of workgroups (98 % last-wave fill), B = 8 is 4.03 waves (81 %).  profiles/README.md has the sweep.
+    ap.add_argument("--batch", type=int, default=31, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -554,7 +554,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
 #define W3_MAXV 7
 #define W3_BS 3  // slots that can hold nt == 0 tiles (ngrp * mtiles <= 8 * W3_BS)
 
-template <int W3_KC>
+// NS = tile slots per wave (compile time, all executed: slots past the last tile contract a dummy tile that is never flushed).
+// The MFMA section has no branches, so the LDS reads of the following tiles are scheduled ahead of each MFMA; with
+// per-slot `if (tile exists)` tests every tile was read -> wait -> MFMA in sequence.
+template <int W3_KC, int NS>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     constexpr int NBUF = 2;
     NBSS_LDS(smem);
@@ -577,10 +580,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     if (a.stats)
         for (int i = tid; i < 2 * a.NB; i += WG_THREADS) lnp[i] = i < a.NB ? a.gamma[i] : a.beta[i - a.NB];
 
-    f32x4 acc[WG_TPW];
-    float bsum[W3_BS];
+    f32x4 acc[NS];
+    float bsum[W3_BS], bflag[W3_BS];
 #pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
+    for (int s = 0; s < NS; ++s) acc[s] = F32X4_ZERO;
 #pragma unroll
     for (int s = 0; s < W3_BS; ++s) bsum[s] = 0.f;
     const bool do_bias = a.dbias != nullptr;
@@ -591,12 +594,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     const int nfirst = ngrp * mtiles, ntot = nfirst * ntiles;  // tile tl = nt * nfirst + (g * mtiles + mt)
 
     // per-slot offsets (elements, inside a buffer) of this lane's transposing reads
-    int oa[WG_TPW], ob[WG_TPW];
+    int oa[NS], ob[NS];
     const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
 #pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
+    for (int s = 0; s < W3_BS; ++s) bflag[s] = (a.dbias != nullptr && s * WG_WAVES + w < nfirst) ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
         const int tl = s * WG_WAVES + w;
-        oa[s] = 0; ob[s] = 0;
+        oa[s] = trow * lda + tcol; ob[s] = imgA + trow * ldb + tcol;  // dummy slot: tile 0's operands
         if (tl < ntot) {
             const int nt = tl / nfirst, gm = tl % nfirst, g = gm / mtiles, mt = gm % mtiles;
             oa[s] = trow * lda + g * mg + mt * 16 + tcol;
@@ -686,21 +691,25 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         stash(buf);
         lds_barrier();
         if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
+        // software pipeline over the NS * KH (tile, k-half) steps: the operands of step i+1 are requested before step i's MFMA
+        constexpr int KH = W3_KC / 32;
+        Frag<T> fa[2], fb[2];
+        frag_load_tr(fa[0], buf + oa[0], lda);
+        frag_load_tr(fb[0], buf + ob[0], ldb);
 #pragma unroll
-        for (int s = 0; s < WG_TPW; ++s) {
-            const int tl = s * WG_WAVES + w;
-            if (tl < ntot && !(a.dbg & 2)) {
+        for (int i = 0; i < NS * KH; ++i) {
+            const int s = i / KH, cur = i & 1;
+            if (i + 1 < NS * KH) {
+                const int s1 = (i + 1) / KH, kh1 = (i + 1) % KH;
+                frag_load_tr(fa[cur ^ 1], buf + oa[s1] + kh1 * 32 * lda, lda);
+                frag_load_tr(fb[cur ^ 1], buf + ob[s1] + kh1 * 32 * ldb, ldb);
+            }
+            acc[s] = mma(fa[cur], fb[cur], acc[s]);
+            if (s < W3_BS) {
+                float cs = 0.f;
 #pragma unroll
-                for (int kh = 0; kh < W3_KC / 32; ++kh) {
-                    Frag<T> fa, fb;
-                    frag_load_tr(fa, buf + oa[s] + kh * 32 * lda, lda);
-                    frag_load_tr(fb, buf + ob[s] + kh * 32 * ldb, ldb);
-                    acc[s] = mma(fa, fb, acc[s]);
-                    if (s < W3_BS && do_bias && tl < nfirst) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) bsum[s < W3_BS ? s : 0] += frag_get(fa, j);
-                    }
-                }
+                for (int j = 0; j < 8; ++j) cs += frag_get(fa[cur], j);
+                bsum[s < W3_BS ? s : 0] += bflag[s < W3_BS ? s : 0] * cs;
             }
         }
         if (NBUF == 1) lds_barrier();
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         float* pt = a.part + wg * ntot * 256;
         float* pbias = a.part + (size_t)gridDim.y * gridDim.x * ntot * 256 + wg * ntot * 16;
 #pragma unroll
-        for (int s = 0; s < WG_TPW; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const int tl = s * WG_WAVES + w;
             if (tl < ntot) {
 #pragma unroll
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         return;
     }
 #pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
+    for (int s = 0; s < NS; ++s) {
         const int tl = s * WG_WAVES + w;
         if (tl < ntot) {
             const int nt = tl / nfirst, gm = tl % nfirst, g = g_lo + gm / mtiles, mt = gm % mtiles;
@@ -833,13 +842,19 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             WgradArgs a3 = a;
             if ((size_t)ybl * xb * ntot3 * 272 * sizeof(float) > WGPART_BYTES) a3.part = nullptr;
             int e3;
+            const int need = cdiv(ntot3, WG_WAVES);  // tile slots per wave
+#define W3_GO(KC, NS)                                                                             \
+    do {                                                                                          \
+        if ((e3 = NBSS_SET_MAX_LDS((wgrad_tr3_kernel<KC, NS>), lds3))) return e3;                 \
+        NBSS_LAUNCH((wgrad_tr3_kernel<KC, NS>), dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);   \
+    } while (0)
             if (fmode3) {
-                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<96>, lds3))) return e3;
-                NBSS_LAUNCH(wgrad_tr3_kernel<96>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
-            } else {
-                if ((e3 = NBSS_SET_MAX_LDS(wgrad_tr3_kernel<64>, lds3))) return e3;
-                NBSS_LAUNCH(wgrad_tr3_kernel<64>, dim3(xb, ybl), dim3(WG_THREADS), lds3, st, a3);
-            }
+                if (need <= 5) W3_GO(96, 5);
+                else W3_GO(96, 14);
+            } else if (need <= 5) W3_GO(64, 5);
+            else if (need <= 10) W3_GO(64, 10);
+            else W3_GO(64, 14);
+#undef W3_GO
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
             if (a3.part && !(a3.dbg & 1)) {
                 NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot3, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a3, xb, 1);
