@@ -79,7 +79,9 @@ int nbss_fconv_fwd(const nbss_cfg* cfg, const float* params, const void* packed,
 /* x + _full: LN -> squeeze+SiLU -> LinearGroup over F -> unsqueeze+SiLU (SpatialNet.py:86,129-146). */
 int nbss_full_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
 /* x + _tsa: LN -> nn.MultiheadAttention over T per (b,f) (SpatialNet.py:88,93-100).
- * o_save (optional, [B,F,T,H] of cfg->dtype): attention output before out_proj, kept for backward. */
+ * o_save (optional, nbss_mhsa_save_bytes(cfg) bytes): what backward needs besides the block input — the attention output
+ * before out_proj ([B,F,T,H] of cfg->dtype) followed by the fp32 log2-sum-exp of every (token, head) score row. */
+int64_t nbss_mhsa_save_bytes(const nbss_cfg* cfg);
 int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* o_save, void* stream);
 /* x + _tconvffn (SpatialNet.py:90,102-114,61-73). */
 int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);

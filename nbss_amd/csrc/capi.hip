@@ -107,6 +107,11 @@ int nbss_full_fwd(const nbss_cfg* cfg, const float* params, const void* packed, 
     return full_fwd_impl(*cfg, params, packed, layer, x, y, (hipStream_t)stream);
 }
 
+int64_t nbss_mhsa_save_bytes(const nbss_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
+    return (int64_t)mhsa_save_bytes(*cfg);
+}
+
 int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* o_save, void* stream) {
     CHECK_CFG(cfg);
     CHECK_LAYER(cfg, layer);
@@ -178,7 +183,7 @@ static size_t stream_bytes(const nbss_cfg& c) {
 
 int64_t nbss_acts_bytes(const nbss_cfg* cfg) {
     if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
-    return (int64_t)((size_t)(6 * cfg->L + 1) * stream_bytes(*cfg));
+    return (int64_t)((size_t)(5 * cfg->L + 1) * stream_bytes(*cfg) + (size_t)cfg->L * mhsa_save_bytes(*cfg));
 }
 
 int64_t nbss_train_ws_bytes(const nbss_cfg* cfg) {
@@ -193,7 +198,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     const nbss_cfg& c = *cfg;
     hipStream_t st = (hipStream_t)stream;
     const size_t sb = stream_bytes(c);
-    // training: every block input is kept (acts = [5L+1 stream copies | L attention outputs]);
+    // training: every block input is kept (acts = [5L+1 stream copies | L attention save buffers]);
     // inference: two ping-pong buffers at the tail of ws
     char* pp = acts ? nullptr : (char*)ws + workspace_bytes(c);
     int k = 0;
@@ -201,7 +206,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     int e = encoder_fwd_impl(c, params, packed, xin, buf(0), st);
     if (e) return e;
     for (int l = 0; l < c.L; ++l) {
-        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1 + l) * sb) : nullptr;
+        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c)) : nullptr;
         if ((e = fconv_fwd_impl(c, params, packed, l, 0, buf(k), buf(k + 1), st))) return e;
         if ((e = full_fwd_impl(c, params, packed, l, buf(k + 1), buf(k + 2), st))) return e;
         if ((e = fconv_fwd_impl(c, params, packed, l, 1, buf(k + 2), buf(k + 3), st))) return e;
@@ -227,7 +232,7 @@ int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, 
     int e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, dA, ws, st);
     if (e) return e;
     for (int l = c.L - 1; l >= 0; --l) {
-        const void* osave = act(5 * c.L + 1 + l);
+        const void* osave = (const char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c);
         if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), dA, dB, ws, st))) return e;
         if ((e = mhsa_bwd_impl(c, params, grads, packed, l, act(k - 2), dB, osave, dA, ws, st))) return e;
         if ((e = fconv_bwd_impl(c, params, grads, packed, l, 1, act(k - 3), dA, dB, ws, st))) return e;

@@ -188,6 +188,11 @@ NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
     return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) + 256;
 }
+// attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32
+NBSS_HD size_t mhsa_lse_offset(const nbss_cfg& c) {
+    return ws_align((size_t)c.B * c.F * c.T * c.H * (c.dtype == NBSS_BF16 ? 2 : 4));
+}
+NBSS_HD size_t mhsa_save_bytes(const nbss_cfg& c) { return mhsa_lse_offset(c) + ws_align((size_t)c.B * c.F * c.T * c.heads * sizeof(float)); }
 // per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands
 NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;

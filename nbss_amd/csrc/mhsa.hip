@@ -68,7 +68,7 @@ template <class T, int HPP>
 __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
-                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave) {
+                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave, float* __restrict__ lse) {
     NBSS_LDS(smem);
     T* Ks = reinterpret_cast<T*>(smem);              // [HPP][TP][DH]
     T* Vt = Ks + HPP * MH_TP * MH_DH;                // [HPP][DH][TP]
@@ -238,6 +238,10 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                     }
                 sum = wave_sum16(sum);
                 const float inv = 1.0f / sum;
+                if (lse && g4 == 0) {  // log2-sum-exp of the scaled score row: backward rebuilds P = exp2(S' - lse) from it
+                    const int t = (w * MH_NSW + si) * 16 + l15;
+                    if (t < T_) lse[((size_t)bf * T_ + t) * MH_HEADS + pass * HPP + hh] = mx + log2f(sum);
+                }
                 f32x4 o0 = F32X4_ZERO, o1 = F32X4_ZERO;
 #pragma unroll
                 for (int ks = 0; ks < MH_NT / 2; ++ks) {
@@ -333,7 +337,7 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     ProfScope ps(PK_MHSA_F, st);
     NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
-                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave);
+                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, osave ? (float*)((char*)osave + mhsa_lse_offset(c)) : nullptr);
     return NBSS_CHECK_LAUNCH();
 }
 

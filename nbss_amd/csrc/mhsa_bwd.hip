@@ -16,6 +16,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include <cstdlib>
 
 #define MB_H 96
 #define MB_HEADS 4
@@ -82,7 +83,7 @@ template <class T>
 __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Win, const T* __restrict__ WinT, const T* __restrict__ WoutT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ osave,
-                                                       T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dqkv) {
+                                                       const float* __restrict__ lse, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dqkv) {
     NBSS_LDS(smem);
     const int T_ = c.T, nst = cdiv(T_, 16), tp = nst * 16, nkp = cdiv(nst, 2);
     T* Qr = reinterpret_cast<T*>(smem);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         // ---------------- stage A: Q', K, V, dO of this head ----------------
         // all global reads of the head first (x, dy, saved O), ahead of this head's dqkv stores in the vmcnt queue
         Frag<T> uf[MB_NSW][MB_KS], dr[MB_NSW][MB_KS];
-        float o0[MB_NSW][4], o1[MB_NSW][4];
+        float o0[MB_NSW][4], o1[MB_NSW][4], lsev[MB_NSW];
 #pragma unroll
         for (int si = 0; si < MB_NSW; ++si) {
 #pragma unroll
@@ -181,9 +182,11 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) o0[si][r] = o1[si][r] = 0.f;
+            lsev[si] = 1e30f;  // padding frame: P = exp2(S - lse) = 0
             if (tv[si]) {
                 load4(ob + (size_t)tt[si] * MB_H + head * MB_DH + 4 * g4, o0[si]);
                 if (g4 < 2) load4(ob + (size_t)tt[si] * MB_H + head * MB_DH + 16 + 4 * g4, o1[si]);
+                lsev[si] = lse[(n0 + tt[si]) * MB_HEADS + head];  // log2-sum-exp of the score row, saved by the forward pass
             }
         }
 #pragma unroll
@@ -258,7 +261,10 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dsum += round_to(ct[si][0][r], x) * o0[si][r] + round_to(ct[si][1][r], x) * o1[si][r];
                     Dv[si] = wave_sum16(dsum);
-                    if (g4 == 0) Dds[t] = Dv[si];
+                    if (g4 == 0) {
+                        Dds[t] = Dv[si];
+                        m2s[t] = lsev[si];
+                    }
                 }
             }
             PHASE(1 + which);
@@ -267,72 +273,63 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         PHASE(5);
 
         // ---------------- pass 1: query strips -> dQ ----------------
+        // With the forward's log2-sum-exp there is no softmax sweep: P^T = exp2(S^T - lse) tile by tile, dS^T = P^T (dP^T - D),
+        // dQ^T += K^T dS^T.  The key-side operands of a tile pair (K, V rows, K^T) are fetched once for both query strips.
+        {
+            f32x4 dq[MB_NSW][2];
 #pragma unroll
-        for (int si = 0; si < MB_NSW; ++si) {
-            if (!sact[si]) continue;
-            f32x4 sc[MB_NT];
-            float mx = -1e30f;
+            for (int si = 0; si < MB_NSW; ++si) dq[si][0] = dq[si][1] = F32X4_ZERO;
+            for (int jp = 0; jp < nkp; ++jp) {
+                Frag<T> ak[2], av[2], akt[2];
+                const bool hi_valid = 2 * jp + 1 < nst;
 #pragma unroll
-            for (int j = 0; j < MB_NT; ++j) {
-                if (j < nst) {
-                    Frag<T> a;
-                    row_pieces<T>(a, Kr + (size_t)(j * 16 + l15) * MB_DH);
-                    sc[j] = mma(a, qf[si], F32X4_ZERO);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
-                        mx = fmaxf(mx, sc[j][r]);
+                for (int e = 0; e < 2; ++e) {
+                    const int jj = 2 * jp + e;
+                    if (jj < nst) {
+                        row_pieces<T>(ak[e], Kr + (size_t)(jj * 16 + l15) * MB_DH);
+                        row_pieces<T>(av[e], Vr + (size_t)(jj * 16 + l15) * MB_DH);
+                    } else {
+                        frag_zero(ak[e]);
+                        frag_zero(av[e]);
                     }
-                } else {
-                    sc[j] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (TR) col_frag_tr(akt[half], Kr, half, jp, hi_valid);
+                    else col_frag<T>(akt[half], Kt, tp, half, jp, hi_valid);
+                }
+#pragma unroll
+                for (int si = 0; si < MB_NSW; ++si) {
+                    if (!sact[si]) continue;
+                    f32x4 ds[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int jj = 2 * jp + e;
+                        const f32x4 st = mma(ak[e], qf[si], F32X4_ZERO);   // rows = keys 16 jj + 4 g4 + r, column = query l15
+                        const f32x4 dp = mma(av[e], dof[si], F32X4_ZERO);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool kv = jj * 16 + 4 * g4 + r < T_;  // (padding keys hold finite values: select, do not multiply)
+                            const float p = exp2f(st[r] - lsev[si]);
+                            ds[e][r] = kv ? p * (dp[r] - Dv[si]) : 0.f;
+                        }
+                    }
+                    Frag<T> dsf;
+                    frag_from_c2(dsf, ds[0], ds[1]);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) dq[si][half] = mma(akt[half], dsf, dq[si][half]);
                 }
             }
-            mx = wave_max16(mx);
-            float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < MB_NT; ++j)
+            for (int si = 0; si < MB_NSW; ++si) {
+                if (!sact[si] || !tv[si]) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (j < nst) ? exp2f(sc[j][r] - mx) : 0.f;
-                    sc[j][r] = p;
-                    sum += p;
+                    dq[si][0][r] *= rs_dh;
+                    dq[si][1][r] *= rs_dh;
                 }
-            sum = wave_sum16(sum);
-            const float inv = 1.0f / sum;
-            if (g4 == 0) m2s[tt[si]] = tv[si] ? mx + log2f(sum) : 1e30f;  // p = exp2(s - (m + log2 l)); padding frames: p = 0
-#pragma unroll
-            for (int j = 0; j < MB_NT; ++j) {
-                if (j < nst) {
-                    Frag<T> a;
-                    row_pieces<T>(a, Vr + (size_t)(j * 16 + l15) * MB_DH);
-                    const f32x4 dp = mma(a, dof[si], F32X4_ZERO);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[j][r] = sc[j][r] * inv * (dp[r] - Dv[si]);  // dS^T (natural-log domain)
-                } else {
-                    sc[j] = F32X4_ZERO;
-                }
+                store_row24<T>(dqkv_row(0 * MB_HEADS + head, n0 + tt[si]), dq[si][0], dq[si][1]);
             }
-            f32x4 dq[2] = {F32X4_ZERO, F32X4_ZERO};
-#pragma unroll
-            for (int ks = 0; ks < MB_NT / 2; ++ks) {
-                if (ks < nkp) {
-                    Frag<T> dsf;
-                    frag_from_c2(dsf, sc[2 * ks], sc[2 * ks + 1]);
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        Frag<T> a;
-                        if (TR) col_frag_tr(a, Kr, half, ks, 2 * ks + 1 < nst);
-                        else col_frag<T>(a, Kt, tp, half, ks, 2 * ks + 1 < nst);
-                        dq[half] = mma(a, dsf, dq[half]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dq[0][r] *= rs_dh;
-                dq[1][r] *= rs_dh;
-            }
-            if (tv[si]) store_row24<T>(dqkv_row(0 * MB_HEADS + head, n0 + tt[si]), dq[0], dq[1]);
         }
         PHASE(6);
         lds_barrier();
@@ -487,7 +484,8 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_MHSA_B, st);
     NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
-                pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (T*)dx, stats, (T*)dqkv);
+                pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)),
+                (T*)dx, stats, (T*)dqkv);
     return NBSS_CHECK_LAUNCH();
 }
 

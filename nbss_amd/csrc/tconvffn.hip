@@ -549,6 +549,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 
     lds_barrier();  // lnp / prm / halo rows are in place
     PHASE(0);
+    f32x4 pend[TF_NSW][2];  // da1 of the previous group, stored after the next group's loads are in flight
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si) pend[si][0] = pend[si][1] = F32X4_ZERO;
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
         f32x4 a1[TF_NSW][2], a2[TF_NSW][2], a3h[TF_NSW][2], a5[TF_NSW][2], ct[TF_NSW][2];
@@ -581,6 +584,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         if (STAGE) {
             const StageSrcs<T> wsrc = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
             wreg.load(wsrc, (size_t)gr * 6 * 512);
+        }
+        if (gr > 0) {
+#pragma unroll
+            for (int si = 0; si < TF_NSW; ++si) store_op<T>(ops.da1, n0 + tt[si], tv[si], gr - 1, ntok, pend[si][0], pend[si][1]);
+        }
+        if (STAGE) {
             wreg.store(wl);
             lds_barrier();
         }
@@ -809,13 +818,17 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 ct[si][0][r] *= dsilu_f(a1[si][0][r]);
                 ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a1[si][1][r]) : 0.f;
             }
-            store_op<T>(ops.da1, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
+            // the da1 store is deferred until the next group's loads have been issued (they would queue behind it in vmcnt)
+            pend[si][0] = ct[si][0];
+            pend[si][1] = ct[si][1];
         }
         PHASE(19);
         lds_barrier();
         PHASE(20);
     }
 
+#pragma unroll
+    for (int si = 0; si < TF_NSW; ++si) store_op<T>(ops.da1, n0 + tt[si], tv[si], TF_G - 1, ntok, pend[si][0], pend[si][1]);
     // du = W1^T da1 over all FFN channels, from the [N][FFN] operand this workgroup has just written (the weight-gradient
     // kernel reads the same buffer): a full barrier makes the stores of the other waves visible (never-read lines: no stale L1)
     __syncthreads();

@@ -92,17 +92,22 @@ def full_fwd(lib, cfg, flat, packed, layer, x):
     return y
 
 
+def mhsa_save(lib, cfg, device) -> Tensor:
+    """buffer for what mhsa_bwd needs from the forward pass (attention output before out_proj + log-sum-exp rows)"""
+    return torch.empty(lib.nbss_mhsa_save_bytes(C.byref(cfg)), dtype=torch.uint8, device=device)
+
+
 def mhsa_fwd(lib, cfg, flat, packed, layer, x, o_save=None):
     y = torch.empty_like(x)
     lib.call("nbss_mhsa_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y),
-             _ptr(lib, o_save), _stream(lib, x))
+             _ptr(lib, o_save, torch.uint8 if o_save is not None else None), _stream(lib, x))
     return y
 
 
 def mhsa_bwd(lib, cfg, flat, grads, packed, layer, x, dy, o_save, ws):
     dx = torch.empty_like(x)
     lib.call("nbss_mhsa_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed), layer,
-             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, o_save, stream_dtype(cfg)), _ptr(lib, dx), _ptr(lib, ws),
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, o_save, torch.uint8), _ptr(lib, dx), _ptr(lib, ws),
              _stream(lib, x))
     return dx
 

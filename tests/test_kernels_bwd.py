@@ -83,7 +83,7 @@ def test_mhsa_bwd(backend, dtype):
             continue  # fp32-stream attention backward keeps 7 [T][24] fp32 arrays in LDS: T <= 224
 
         def bwd(cs, G, x, dy, ws):
-            o = torch.empty_like(x)
+            o = ops.mhsa_save(cs.lib, cs.cfg, x.device)
             ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=o)
             return ops.mhsa_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, o, ws)
 

@@ -26,7 +26,7 @@ def main():
     dy = torch.randn(B, 129, 251, 96, device=dev).bfloat16()
     G = torch.zeros_like(flat)
     ws = ops.workspace(lib, cfg, dev)
-    o = torch.empty_like(x)
+    o = ops.mhsa_save(lib, cfg, dev)
     fns = {
         "fconv_fwd": lambda: ops.fconv_fwd(lib, cfg, flat, packed, 0, 0, x),
         "mhsa_fwd": lambda: ops.mhsa_fwd(lib, cfg, flat, packed, 0, x, o_save=o),
@@ -38,7 +38,7 @@ def main():
     }
     if name == "mhsa_bwd":
         fns["mhsa_fwd"]()
-    reader = getattr(lib, "nbss_phase_read_" + name)
+    reader = getattr(lib, "nbss_phase_read_" + name)  # (the single-pass bf16 attention backward shares mhsa_bwd's accumulators)
     reader.restype = C.c_int
     buf = (C.c_ulonglong * 32)()
     fns[name]()

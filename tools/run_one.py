@@ -24,7 +24,7 @@ def main():
     dy = torch.randn(B, 129, 251, 96, device=dev).bfloat16()
     G = torch.zeros_like(flat)
     ws = ops.workspace(lib, cfg, dev)
-    o = torch.empty_like(x)
+    o = ops.mhsa_save(lib, cfg, dev)
     fns = {
         "fconv_fwd": lambda: ops.fconv_fwd(lib, cfg, flat, packed, 0, 0, x),
         "full_fwd": lambda: ops.full_fwd(lib, cfg, flat, packed, 0, x),

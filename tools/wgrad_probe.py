@@ -25,7 +25,7 @@ def main():
     dy = torch.randn(B, 129, 251, 96, device=dev).bfloat16()
     G = torch.zeros_like(flat)
     ws = ops.workspace(lib, cfg, dev)
-    o = torch.empty_like(x)
+    o = ops.mhsa_save(lib, cfg, dev)
     fns = {
         "fconv": lambda: ops.fconv_bwd(lib, cfg, flat, G, packed, 0, 0, x, dy, ws),
         "full": lambda: ops.full_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws),
