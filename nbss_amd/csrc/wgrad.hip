@@ -580,24 +580,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     if (a.stats)
         for (int i = tid; i < 2 * a.NB; i += WG_THREADS) lnp[i] = i < a.NB ? a.gamma[i] : a.beta[i - a.NB];
 
-    f32x4 acc[NS];
-    float bsum[W3_BS], bflag[W3_BS];
+    f32x4 acc[NS], bacc[W3_BS];  // bacc: column sums of the dY tiles (bias gradients) = dY^T * ones, on the otherwise idle MFMA pipe
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = F32X4_ZERO;
 #pragma unroll
-    for (int s = 0; s < W3_BS; ++s) bsum[s] = 0.f;
+    for (int s = 0; s < W3_BS; ++s) bacc[s] = F32X4_ZERO;
+    Frag<T> ones;
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) frag_set(ones, jq, 1.0f);
     const bool do_bias = a.dbias != nullptr;
     const T* Ag = reinterpret_cast<const T*>(a.A);
     const T* Bg = reinterpret_cast<const T*>(a.B);
     const int pA = ncolsA / 8, pB = ncolsB / 8;
-    const int nvA = W3_KC * pA, nvec = nvA + rowsB * pB;
+    const int nvA = W3_KC * pA, nvec = nvA + rowsB * pB;  // 16-byte vectors of the dY image / of both images
     const int nfirst = ngrp * mtiles, ntot = nfirst * ntiles;  // tile tl = nt * nfirst + (g * mtiles + mt)
 
     // per-slot offsets (elements, inside a buffer) of this lane's transposing reads
     int oa[NS], ob[NS];
     const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
-#pragma unroll
-    for (int s = 0; s < W3_BS; ++s) bflag[s] = (a.dbias != nullptr && s * WG_WAVES + w < nfirst) ? 1.f : 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int tl = s * WG_WAVES + w;
@@ -610,54 +610,65 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
             ob[s] = imgA + ((q0 / ng) * rs + trow) * ldb + g * ng + q0 % ng;  // tap = q0 / ng: image row k + tap rs holds the token tap - h steps away
         }
     }
-    // per-vector descriptors of this thread (chunk independent): chunk-relative row, global element offset, LDS offset
-    int vkk[W3_MAXV], vtok[W3_MAXV], vgo[W3_MAXV], vdst[W3_MAXV];
-    bool vt1[W3_MAXV];  // second frame of an F-mode pair
+    // Per-vector descriptors (chunk independent).  Slot u is an A slot for EVERY thread when u < UA and a B slot otherwise (a few
+    // lanes of the last slot of each kind idle), so the source pointer of a slot is wave-uniform: the load is "scalar base +
+    // 32-bit lane offset" with no per-lane 64-bit address arithmetic.  Offsets are made non-negative against the first image row.
     const int rsA = a.a_gw ? a.a_gw : a.lda, rsB = a.b_gw ? a.b_gw : a.ldb;  // global row strides
-    bool vA[W3_MAXV], vok[W3_MAXV];
+    const int UA = cdiv(nvA, WG_THREADS);
+    int vkk[W3_MAXV], vtok[W3_MAXV], vdst[W3_MAXV];
+    unsigned vgo[W3_MAXV];
+    bool vt1[W3_MAXV], vok[W3_MAXV];
+    const int tokB0 = fmode ? -h * a.T : -h;  // token offset of image row 0 of X
 #pragma unroll
     for (int u = 0; u < W3_MAXV; ++u) {
-        const int v = tid + u * WG_THREADS;
-        vok[u] = v < nvec;
-        vA[u] = v < nvA;
-        if (vA[u]) {
-            const int k = v / pA, c8 = v % pA, col = acols0 + 8 * c8;
-            vkk[u] = fmode ? k / 2 : k; vt1[u] = fmode && (k & 1); vtok[u] = fmode ? (k / 2) * a.T + (k & 1) : k;
-            vgo[u] = vtok[u] * rsA + (a.a_gw ? (col / a.a_gw) * a.a_gs + col % a.a_gw : col); vdst[u] = k * lda + 8 * c8;
-        } else {
-            const int v2 = vok[u] ? v - nvA : 0, j = v2 / pB, c8 = v2 % pB, col = bcols0 + 8 * c8;
-            vkk[u] = fmode ? j / 2 - h : j - h; vt1[u] = fmode && (j & 1); vtok[u] = fmode ? (j / 2 - h) * a.T + (j & 1) : j - h;
-            vgo[u] = vtok[u] * rsB + (a.b_gw ? (col / a.b_gw) * a.b_gs + col % a.b_gw : col); vdst[u] = imgA + j * ldb + 8 * c8;
-        }
+        const bool isA = u < UA;
+        const int v = tid + (isA ? u : u - UA) * WG_THREADS;
+        vok[u] = isA ? v < nvA : v < nvec - nvA;
+        const int pp = isA ? pA : pB, r = vok[u] ? v / pp : 0, c8 = vok[u] ? v % pp : 0;
+        const int col = (isA ? acols0 : bcols0) + 8 * c8, gw = isA ? a.a_gw : a.b_gw, gs = isA ? a.a_gs : a.b_gs, rsg = isA ? rsA : rsB;
+        const int hh = isA ? 0 : h;
+        vkk[u] = fmode ? r / 2 - hh : r - hh;
+        vt1[u] = fmode && (r & 1);
+        vtok[u] = fmode ? (r / 2 - hh) * a.T + (r & 1) : r - hh;
+        vgo[u] = (unsigned)((vtok[u] - (isA ? 0 : tokB0)) * rsg + (gw ? (col / gw) * gs + col % gw : col));
+        vdst[u] = (isA ? 0 : imgA) + r * (isA ? lda : ldb) + 8 * c8;
     }
     const int cpr = cdiv(a.T, W3_KC);
     const int nfc = cdiv(a.F, W3_KC / 2), ntp = cdiv(a.T, 2);  // F mode: frequency chunks and frame pairs per batch item
     const int nchunks = fmode ? (a.Ntok / (a.F * a.T)) * ntp * nfc : a.taps > 1 ? (a.Ntok / a.T) * cpr : cdiv(a.Ntok, W3_KC);
+    // chunk index as a mixed-radix counter (c0 < r0, c1 < r1, c2), advanced by gridDim.x without divisions
+    const int r0 = fmode ? nfc : a.taps > 1 ? cpr : 1, r1 = fmode ? ntp : 1;
+    const int G = gridDim.x, d0 = G % r0, d1 = (G / r0) % r1, d2 = G / r0 / r1;
+    int c0 = (int)blockIdx.x % r0, c1 = ((int)blockIdx.x / r0) % r1, c2 = (int)blockIdx.x / r0 / r1;
     u32x4 pre[W3_MAXV];
     float pmu[W3_MAXV], prs[W3_MAXV];
-    auto prefetch = [&](int ch) {
+    auto prefetch = [&]() {  // the chunk the counter points at; then advance the counter
         long nbase;
-        int lo, lim;  // chunk-relative rows (F mode: frequencies) lo <= k < lim exist
+        int lo, span;  // chunk-relative rows (F mode: frequencies) lo <= k < lo + span exist
         bool t1ok = true;  // F mode: the second frame of the pair exists
         if (fmode) {
-            const int bb = ch / (ntp * nfc), rem = ch % (ntp * nfc), t0 = 2 * (rem / nfc), f0 = (rem % nfc) * (W3_KC / 2);
-            nbase = ((long)bb * a.F + f0) * a.T + t0; lo = -f0; lim = a.F - f0; t1ok = t0 + 1 < a.T;
+            const int t0 = 2 * c1, f0 = c0 * (W3_KC / 2);
+            nbase = ((long)c2 * a.F + f0) * a.T + t0; lo = -f0; span = a.F; t1ok = t0 + 1 < a.T;
         } else if (a.taps > 1) {
-            const int row = ch / cpr, t0 = (ch % cpr) * W3_KC;
-            nbase = (long)row * a.T + t0; lo = -t0; lim = a.T - t0;
+            const int t0 = c0 * W3_KC;
+            nbase = ((long)c2 * r1 + c1) * a.T + t0; lo = -t0; span = a.T;
         } else {
-            nbase = (long)ch * W3_KC; lo = 0; lim = a.Ntok - (int)nbase;
+            nbase = ((long)c2 * r1 + c1) * W3_KC; lo = 0; span = a.Ntok - (int)nbase;
         }
+        c0 += d0; c1 += d1; c2 += d2;
+        if (c0 >= r0) { c0 -= r0; ++c1; }
+        if (c1 >= r1) { c1 -= r1; ++c2; }
         const T* Ab = Ag + nbase * rsA;
-        const T* Bb = Bg + nbase * rsB;
+        const T* Bb = Bg + (nbase + tokB0) * rsB;
         const float* sb = a.stats ? a.stats + 2 * nbase : nullptr;
 #pragma unroll
         for (int u = 0; u < W3_MAXV; ++u) {
             pre[u] = (u32x4){0, 0, 0, 0};
             pmu[u] = 0.f; prs[u] = 0.f;
-            if (!vok[u] || vkk[u] < lo || vkk[u] >= lim || (vt1[u] && !t1ok) || (a.dbg & 4)) continue;
-            pre[u] = *reinterpret_cast<const u32x4*>((vA[u] ? Ab : Bb) + vgo[u]);
-            if (!vA[u] && sb) { pmu[u] = sb[2 * vtok[u]]; prs[u] = sb[2 * vtok[u] + 1]; }
+            if (!vok[u] || (unsigned)(vkk[u] - lo) >= (unsigned)span || (vt1[u] && !t1ok) || (a.dbg & 4)) continue;
+            const T* sbase = u < UA ? Ab : Bb;  // wave-uniform
+            pre[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(sbase) + (size_t)(vgo[u] * 2u));
+            if (u >= UA && sb) { pmu[u] = sb[2 * vtok[u]]; prs[u] = sb[2 * vtok[u] + 1]; }
         }
     };
     auto stash = [&](T* buf) {
@@ -665,12 +676,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         for (int u = 0; u < W3_MAXV; ++u) {
             if (!vok[u] || (a.dbg & 8)) continue;
             u32x4 x = pre[u];
-            if (!vA[u] && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
+            if (u >= UA && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
                 float f[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
                 float gm[8], bt[8];
-                const int col = vgo[u] - vtok[u] * rsB;  // (LayerNorm operands are always plain row-major)
+                const int col = (int)vgo[u] - (vtok[u] - tokB0) * rsB;  // (LayerNorm operands are always plain row-major)
                 load8(lnp + col, gm);
                 load8(lnp + a.NB + col, bt);
 #pragma unroll
@@ -683,17 +694,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     };
 
     int ch = blockIdx.x;
-    if (ch < nchunks) prefetch(ch);
+    if (a.dbg & 16) return;  // probe: launch + prologue only
+    if (ch < nchunks) prefetch();
     lds_barrier();  // zero fill done
     int b = 0;
     for (; ch < nchunks; ch += gridDim.x) {
         T* buf = base + (size_t)b * img;
         stash(buf);
         lds_barrier();
-        if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
+        if (ch + (int)gridDim.x < nchunks) prefetch();
         // software pipeline over the NS * KH (tile, k-half) steps: the operands of step i+1 are requested before step i's MFMA
         constexpr int KH = W3_KC / 32;
         Frag<T> fa[2], fb[2];
+        if (a.dbg & 2) { b ^= 1; continue; }  // probe: no MFMA section
         frag_load_tr(fa[0], buf + oa[0], lda);
         frag_load_tr(fb[0], buf + ob[0], ldb);
 #pragma unroll
@@ -705,12 +718,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
                 frag_load_tr(fb[cur ^ 1], buf + ob[s1] + kh1 * 32 * ldb, ldb);
             }
             acc[s] = mma(fa[cur], fb[cur], acc[s]);
-            if (s < W3_BS) {
-                float cs = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cs += frag_get(fa[cur], j);
-                bsum[s < W3_BS ? s : 0] += bflag[s < W3_BS ? s : 0] * cs;
-            }
+            if (s < W3_BS) bacc[s < W3_BS ? s : 0] = mma(fa[cur], ones, bacc[s < W3_BS ? s : 0]);
         }
         if (NBUF == 1) lds_barrier();
         else b ^= 1;
@@ -727,9 +735,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
             if (tl < ntot) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[s][r];
-                if (s < W3_BS && do_bias && tl < nfirst) {
-                    const float tsum = wave_sum16(bsum[s < W3_BS ? s : 0]);
-                    if (g4 == 0) pbias[tl * 16 + l15] = tsum;
+                if (s < W3_BS && do_bias && tl < nfirst && l15 == 0) {  // every column of bacc holds the sums: rows 4 g4 + r
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pbias[tl * 16 + 4 * g4 + r] = bacc[s < W3_BS ? s : 0][r];
                 }
             }
         }
@@ -749,10 +757,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
                     if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
                 }
             }
-            if (s < W3_BS && do_bias && nt == 0) {
-                const float tsum = wave_sum16(bsum[s < W3_BS ? s : 0]);
-                const int m = mt * 16 + l15;
-                if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
+            if (s < W3_BS && do_bias && nt == 0 && l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mt * 16 + 4 * g4 + r;
+                    if (m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, bacc[s < W3_BS ? s : 0][r]);
+                }
             }
         }
     }
@@ -828,7 +838,7 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
         const bool tmode3 = a.taps > 1 && a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0;
         const int kc3 = fmode3 ? 96 : 64, h3 = a.taps / 2, rowsB3 = kc3 + 2 * h3 * (fmode3 ? 2 : 1), nfirst3 = (all ? a.groups : 1) * mtiles;
         const size_t img3 = ((size_t)kc3 * tr_ld(ncA) + (size_t)rowsB3 * tr_ld(ncB)) * 2;
-        const int nvec3 = kc3 * (ncA / 8) + rowsB3 * (ncB / 8);
+        const int nvec3 = (cdiv(kc3 * (ncA / 8), WG_THREADS) + cdiv(rowsB3 * (ncB / 8), WG_THREADS)) * WG_THREADS;  // whole A slots + whole B slots
         const bool gm_ok = (!a.a_gw || a.a_gw % 8 == 0) && (!a.b_gw || (a.b_gw % 8 == 0 && !a.stats));
         if (gm_ok && (a.taps == 1 || tmode3 || fmode3) && nvec3 <= W3_MAXV * WG_THREADS && nfirst3 <= WG_WAVES * W3_BS &&
             2 * img3 + 2 * (size_t)a.NB * sizeof(float) <= 158 * 1024) {
