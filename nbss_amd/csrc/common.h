@@ -156,6 +156,38 @@ NBSS_DEV void store4(bf16_t* p, float a, float b, float c, float d) {
     u32x2 v = {pack2bf(a, b), pack2bf(c, d)};
     *reinterpret_cast<u32x2*>(p) = v;
 }
+// Streaming (non-temporal) variants for write-once tensors that nobody on this workgroup's XCD reads again soon (the wgrad
+// operands): they must not evict the x / dy rows the same kernel re-reads for every conv group / head from L2.
+NBSS_DEV void store4_nt(float* p, float a, float b, float c, float d) {
+    f32x4 v = {a, b, c, d};
+#ifdef NBSS_EMU
+    *reinterpret_cast<f32x4*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#endif
+}
+NBSS_DEV void store4_nt(bf16_t* p, float a, float b, float c, float d) {
+    u32x2 v = {pack2bf(a, b), pack2bf(c, d)};
+#ifdef NBSS_EMU
+    *reinterpret_cast<u32x2*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+#endif
+}
+NBSS_DEV void store1_nt(float* p, float a) {
+#ifdef NBSS_EMU
+    *p = a;
+#else
+    __builtin_nontemporal_store(a, p);
+#endif
+}
+NBSS_DEV void store1_nt(bf16_t* p, float a) {
+#ifdef NBSS_EMU
+    *p = f2bf(a);
+#else
+    __builtin_nontemporal_store(f2bf(a), p);
+#endif
+}
 NBSS_DEV void store1(float* p, float a) { *p = a; }
 NBSS_DEV void store1(bf16_t* p, float a) { *p = f2bf(a); }
 NBSS_DEV float load1(const float* p) { return *p; }

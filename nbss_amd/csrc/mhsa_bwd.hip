@@ -41,6 +41,13 @@ NBSS_DEV void store_row24(T* __restrict__ row, const f32x4& lo, const f32x4& hi)
 }
 
 template <class T>
+NBSS_DEV void store_row24_nt(T* __restrict__ row, const f32x4& lo, const f32x4& hi) {  // streaming: the dqkv wgrad operand
+    const int g4 = lane_id() >> 4;
+    store4_nt(row + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
+    if (g4 < 2) store4_nt(row + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
+}
+
+template <class T>
 NBSS_DEV void store_col24(T* __restrict__ base, int tp, int t, const f32x4& lo, const f32x4& hi) {  // transposed [24][tp]
     const int g4 = lane_id() >> 4;
 #pragma unroll
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                     dq[si][0][r] *= rs_dh;
                     dq[si][1][r] *= rs_dh;
                 }
-                store_row24<T>(dqkv_row(0 * MB_HEADS + head, n0 + tt[si]), dq[si][0], dq[si][1]);
+                store_row24_nt<T>(dqkv_row(0 * MB_HEADS + head, n0 + tt[si]), dq[si][0], dq[si][1]);
             }
         }
         PHASE(6);
@@ -409,8 +416,8 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                     dk[si][0][r] *= 0.6931471805599453f;  // Q' carries log2(e)/sqrt(dh): dk = dS^T q / sqrt(dh) = dS^T Q' ln2
                     dk[si][1][r] *= 0.6931471805599453f;
                 }
-                store_row24<T>(dqkv_row(1 * MB_HEADS + head, n0 + tt[si]), dk[si][0], dk[si][1]);
-                store_row24<T>(dqkv_row(2 * MB_HEADS + head, n0 + tt[si]), dv[si][0], dv[si][1]);
+                store_row24_nt<T>(dqkv_row(1 * MB_HEADS + head, n0 + tt[si]), dk[si][0], dk[si][1]);
+                store_row24_nt<T>(dqkv_row(2 * MB_HEADS + head, n0 + tt[si]), dv[si][0], dv[si][1]);
             }
         }
         PHASE(8);

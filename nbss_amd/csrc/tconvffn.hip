@@ -444,8 +444,8 @@ NBSS_DEV void store_op(T* __restrict__ op, size_t n, bool valid, int gr, size_t 
     // ([N][FFN], 48-byte pieces of a 384-byte row per group) made every store a partial-line write: the kernel fetched 1 GB
     // from HBM per launch (FETCH_SIZE) for 0.2 GB of algorithmic reads.  The fp32 stream keeps [N][FFN] (generic wgrad kernel).
     T* r = TF_OPS_GM(T) ? op + ((size_t)gr * ntok + n) * TF_CG : op + n * TF_FFN + gr * TF_CG;
-    store4(r + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
-    if (g4 < 2) store4(r + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
+    store4_nt(r + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
+    if (g4 < 2) store4_nt(r + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
 }
 
 // sum over the 16 lanes that share (lane>>4): per-channel reduction over the frames of a strip
