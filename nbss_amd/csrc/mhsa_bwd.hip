@@ -168,17 +168,46 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     auto dqkv_row = [&](int grp, size_t n) -> T* {
         return TR ? dqkv + ((size_t)grp * ntok + n) * MB_DH : dqkv + n * (3 * MB_H) + grp * MB_DH;
     };
+    // bf16: LN(x) and dy fragments of the wave's strips stay in registers for all four heads (48 VGPRs) instead of being re-read
+    // and re-normalised per head (PMC: the per-head re-reads of x, dy missed L2 — 3 GB fetched per launch for 0.6 GB of inputs)
+    constexpr bool DYREG = sizeof(T) == 2;
+    Frag<T> uf[MB_NSW][MB_KS], dr[MB_NSW][MB_KS];
+    if (DYREG) {
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si)
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                if (tv[si]) {
+                    frag_load(uf[si][ks], xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
+                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
+                } else {
+                    frag_zero(uf[si][ks]);
+                    frag_zero(dr[si][ks]);
+                }
+            }
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si)
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                float gm[8], bt[8];
+                load8(lp.p[P_MH_LN_W] + ks * 32 + 8 * g4, gm);
+                load8(lp.p[P_MH_LN_B] + ks * 32 + 8 * g4, bt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    frag_set(uf[si][ks], j, tv[si] ? (frag_get(uf[si][ks], j) - smean[si]) * srstd[si] * gm[j] + bt[j] : bt[j]);
+            }
+    }
     for (int head = 0; head < MB_HEADS; ++head) {
         Frag<T> qf[MB_NSW], dof[MB_NSW];
         float Dv[MB_NSW];
         // ---------------- stage A: Q', K, V, dO of this head ----------------
         // all global reads of the head first (x, dy, saved O), ahead of this head's dqkv stores in the vmcnt queue
-        Frag<T> uf[MB_NSW][MB_KS], dr[MB_NSW][MB_KS];
         float o0[MB_NSW][4], o1[MB_NSW][4], lsev[MB_NSW];
 #pragma unroll
         for (int si = 0; si < MB_NSW; ++si) {
 #pragma unroll
             for (int ks = 0; ks < MB_KS; ++ks) {
+                if (DYREG) continue;
                 if (tv[si]) {
                     frag_load(uf[si][ks], xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
                     frag_load(dr[si][ks], dyb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
@@ -200,6 +229,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         for (int si = 0; si < MB_NSW; ++si)
 #pragma unroll
             for (int ks = 0; ks < MB_KS; ++ks) {  // LN(x) in place of x (rebuilt per head from the row statistics)
+                if (DYREG) continue;
                 float gm[8], bt[8];
                 load8(lnp + ks * 32 + 8 * g4, gm);
                 load8(lnp + MB_H + ks * 32 + 8 * g4, bt);
