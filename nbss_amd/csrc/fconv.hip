@@ -53,8 +53,9 @@ NBSS_DEV void ln_row_inplace(T* row, const float* __restrict__ gamma, const floa
                (v[i + 2] - mean) * rstd * gamma[i + 2] + beta[i + 2], (v[i + 3] - mean) * rstd * gamma[i + 3] + beta[i + 3]);
 }
 
-template <class T, int TT>
-__global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+// GPW = conv groups per wave: 2 with 4 waves (fp32), 1 with 8 waves (bf16: two 8-wave workgroups per CU)
+template <class T, int TT, int GPW>
+__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? 4 : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ cb, const float* __restrict__ slope,
                                                         const T* __restrict__ Wp, const T* __restrict__ x, T* __restrict__ y) {
     NBSS_LDS(smem);
@@ -86,14 +87,14 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
     lds_barrier();
 
     // ---- phase 2: grouped conv on the matrix cores -----------------------------------------
-    f32x4 acc[2][TT][FC_MTF_MAX];
-    Frag<T> a[2][FC_KS];
+    f32x4 acc[GPW][TT][FC_MTF_MAX];
+    Frag<T> a[GPW][FC_KS];
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
+    for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
-        for (int ks = 0; ks < FC_KS; ++ks) wfrag_load(a[gi][ks], Wp, 2 * w + gi, FC_KS, ks);
+        for (int ks = 0; ks < FC_KS; ++ks) wfrag_load(a[gi][ks], Wp, GPW * w + gi, FC_KS, ks);
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
+    for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
         if (ft < mtf) {
             const int f = ft * 16 + l15;
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int ch0 = (2 * w + gi) * FC_CG;
+            for (int gi = 0; gi < GPW; ++gi) {
+                const int ch0 = (GPW * w + gi) * FC_CG;
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256) void fconv_fwd_kernel(nbss_cfg c, const float*
     // ---- phase 3: bias + PReLU -> LDS [f][tt][H] ---------------------------------------------
     if (g4 < 3) {
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int ch = (2 * w + gi) * FC_CG + 4 * g4;
+        for (int gi = 0; gi < GPW; ++gi) {
+            const int ch = (GPW * w + gi) * FC_CG + 4 * g4;
             float bb[4], sl[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { bb[r] = cb[ch + r]; sl[r] = slope[ch + r]; }
@@ -480,7 +481,7 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T, int TT>
+template <class T, int TT, int GPW>
 static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
@@ -490,15 +491,15 @@ static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, in
     const float* cb = P + param_off(c, layer, which ? P_FC2_B : P_FC1_B);
     const float* sl = P + param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU);
     const T* Wp = (const T*)packed + pack_off(c, layer, which ? K_FC2 : K_FC1);
-    int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT>), lds);
+    int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT, GPW>), lds);
     if (e) return e;
-    dim3 grid(c.B * cdiv(c.T, TT)), block(256);
+    dim3 grid(c.B * cdiv(c.T, TT)), block(64 * FC_G / GPW);
     ProfScope ps(PK_FCONV_F, st);
-    NBSS_LAUNCH((fconv_fwd_kernel<T, TT>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
+    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 int fconv_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
-    if (c.dtype == NBSS_BF16) return fconv_fwd_t<bf16_t, 2>(c, P, packed, layer, which, x, y, st);
-    return fconv_fwd_t<float, 1>(c, P, packed, layer, which, x, y, st);
+    if (c.dtype == NBSS_BF16) return fconv_fwd_t<bf16_t, 2, 1>(c, P, packed, layer, which, x, y, st);
+    return fconv_fwd_t<float, 1, 2>(c, P, packed, layer, which, x, y, st);
 }
