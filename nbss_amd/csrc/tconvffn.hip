@@ -97,11 +97,11 @@ struct StageSrcs {  // named members, not an array: a select between array eleme
         else return p7;
     }
 };
-template <class T, int NSRC, int I>
+template <class T, int NSRC, int I, int NTHR>
 NBSS_DEV void stage_load1(u32x4& r, const StageSrcs<T>& srcs, size_t goff) {
     constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN;  // vectors per source (6 fragments)
-    constexpr int s0 = (I * 512) / VPS < NSRC ? (I * 512) / VPS : NSRC - 1;  // round I touches at most 3 consecutive sources
-    const int v = (int)threadIdx.x + I * 512;
+    constexpr int s0 = (I * NTHR) / VPS < NSRC ? (I * NTHR) / VPS : NSRC - 1;  // round I touches at most 4 consecutive sources
+    const int v = (int)threadIdx.x + I * NTHR;
     int off = v - s0 * VPS;
     const T* p = srcs.template get<s0>();
     if constexpr (s0 + 1 < NSRC) {
@@ -112,24 +112,28 @@ NBSS_DEV void stage_load1(u32x4& r, const StageSrcs<T>& srcs, size_t goff) {
         const T* q = srcs.template get<s0 + 2>();
         if (off >= VPS) { p = q; off -= VPS; }
     }
+    if constexpr (s0 + 3 < NSRC) {
+        const T* q = srcs.template get<s0 + 3>();
+        if (off >= VPS) { p = q; off -= VPS; }
+    }
     if (v < NSRC * VPS) r = *reinterpret_cast<const u32x4*>(p + goff + (size_t)off * VN);
 }
-template <class T, int NSRC, int I, int NV>
+template <class T, int NSRC, int I, int NV, int NTHR>
 NBSS_DEV void stage_loads(u32x4 (&r)[NV], const StageSrcs<T>& srcs, size_t goff) {
     if constexpr (I < NV) {
-        stage_load1<T, NSRC, I>(r[I], srcs, goff);
-        stage_loads<T, NSRC, I + 1, NV>(r, srcs, goff);
+        stage_load1<T, NSRC, I, NTHR>(r[I], srcs, goff);
+        stage_loads<T, NSRC, I + 1, NV, NTHR>(r, srcs, goff);
     }
 }
-template <class T, int NSRC>
+template <class T, int NSRC, int NTHR = 512>
 struct StageRegs {
-    static constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN, NV = (NSRC * VPS + 511) / 512;
+    static constexpr int VN = 16 / sizeof(T), VPS = 6 * 512 / VN, NV = (NSRC * VPS + NTHR - 1) / NTHR;
     u32x4 r[NV];
-    NBSS_DEV void load(const StageSrcs<T>& srcs, size_t goff) { stage_loads<T, NSRC, 0, NV>(r, srcs, goff); }
+    NBSS_DEV void load(const StageSrcs<T>& srcs, size_t goff) { stage_loads<T, NSRC, 0, NV, NTHR>(r, srcs, goff); }
     NBSS_DEV void store(T* __restrict__ wl) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int v = (int)threadIdx.x + i * 512;
+            const int v = (int)threadIdx.x + i * NTHR;
             if (v < NSRC * VPS) *reinterpret_cast<u32x4*>(wl + (size_t)v * VN) = r[i];
         }
     }
@@ -159,19 +163,19 @@ NBSS_DEV void u_frag_ks(Frag<T>& f, const T* __restrict__ xr, bool valid, float 
 }
 
 // one grouped conv for the wave's strips: out[si][half] (C tiles: lane = frame, rows = 4 channels)
-template <class T>
-NBSS_DEV void conv_group(const T* __restrict__ Wc, const T* __restrict__ hin, int w, f32x4 (&out)[TF_NSW][2]) {
+template <class T, int NSW>
+NBSS_DEV void conv_group(const T* __restrict__ Wc, const T* __restrict__ hin, int w, f32x4 (&out)[NSW][2]) {
     const int l15 = lane_id() & 15;
-    Frag<T> bq[TF_NSW][TF_CKS];
+    Frag<T> bq[NSW][TF_CKS];
 #pragma unroll
-    for (int si = 0; si < TF_NSW; ++si) conv_bfrags<T>(hin, (w * TF_NSW + si) * 16 + l15, bq[si]);
+    for (int si = 0; si < NSW; ++si) conv_bfrags<T>(hin, (w * NSW + si) * 16 + l15, bq[si]);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         Frag<T> a[TF_CKS];
 #pragma unroll
         for (int ks = 0; ks < TF_CKS; ++ks) wfrag_load(a[ks], Wc, half, TF_CKS, ks);
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
             f32x4 acc = F32X4_ZERO;
 #pragma unroll
             for (int ks = 0; ks < TF_CKS; ++ks) acc = mma(a[ks], bq[si][ks], acc);
@@ -194,15 +198,17 @@ NBSS_DEV void store_rows(T* __restrict__ h, int t, bool valid, const f32x4& lo, 
     }
 }
 
-template <class T>
-__global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, int layer, const T* __restrict__ W1,
+// NSW = 16-frame strips per wave: 2 with 8 waves (fp32), 1 with 16 waves (bf16: 4 waves per SIMD to hide the LDS / MFMA chains)
+template <class T, int NSW>
+__global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, int layer, const T* __restrict__ W1,
                                                            const T* __restrict__ Wc1, const T* __restrict__ Wc2, const T* __restrict__ Wc3,
                                                            const T* __restrict__ W2, const T* __restrict__ x, T* __restrict__ y) {
     NBSS_LDS(smem);
     T* ha = reinterpret_cast<T*>(smem);                    // [TP+2][24]
     T* hb = ha + (TF_TP + 2) * TF_CG;                      // [TP+2][24]
-    float* red = reinterpret_cast<float*>(hb + (TF_TP + 2) * TF_CG);  // [8 waves][2]
-    T* wl0 = reinterpret_cast<T*>(red + 16);  // 2 x this group's weights: W1 | conv1 | conv2 | conv3 | W2, 6 fragments each
+    constexpr int NW = 16 / NSW, NTHR = 64 * NW;
+    float* red = reinterpret_cast<float*>(hb + (TF_TP + 2) * TF_CG);  // [NW waves][2]
+    T* wl0 = reinterpret_cast<T*>(red + 2 * NW);  // 2 x this group's weights: W1 | conv1 | conv2 | conv3 | W2, 6 fragments each
     float* prm = reinterpret_cast<float*>(wl0 + (sizeof(T) == 2 ? 2 : 1) * 30 * 512);  // [7][FFN]: b1 cb1 cb2 cb3 gnw gnb b2 (per-lane global reads of these sat in every dependency chain)
     const int T_ = c.T;
     const int bf = blockIdx.x;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         store1(hb + (size_t)(TF_TP + 1) * TF_CG + tid, 0.f);
     }
 
-    Frag<T> u[TF_NSW][TF_KS];
+    Frag<T> u[NSW][TF_KS];
     {
         float gam[TF_KS][8], bet[TF_KS][8];
 #pragma unroll
@@ -250,35 +256,35 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
                 bet[ks][j] = lnb[ks * 32 + 8 * g4 + j];
             }
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
-            const int t = (w * TF_NSW + si) * 16 + l15;
+        for (int si = 0; si < NSW; ++si) {
+            const int t = (w * NSW + si) * 16 + l15;
             ln_strip_tf<T>(xb + (size_t)t * TF_H, t < T_, gam, bet, u[si]);
         }
     }
-    f32x4 yacc[TF_NSW][TF_H / 16];
+    f32x4 yacc[NSW][TF_H / 16];
 #pragma unroll
-    for (int si = 0; si < TF_NSW; ++si)
+    for (int si = 0; si < NSW; ++si)
 #pragma unroll
         for (int mt = 0; mt < TF_H / 16; ++mt) yacc[si][mt] = F32X4_ZERO;
 
-    int tt[TF_NSW];
-    bool tv[TF_NSW];
+    int tt[NSW];
+    bool tv[NSW];
 #pragma unroll
-    for (int si = 0; si < TF_NSW; ++si) {
-        tt[si] = (w * TF_NSW + si) * 16 + l15;
+    for (int si = 0; si < NSW; ++si) {
+        tt[si] = (w * NSW + si) * 16 + l15;
         tv[si] = tt[si] < T_;
     }
     const int d0 = 4 * g4, d1 = 16 + 4 * g4;
     const bool v1 = g4 < 2;  // second tile holds channels 16..23 only
 
-    constexpr int FVN = 16 / sizeof(T), FVPF = 512 / FVN, FNV2 = (6 * FVPF + 511) / 512;  // W2: 6 strided fragments
-    StageRegs<T, 4> fw;
+    constexpr int FVN = 16 / sizeof(T), FVPF = 512 / FVN, FNV2 = (6 * FVPF + NTHR - 1) / NTHR;  // W2: 6 strided fragments
+    StageRegs<T, 4, NTHR> fw;
     u32x4 fw2[FNV2];
     const StageSrcs<T> fsrc = {W1, Wc1, Wc2, Wc3, nullptr, nullptr, nullptr, nullptr};
     auto fwd_wloads = [&](int g) {
 #pragma unroll
         for (int i = 0; i < FNV2; ++i) {  // W2: one fragment per output tile, strided by the group count
-            const int v = tid + i * 512, mt = v / FVPF, off = v % FVPF;
+            const int v = tid + i * NTHR, mt = v / FVPF, off = v % FVPF;
             if (v < 6 * FVPF) fw2[i] = *reinterpret_cast<const u32x4*>(W2 + (size_t)(mt * TF_G + g) * 512 + (size_t)off * FVN);
         }
         fw.load(fsrc, (size_t)g * 6 * 512);
@@ -287,13 +293,13 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         fw.store(dst);
 #pragma unroll
         for (int i = 0; i < FNV2; ++i) {
-            const int v = tid + i * 512;
+            const int v = tid + i * NTHR;
             if (v < 6 * FVPF) *reinterpret_cast<u32x4*>(dst + 24 * 512 + (size_t)v * FVN) = fw2[i];
         }
     };
     for (int gr = 0; gr < TF_G; ++gr) {
         const int cbase = gr * TF_CG;
-        f32x4 ct[TF_NSW][2];
+        f32x4 ct[NSW][2];
         // the group's 30 weight fragments go through LDS once per workgroup (8 waves share them; the packed buffer is
         // regularly evicted from L2 by the activation traffic, and per-wave global fragment loads sat in every MFMA chain).
         // Two LDS buffers: group g+1's fragments are requested here and written to the other buffer at the end of group g.
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
 #pragma unroll
             for (int ks = 0; ks < TF_KS; ++ks) lfrag<T>(a[ks], wl, half * 3 + ks);
 #pragma unroll
-            for (int si = 0; si < TF_NSW; ++si) {
+            for (int si = 0; si < NSW; ++si) {
                 f32x4 acc = F32X4_ZERO;
 #pragma unroll
                 for (int ks = 0; ks < TF_KS; ++ks) acc = mma(a[ks], u[si][ks], acc);
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
             }
         }
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f(ct[si][0][r] + b1[cbase + d0 + r]);
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         // (b) h2 = SiLU(gconv1(h1)) -> hb
         conv_group<T>(wl + 6 * 512, ha, w, ct);
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f(ct[si][0][r] + cb1[cbase + d0 + r]);
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         conv_group<T>(wl + 12 * 512, hb, w, ct);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = round_to(ct[si][0][r] + cb2[cbase + d0 + r], x);
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         lds_barrier();
         float ts1 = 0.f, ts2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NW; ++i) {
             ts1 += red[2 * i];
             ts2 += red[2 * i + 1];
         }
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         const float var = fmaxf(ts2 / cnt - mean * mean, 0.f);
         const float rstd = rsqrtf(var + 1e-5f);
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f((ct[si][0][r] - mean) * rstd * gnw[cbase + d0 + r] + gnb[cbase + d0 + r]);
@@ -386,9 +392,9 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
         lds_barrier();
         // (d) h5 = SiLU(gconv3(h4)) stays in registers and feeds y += W2[:, group] h5
         conv_group<T>(wl + 18 * 512, ha, w, ct);
-        Frag<T> h5[TF_NSW];
+        Frag<T> h5[NSW];
 #pragma unroll
-        for (int si = 0; si < TF_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f(ct[si][0][r] + cb3[cbase + d0 + r]);
@@ -401,14 +407,14 @@ __global__ __launch_bounds__(512, TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg 
             Frag<T> a;
             lfrag<T>(a, wl, 24 + mt);
 #pragma unroll
-            for (int si = 0; si < TF_NSW; ++si) yacc[si][mt] = mma(a, h5[si], yacc[si][mt]);
+            for (int si = 0; si < NSW; ++si) yacc[si][mt] = mma(a, h5[si], yacc[si][mt]);
         }
         if (DB && gr + 1 < TF_G) fwd_wstore(wl0 + (size_t)((gr + 1) & 1) * 30 * 512);  // last read two barriers ago
         lds_barrier();  // ha / hb / red are rewritten by the next group; the other weight buffer is complete
     }
 
 #pragma unroll
-    for (int si = 0; si < TF_NSW; ++si) {
+    for (int si = 0; si < NSW; ++si) {
         if (tv[si]) {
 #pragma unroll
             for (int mt = 0; mt < TF_H / 16; ++mt) {
@@ -1003,19 +1009,19 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T>
+template <class T, int NSW>
 static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (16 + 7 * TF_FFN) * sizeof(float) + (size_t)(sizeof(T) == 2 ? 2 : 1) * 30 * 512 * sizeof(T);
+    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (32 + 7 * TF_FFN) * sizeof(float) + (size_t)(sizeof(T) == 2 ? 2 : 1) * 30 * 512 * sizeof(T);
     const T* pk = (const T*)packed;
-    dim3 grid(c.B * c.F), block(512);
+    dim3 grid(c.B * c.F), block(64 * 16 / NSW);
     ProfScope ps(PK_TCF_F, st);
-    NBSS_LAUNCH((tconvffn_fwd_kernel<T>), grid, block, lds, st, c, lp, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
+    NBSS_LAUNCH((tconvffn_fwd_kernel<T, NSW>), grid, block, lds, st, c, lp, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
                 pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W2), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float>(c, P, packed, layer, x, y, st);
+    return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t, 1>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float, 2>(c, P, packed, layer, x, y, st);
 }
