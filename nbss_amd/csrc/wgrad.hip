@@ -7,15 +7,19 @@
 // (b,t).  X may be LayerNorm(x) applied on the fly from the per-token (mean, rstd) the data-gradient
 // kernels emit, so the normalised tensor is never materialised.
 //
-// One workgroup (8 waves) owns ALL output tiles of a problem (of one group for LinearGroup) and contracts its
-// share of 32-token chunks: full operand rows are fetched once (16-byte loads where the width allows), a thread
-// transposes a 4-token x 4|8-channel block in registers and writes 8-byte rows into the TRANSPOSED LDS images
-// ([column][32 tokens], 80-byte rows: conflict-free 16-byte fragment reads), so MFMA A/B fragments (K = tokens) are
-// single ds_read_b128's.  Up to 14 C tiles per wave accumulate in registers across all chunks and are flushed with
-// atomicAdd into the fp32 gradient buffer; column sums of dY (the bias gradients) ride along.
-// r01 history (profiles/): per-group workgroups re-read every row 8x in 48-byte pieces and dense problems re-staged the
-// operands once per 32-tile block (27 ms/step); runtime integer divisions in the staging loop (-3 ms when hoisted);
-// a register prefetch across the barrier spilled and was slower (26.8 vs 24.4 ms/step).
+// Two kernels:
+//  * wgrad_tr3_kernel (bf16 stream, every hot problem): 256 persistent workgroups of 8 waves; a workgroup owns ALL output
+//    tiles of the problem and contracts its share of 64-token chunks.  Operand rows are fetched as 16-byte pieces (register
+//    prefetch of the next chunk, double-buffered LDS) into ROW-major LDS images; MFMA fragments whose K dimension is the token
+//    axis come out of them through transposing reads (ds_read_b64_tr_b16), software-pipelined one tile ahead.  Chunks of a
+//    tapped problem are aligned so that a tap is a row offset inside ONE X image.  Accumulators stay in registers across
+//    all chunks; each workgroup stores its partial tiles and wgrad_reduce_kernel folds them into the fp32 gradient (the bias
+//    gradients — column sums of dY — are an extra MFMA against a ones fragment).
+//  * wgrad_kernel (fp32 stream, and shapes the first does not take: LinearGroup's F x F blocks, encoder/decoder): operands
+//    staged TRANSPOSED in LDS ([column][32 tokens], 80-byte rows: conflict-free 16-byte fragment reads), atomicAdd flush.
+// r01 history (profiles/README.md): per-group workgroups re-read every row 8x (27 ms/step at batch 8) -> 8-wave workgroups,
+// hoisted divisions (18) -> transposing reads (16.6) -> double buffering + LN affine through LDS (12.9) -> two-stage flush
+// (10.7) -> 64-token chunks / one X image (8.8) -> F-convs on the same kernel (8.1) -> pipelined reads (7.5).
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
@@ -230,318 +234,6 @@ NBSS_HD int tr_ld(int cols) {
     int ld = cols + 16;
     while (ld % 32 != 16) ld += 8;
     return ld;
-}
-
-__global__ __launch_bounds__(WG_THREADS) void wgrad_tr_kernel(WgradArgs a) {
-    NBSS_LDS(smem);
-    typedef bf16_t T;
-    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
-    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
-    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
-    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
-    const int tpg = mtiles * ntiles;
-    const bool per_group = gridDim.y > 1;
-    const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
-    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
-    const int lda = tr_ld(ncolsA), ldb = tr_ld(ncolsB);
-    T* Ai = reinterpret_cast<T*>(smem);                 // [KC][lda]
-    T* Bi = Ai + (size_t)WG_KC * lda;                   // [taps][KC][ldb]
-    for (int i = tid; i < (WG_KC * lda + a.taps * WG_KC * ldb) / 2; i += WG_THREADS) reinterpret_cast<uint32_t*>(Ai)[i] = 0u;
-
-    f32x4 acc[WG_TPW];
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
-    float bsum[WG_TPW];
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) bsum[s] = 0.f;
-    const bool do_bias = a.dbias != nullptr;
-    const T* Ag = reinterpret_cast<const T*>(a.A);
-    const T* Bg = reinterpret_cast<const T*>(a.B);
-    const int pA = ncolsA / 8, pB = ncolsB / 8, center = a.taps / 2;
-    const int nvA = WG_KC * pA, nvB = a.taps * WG_KC * pB;
-    const int nchunks = cdiv(a.Ntok, WG_KC);
-    const int ntot = ngrp * tpg;
-    const bool shifted = a.taps > 1;
-
-    // per-slot LDS addresses of this lane's transposing reads (chunk independent)
-    const T* pa[WG_TPW];
-    const T* pb[WG_TPW];
-    bool first_n[WG_TPW];
-    const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
-        const int tl = s * WG_WAVES + w;
-        pa[s] = Ai; pb[s] = Bi; first_n[s] = false;
-        if (tl < ntot) {
-            const int g = tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
-            pa[s] = Ai + (size_t)trow * lda + g * mg + mt * 16 + tcol;
-            int q0 = nt * 16 + tcol;
-            if (q0 >= nexp) q0 = 0;  // padding columns of the last tile: any valid address, discarded at the flush
-            pb[s] = Bi + ((size_t)(q0 / ng) * WG_KC + trow) * ldb + g * ng + q0 % ng;
-            first_n[s] = nt == 0;
-        }
-    }
-    lds_barrier();
-
-    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const int n0 = ch * WG_KC;
-        // ---- stage: 16-byte row pieces, global -> LDS, row-major ----
-        for (int v = tid; v < nvA; v += WG_THREADS) {
-            const int k = v / pA, c8 = v % pA, n = n0 + k;
-            u32x4 x = {0, 0, 0, 0};
-            if (n < a.Ntok) x = *reinterpret_cast<const u32x4*>(Ag + (size_t)n * a.lda + acols0 + 8 * c8);
-            *reinterpret_cast<u32x4*>(Ai + (size_t)k * lda + 8 * c8) = x;
-        }
-        for (int v = tid; v < nvB; v += WG_THREADS) {
-            const int tap = v / (WG_KC * pB), r2 = v % (WG_KC * pB), k = r2 / pB, c8 = r2 % pB, n = n0 + k, d = tap - center;
-            u32x4 x = {0, 0, 0, 0};
-            bool ok = n < a.Ntok;
-            if (ok && shifted) {
-                const int pos = a.shift_dim == 0 ? n % a.T : (n / a.T) % a.F, lim = a.shift_dim == 0 ? a.T : a.F;
-                ok = pos + d >= 0 && pos + d < lim;
-            }
-            if (ok) {
-                const size_t ns = (size_t)((long)n + (long)d * a.shift_stride);
-                x = *reinterpret_cast<const u32x4*>(Bg + ns * a.ldb + bcols0 + 8 * c8);
-                if (a.stats) {  // LayerNorm on the fly
-                    const float mu = a.stats[2 * ns], rs = a.stats[2 * ns + 1];
-                    float f[8];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = (f[e] - mu) * rs * a.gamma[bcols0 + 8 * c8 + e] + a.beta[bcols0 + 8 * c8 + e];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) x[i] = pack2bf(f[2 * i], f[2 * i + 1]);
-                }
-            }
-            *reinterpret_cast<u32x4*>(Bi + ((size_t)tap * WG_KC + k) * ldb + 8 * c8) = x;
-        }
-        lds_barrier();
-        // ---- MFMA: K = the 32 tokens of this chunk; operands through transposing reads ----
-#pragma unroll
-        for (int s = 0; s < WG_TPW; ++s) {
-            if (s * WG_WAVES + w < ntot) {
-                Frag<T> fa, fb;
-                frag_load_tr(fa, pa[s], lda);
-                frag_load_tr(fb, pb[s], ldb);
-                acc[s] = mma(fa, fb, acc[s]);
-                if (do_bias && first_n[s]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum[s] += frag_get(fa, j);
-                }
-            }
-        }
-        lds_barrier();
-    }
-
-    // ---- flush ----
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
-        const int tl = s * WG_WAVES + w;
-        if (tl < ntot) {
-            const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
-            const int q = nt * 16 + l15;
-            if (q < nexp) {
-                const int tap = q / ng, i = q % ng;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mt * 16 + 4 * g4 + r;
-                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
-                }
-            }
-            if (do_bias && nt == 0) {  // fragment lanes: channel = 16 mt + l15, the 4 lane groups hold disjoint tokens
-                const float tsum = wave_sum16(bsum[s]);
-                const int m = mt * 16 + l15;
-                if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
-            }
-        }
-    }
-}
-
-// Double-buffered variant of the transposing-read kernel: the 16-byte row pieces of chunk c+1 are requested into registers
-// before chunk c's MFMAs and written to the other LDS buffer afterwards, so HBM latency overlaps the contraction and there
-// is ONE barrier per chunk (buffer b is only rewritten after every wave has passed the next barrier).
-#define WG_MAXV 6  // 16-byte vectors a thread carries per chunk
-
-__global__ __launch_bounds__(WG_THREADS) void wgrad_tr2_kernel(WgradArgs a) {
-    NBSS_LDS(smem);
-    typedef bf16_t T;
-    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
-    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
-    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
-    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
-    const int tpg = mtiles * ntiles;
-    const bool per_group = gridDim.y > 1;
-    const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
-    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
-    const int lda = tr_ld(ncolsA), ldb = tr_ld(ncolsB);
-    const int img = WG_KC * lda + a.taps * WG_KC * ldb;  // elements per buffer
-    T* base = reinterpret_cast<T*>(smem);
-    for (int i = tid; i < img; i += WG_THREADS) reinterpret_cast<uint32_t*>(base)[i] = 0u;  // 2 buffers x img elements
-    float* lnp = reinterpret_cast<float*>(base + 2 * (size_t)img);  // [2 NB] LayerNorm gamma | beta of the X operand
-    if (a.stats)
-        for (int i = tid; i < 2 * a.NB; i += WG_THREADS) lnp[i] = i < a.NB ? a.gamma[i] : a.beta[i - a.NB];
-
-    f32x4 acc[WG_TPW];
-    float bsum[WG_TPW];
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) { acc[s] = F32X4_ZERO; bsum[s] = 0.f; }
-    const bool do_bias = a.dbias != nullptr;
-    const T* Ag = reinterpret_cast<const T*>(a.A);
-    const T* Bg = reinterpret_cast<const T*>(a.B);
-    const int pA = ncolsA / 8, pB = ncolsB / 8, center = a.taps / 2;
-    const int nvA = WG_KC * pA, nvec = nvA + a.taps * WG_KC * pB;
-    const int nchunks = cdiv(a.Ntok, WG_KC);
-    const int ntot = ngrp * tpg;
-    const bool shifted = a.taps > 1;
-
-    // per-slot offsets (elements, inside a buffer) of this lane's transposing reads
-    int oa[WG_TPW], ob[WG_TPW];
-    bool first_n[WG_TPW];
-    const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
-        const int tl = s * WG_WAVES + w;
-        oa[s] = 0; ob[s] = 0; first_n[s] = false;
-        if (tl < ntot) {
-            const int g = tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
-            oa[s] = trow * lda + g * mg + mt * 16 + tcol;
-            int q0 = nt * 16 + tcol;
-            if (q0 >= nexp) q0 = 0;
-            ob[s] = WG_KC * lda + ((q0 / ng) * WG_KC + trow) * ldb + g * ng + q0 % ng;
-            first_n[s] = nt == 0;
-        }
-    }
-    // per-vector descriptors of this thread (chunk independent): row k, tap shift, global column, LDS offset
-    int vk[WG_MAXV], vd[WG_MAXV], vcol[WG_MAXV], vdst[WG_MAXV];
-    bool vA[WG_MAXV], vok[WG_MAXV];
-#pragma unroll
-    for (int u = 0; u < WG_MAXV; ++u) {
-        const int v = tid + u * WG_THREADS;
-        vok[u] = v < nvec;
-        vA[u] = v < nvA;
-        if (vA[u]) {
-            vk[u] = v / pA; vd[u] = 0;
-            vcol[u] = acols0 + 8 * (v % pA);
-            vdst[u] = vk[u] * lda + 8 * (v % pA);
-        } else {
-            const int v2 = vok[u] ? v - nvA : 0, tap = v2 / (WG_KC * pB), r2 = v2 % (WG_KC * pB);
-            vk[u] = r2 / pB; vd[u] = tap - center;
-            vcol[u] = bcols0 + 8 * (r2 % pB);
-            vdst[u] = WG_KC * lda + (tap * WG_KC + vk[u]) * ldb + 8 * (r2 % pB);
-        }
-    }
-    u32x4 pre[WG_MAXV];
-    float pmu[WG_MAXV], prs[WG_MAXV];
-    auto prefetch = [&](int n0) {
-#pragma unroll
-        for (int u = 0; u < WG_MAXV; ++u) {
-            pre[u] = (u32x4){0, 0, 0, 0};
-            pmu[u] = 0.f; prs[u] = 0.f;
-            if (!vok[u]) continue;
-            const int n = n0 + vk[u];
-            if (n >= a.Ntok || (a.dbg & 4)) continue;
-            if (vA[u]) {
-                pre[u] = *reinterpret_cast<const u32x4*>(Ag + (size_t)n * a.lda + vcol[u]);
-            } else {
-                bool ok = true;
-                if (shifted) {
-                    const int pos = a.shift_dim == 0 ? n % a.T : (n / a.T) % a.F, lim = a.shift_dim == 0 ? a.T : a.F;
-                    ok = pos + vd[u] >= 0 && pos + vd[u] < lim;
-                }
-                if (ok) {
-                    const size_t ns = (size_t)((long)n + (long)vd[u] * a.shift_stride);
-                    pre[u] = *reinterpret_cast<const u32x4*>(Bg + ns * a.ldb + vcol[u]);
-                    if (a.stats) { pmu[u] = a.stats[2 * ns]; prs[u] = a.stats[2 * ns + 1]; }
-                }
-            }
-        }
-    };
-    auto stash = [&](T* buf) {
-#pragma unroll
-        for (int u = 0; u < WG_MAXV; ++u) {
-            if (!vok[u] || (a.dbg & 8)) continue;
-            u32x4 x = pre[u];
-            if (!vA[u] && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
-                float f[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
-                float gm[8], bt[8];
-                load8(lnp + vcol[u], gm);
-                load8(lnp + a.NB + vcol[u], bt);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = prs[u] != 0.f ? (f[e] - pmu[u]) * prs[u] * gm[e] + bt[e] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[i] = pack2bf(f[2 * i], f[2 * i + 1]);
-            }
-            *reinterpret_cast<u32x4*>(buf + vdst[u]) = x;
-        }
-    };
-
-    int ch = blockIdx.x;
-    if (ch < nchunks) prefetch(ch * WG_KC);
-    lds_barrier();  // zero fill done
-    int b = 0;
-    for (; ch < nchunks; ch += gridDim.x) {
-        T* buf = base + (size_t)b * img;
-        stash(buf);
-        lds_barrier();
-        if (ch + (int)gridDim.x < nchunks) prefetch((ch + gridDim.x) * WG_KC);
-#pragma unroll
-        for (int s = 0; s < WG_TPW; ++s) {
-            if (s * WG_WAVES + w < ntot && !(a.dbg & 2)) {
-                Frag<T> fa, fb;
-                frag_load_tr(fa, buf + oa[s], lda);
-                frag_load_tr(fb, buf + ob[s], ldb);
-                acc[s] = mma(fa, fb, acc[s]);
-                if (do_bias && first_n[s]) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum[s] += frag_get(fa, j);
-                }
-            }
-        }
-        b ^= 1;
-    }
-
-    if (a.part) {  // partial tiles in fragment order (coalesced 256-byte stores); wgrad_reduce_kernel folds them into dW
-        const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        float* pt = a.part + wg * ntot * 256;
-        float* pbias = a.part + (size_t)gridDim.y * gridDim.x * ntot * 256 + wg * ntot * 16;
-#pragma unroll
-        for (int s = 0; s < WG_TPW; ++s) {
-            const int tl = s * WG_WAVES + w;
-            if (tl < ntot && !(a.dbg & 1)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[s][r];
-                if (do_bias && first_n[s]) {
-                    const float tsum = wave_sum16(bsum[s]);
-                    if (g4 == 0) pbias[tl * 16 + l15] = tsum;
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
-        const int tl = s * WG_WAVES + w;
-        if (tl < ntot && !(a.dbg & 1)) {
-            const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
-            const int q = nt * 16 + l15;
-            if (q < nexp) {
-                const int tap = q / ng, i = q % ng;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mt * 16 + 4 * g4 + r;
-                    if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, acc[s][r]);
-                }
-            }
-            if (do_bias && nt == 0) {
-                const float tsum = wave_sum16(bsum[s]);
-                const int m = mt * 16 + l15;
-                if (g4 == 0 && m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, tsum);
-            }
-        }
-    }
 }
 
 // Third generation: 64-token chunks and ONE shared X image for all taps of a T-conv.  Chunks of a tapped problem are aligned to
@@ -871,38 +563,6 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
                 return NBSS_CHECK_LAUNCH();
             }
             return NBSS_OK;
-        }
-        if (a.a_gw || a.b_gw) return NBSS_EUNSUPPORTED;  // group-major operands: wgrad_tr3_kernel only
-        const size_t lds_tr = ((size_t)WG_KC * tr_ld(ncA) + (size_t)a.taps * WG_KC * tr_ld(ncB)) * 2;
-        const int nvec = WG_KC * (ncA / 8) + a.taps * WG_KC * (ncB / 8);
-        if (2 * lds_tr + 2 * (size_t)a.NB * sizeof(float) <= 158 * 1024 && nvec <= WG_MAXV * WG_THREADS) {  // double-buffered, register-prefetched variant
-            int xb = 256 / ybl;
-            if (xb < 16) xb = 16;
-            if (xb > nchunks) xb = nchunks;
-            ProfScope ps(PK_WGRAD, st);
-            const size_t lds2 = 2 * lds_tr + 2 * (size_t)a.NB * sizeof(float);
-            int e2 = NBSS_SET_MAX_LDS(wgrad_tr2_kernel, lds2);
-            if (e2) return e2;
-            const int ntot2 = (all ? a.groups : 1) * tpg;
-            WgradArgs a2 = a;
-            if ((size_t)ybl * xb * ntot2 * 272 * sizeof(float) > WGPART_BYTES) a2.part = nullptr;
-            NBSS_LAUNCH(wgrad_tr2_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds2, st, a2);
-            if ((e2 = NBSS_CHECK_LAUNCH())) return e2;
-            if (a2.part && !(a2.dbg & 1)) {
-                NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot2, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a2, xb, 0);
-                return NBSS_CHECK_LAUNCH();
-            }
-            return NBSS_OK;
-        }
-        if (lds_tr <= 120 * 1024) {
-            int xb = 256 / ybl;  // one workgroup per CU: doubling it (2 per CU) cost 16.6 -> 18.9 ms/step (more flush atomics, less work each)
-            if (xb < 16) xb = 16;
-            if (xb > nchunks) xb = nchunks;
-            ProfScope ps(PK_WGRAD, st);
-            int e2 = NBSS_SET_MAX_LDS(wgrad_tr_kernel, lds_tr);
-            if (e2) return e2;
-            NBSS_LAUNCH(wgrad_tr_kernel, dim3(xb, ybl), dim3(WG_THREADS), lds_tr, st, a);
-            return NBSS_CHECK_LAUNCH();
         }
     }
     if (a.a_gw || a.b_gw) return NBSS_EUNSUPPORTED;
