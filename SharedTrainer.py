@@ -215,6 +215,74 @@ def fit(cfg: dict) -> Dict[str, Any]:
     return {"log": log, "module": module}
 
 
+def _setup(cfg: dict):
+    """device, module, data module and a TrainStep for the non-training subcommands (inference path: no activations kept)"""
+    from nbss_amd._lib import NBSS_BF16, NBSS_F32
+    from nbss_amd.engine import TrainStep
+    tr = cfg.get("trainer", {})
+    if tr.get("accelerator", "gpu") == "cpu" or not torch.cuda.is_available():
+        raise RuntimeError("SharedTrainer: the SpatialNet path runs on MI355X HIP kernels only (no CPU path)")
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(int(cfg.get("seed_everything", 2)))
+    module = build_module(cfg).to(dev)
+    module.precision = str(tr.get("precision", "32"))
+    ckpt = cfg.get("ckpt_path")
+    if ckpt:  # reference checkpoints: {"state_dict": {"arch.*": ...}} (general_steps.py:189-199 tolerates the _orig_mod. prefix)
+        sd = torch.load(ckpt, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        sd = {k.replace("_orig_mod.", "").removeprefix("arch."): v for k, v in sd.items() if not k.endswith("stft.window")}
+        module.arch.load_state_dict(sd, strict=True)
+    data = _instantiate(cfg["data"]) if "data" in cfg else None
+    if data is None:
+        from data_loaders.synthetic import SyntheticDataModule
+        data = SyntheticDataModule()
+    eng = module.arch._engine_for(dev)
+    eng.dtype = NBSS_BF16 if module.precision in ("bf16-mixed", "bf16") else NBSS_F32
+    ts = TrainStep(eng, n_fft=module.stft.n_fft, ref_channel=module.channels.index(module.ref_channel))
+    return dev, module, data, ts
+
+
+def evaluate(cfg: dict, stage: int) -> Dict[str, Any]:
+    """`validate` (stage 1) / `test` (stage 2): uPIT neg-SI-SDR of the separated signals and the SI-SDR improvement over the
+    unprocessed reference-channel mixture, through the forward-only path (SharedTrainer.py:151-205 without the PESQ/STOI pools)."""
+    from nbss_amd import ops
+    dev, module, data, ts = _setup(cfg)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    tot, tot_in, n = 0.0, 0.0, 0
+    for x, ys, _ in data.batches(stage, rank, world, 0):
+        xs = x[:, module.channels].to(dev).contiguous()
+        yr = ys[:, :, module.ref_channel].to(dev).contiguous()
+        loss, yr_hat, _, _, _ = ts.forward_loss(xs, yr, need_grad=False)
+        mix = xs[:, module.channels.index(module.ref_channel)][:, None].expand_as(yr).contiguous()
+        loss_in, _, _ = ops.pit_neg_sisdr(ts.lib, mix, yr, need_grad=False)
+        tot += float(loss)
+        tot_in += float(loss_in)
+        n += 1
+    name = "val" if stage == 1 else "test"
+    rec = {f"{name}/neg_si_sdr": tot / max(n, 1), f"{name}/si_sdr_improvement_dB": (tot_in - tot) / max(n, 1), "batches": n}
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    return rec
+
+
+def predict(cfg: dict) -> Dict[str, Any]:
+    """`predict`: separated waveforms [B,Spk,N] of the test split (returned; written as .pt files when trainer.default_root_dir is set)"""
+    dev, module, data, ts = _setup(cfg)
+    out_dir = cfg.get("trainer", {}).get("default_root_dir")
+    outs = []
+    for bi, (x, ys, paras) in enumerate(data.batches(2, 0, 1, 0)):
+        xs = x[:, module.channels].to(dev).contiguous()
+        yr = ys[:, :, module.ref_channel].to(dev).contiguous()
+        _, yr_hat, _, _, perm = ts.forward_loss(xs, yr, need_grad=False)
+        outs.append(yr_hat.cpu())
+        if out_dir:
+            os.makedirs(out_dir, exist_ok=True)
+            torch.save({"yr_hat": outs[-1], "paras": paras}, os.path.join(out_dir, f"predict_{bi:05d}.pt"))
+    return {"yr_hat": outs}
+
+
 class TrainCLI:
     """`TrainCLI(TrainModule, ...)`-shaped entry point (reference :344-371)"""
 
@@ -223,8 +291,10 @@ class TrainCLI:
         self.subcommand, self.config = sub, cfg
         if sub == "fit":
             self.result = fit(cfg)
+        elif sub in ("validate", "test"):
+            self.result = evaluate(cfg, 1 if sub == "validate" else 2)
         else:
-            raise NotImplementedError(f"'{sub}' (evaluation with PESQ/STOI pools) is outside the hot path; see DESIGN.md §9")
+            self.result = predict(cfg)
 
 
 if __name__ == "__main__":

@@ -278,8 +278,9 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                     const int t = (w * MH_NSW + si) * 16 + l15;
                     if (t < T_) {
                         T* orow = osave + ((size_t)bf * T_ + t) * MH_H + (pass * HPP + hh) * MH_DH;
-                        store4_nt(orow + 4 * g4, o0[0], o0[1], o0[2], o0[3]);  // read again only by backward
-                        if (g4 < 2) store4_nt(orow + 16 + 4 * g4, o1[0], o1[1], o1[2], o1[3]);
+                        // (plain stores: the four heads' 48-byte pieces of a row merge in L2; non-temporal ones were 2x slower on some boxes)
+                        store4(orow + 4 * g4, o0[0], o0[1], o0[2], o0[3]);
+                        if (g4 < 2) store4(orow + 16 + 4 * g4, o1[0], o1[1], o1[2], o1[3]);
                     }
                 }
             }

@@ -43,6 +43,30 @@ def test_fit_one_epoch_on_gpu():
 
 
 @pytest.mark.gpu
+def test_validate_test_predict_on_gpu(tmp_path):
+    """the forward-only path behind the reference's validate / test / predict subcommands"""
+    base = ["--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml"),
+            "--model.arch.dim_input=12", "--model.arch.dim_output=4", "--trainer.precision=bf16-mixed", "--data.num_samples=[8,4,4]",
+            "--data.audio_time_len=[1.0,1.0,1.0]", "--model.arch.num_layers=2"]
+    for sub, key in (("validate", "val"), ("test", "test")):
+        rec = TrainCLI(argv=[sub] + base).result
+        assert rec["batches"] >= 1 and all(torch.isfinite(torch.tensor(v)) for v in rec.values())
+        assert f"{key}/neg_si_sdr" in rec and f"{key}/si_sdr_improvement_dB" in rec
+    out = TrainCLI(argv=["predict"] + base + [f"--trainer.default_root_dir={tmp_path}"]).result["yr_hat"]
+    assert len(out) >= 1 and out[0].shape[1:] == (2, 8000) and torch.isfinite(out[0]).all()
+    assert (tmp_path / "predict_00000.pt").exists()
+
+
+def test_subcommands_fail_loudly_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("HIP device present")
+    for sub in ("fit", "validate", "test", "predict"):
+        with pytest.raises(RuntimeError, match="HIP kernels only"):
+            TrainCLI(argv=[sub, "--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml"),
+                           "--model.arch.dim_input=12", "--model.arch.dim_output=4"])
+
+
+@pytest.mark.gpu
 def test_dropin_module_autograd_on_gpu():
     """models.arch.SpatialNet.SpatialNet as a plain nn.Module under torch autograd + torch.optim (generic trainer path)"""
     from models.arch.SpatialNet import SpatialNet

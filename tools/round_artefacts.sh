@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q -x > gpurun_out/${TAG}_pytest_gpu.log 2>&1; tail -2 gpurun_out/${TAG}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json; cut -c1-400 gpurun_out/${TAG}_bench.json
-for b in 2 4 8 15 16 31; do python bench.py --steps 5 --warmup 3 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+for b in 2 4 8 16 31 32; do python bench.py --steps 5 --warmup 3 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['batch_per_gpu'], round(d['value'],1), 'utt/s', round(d['ms_per_step'],2), 'ms/step')"; done | tee gpurun_out/${TAG}_batch_sweep.txt
 ( cd /tmp && export TMPDIR=/tmp && rm -rf $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1 )
 python tools/rocprof_summary.py gpurun_out/${TAG}_prof gpurun_out/${TAG}_rocprof.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (batch 31; 7 steps + one-time table/pack kernels)"
