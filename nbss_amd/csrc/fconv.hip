@@ -458,12 +458,10 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     float* stats = (float*)ws;
     void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    static const int tt_bf16 = getenv("NBSS_FCONV_BWD_TT") ? atoi(getenv("NBSS_FCONV_BWD_TT")) : FC_BWD_TT;
     int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-            : tt_bf16 == 2       ? fconv_bwd_t<bf16_t, 2>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-                                 : fconv_bwd_t<bf16_t, 1>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
+                                 : fconv_bwd_t<bf16_t, FC_BWD_TT>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
     if (e) return e;
-    const int nwg = c.dtype == NBSS_BF16 ? c.B * cdiv(c.T, tt_bf16 == 2 ? 2 : 1) : c.B * c.T;
+    const int nwg = c.dtype == NBSS_BF16 ? c.B * cdiv(c.T, FC_BWD_TT) : c.B * c.T;
     AffSegs sg;
     sg.n = 3;
     sg.off[0] = param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); sg.cnt[0] = FC_H;

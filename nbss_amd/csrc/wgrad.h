@@ -22,7 +22,7 @@ struct WgradArgs {
                             // the 256-deep same-address atomicAdd flush (31% of the kernel's time when measured)
     // optional group-major operand layouts [cols / gw][Ntok][gw] (gw = 0: plain [Ntok][ld]); transposing-read kernel only
     int a_gw = 0, a_gs = 0, b_gw = 0, b_gs = 0;  // group width (elements) and group stride (elements)
-    int dbg = 0;  // NBSS_WG_DEBUG probe bits (tools/wgrad_probe.sh): 1 no flush, 2 no MFMA/reads, 4 no global loads, 8 no LDS stash
+    int dbg = 0;  // diagnostic build only: NBSS_WG_DEBUG probe bits (1 no flush, 2 no MFMA, 4 no loads, 8 no LDS stash, 16 prologue only)
 };
 
 int wgrad_launch(const WgradArgs& a, int dtype, hipStream_t st);

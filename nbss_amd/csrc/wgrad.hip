@@ -243,6 +243,14 @@ NBSS_HD int tr_ld(int cols) {
 // F-convs (taps along F = a stride of T tokens) use the same kernel with chunks of KC/2 frequencies x 2 adjacent frames of one
 // batch item: image row 2 fo + tt holds token (f0 + fo, t0 + tt), a tap is a row offset of 2, and every global access is a
 // 16-byte piece of a 384-byte (2-frame) run.
+// Knock-out probes (tools/wgrad_probe.py): compiled only into the diagnostic build (python -m nbss_amd.build phase)
+#ifdef NBSS_PHASE_PROF
+#define WG_PROBE(bit) (a.dbg & (bit))
+#define WG_PROBE_HOST(args, bit) ((args).dbg & (bit))
+#else
+#define WG_PROBE(bit) false
+#define WG_PROBE_HOST(args, bit) false
+#endif
 #define W3_MAXV 7
 #define W3_BS 3  // slots that can hold nt == 0 tiles (ngrp * mtiles <= 8 * W3_BS)
 
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         for (int u = 0; u < W3_MAXV; ++u) {
             pre[u] = (u32x4){0, 0, 0, 0};
             pmu[u] = 0.f; prs[u] = 0.f;
-            if (!vok[u] || (unsigned)(vkk[u] - lo) >= (unsigned)span || (vt1[u] && !t1ok) || (a.dbg & 4)) continue;
+            if (!vok[u] || (unsigned)(vkk[u] - lo) >= (unsigned)span || (vt1[u] && !t1ok) || WG_PROBE(4)) continue;
             const T* sbase = u < UA ? Ab : Bb;  // wave-uniform
             pre[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(sbase) + (size_t)(vgo[u] * 2u));
             if (u >= UA && sb) { pmu[u] = sb[2 * vtok[u]]; prs[u] = sb[2 * vtok[u] + 1]; }
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     auto stash = [&](T* buf) {
 #pragma unroll
         for (int u = 0; u < W3_MAXV; ++u) {
-            if (!vok[u] || (a.dbg & 8)) continue;
+            if (!vok[u] || WG_PROBE(8)) continue;
             u32x4 x = pre[u];
             if (u >= UA && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
                 float f[8];
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     };
 
     int ch = blockIdx.x;
-    if (a.dbg & 16) return;  // probe: launch + prologue only
+    if (WG_PROBE(16)) return;  // probe: launch + prologue only
     if (ch < nchunks) prefetch();
     lds_barrier();  // zero fill done
     int b = 0;
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         // software pipeline over the NS * KH (tile, k-half) steps: the operands of step i+1 are requested before step i's MFMA
         constexpr int KH = W3_KC / 32;
         Frag<T> fa[2], fb[2];
-        if (a.dbg & 2) { b ^= 1; continue; }  // probe: no MFMA section
+        if (WG_PROBE(2)) { b ^= 1; continue; }  // probe: no MFMA section
         frag_load_tr(fa[0], buf + oa[0], lda);
         frag_load_tr(fb[0], buf + ob[0], ldb);
 #pragma unroll
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         else b ^= 1;
     }
 
-    if (a.dbg & 1) return;
+    if (WG_PROBE(1)) return;  // probe: no flush
     if (a.part) {  // partial tiles in fragment order (coalesced 256-byte stores); wgrad_reduce_kernel folds them into dW
         const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         float* pt = a.part + wg * ntot * 256;
@@ -558,7 +566,7 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             else W3_GO(64, 14);
 #undef W3_GO
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
-            if (a3.part && !(a3.dbg & 1)) {
+            if (a3.part && !WG_PROBE_HOST(a3, 1)) {
                 NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot3, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a3, xb, 1);
                 return NBSS_CHECK_LAUNCH();
             }
@@ -583,9 +591,11 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
 }
 
 int wgrad_launch(const WgradArgs& a0, int dtype, hipStream_t st) {
-    static const int dbg = getenv("NBSS_WG_DEBUG") ? atoi(getenv("NBSS_WG_DEBUG")) : 0;
     WgradArgs a = a0;
+#ifdef NBSS_PHASE_PROF
+    static const int dbg = getenv("NBSS_WG_DEBUG") ? atoi(getenv("NBSS_WG_DEBUG")) : 0;  // tools/wgrad_probe.py knock-out runs
     a.dbg = dbg;
+#endif
     if (a.MA % a.groups || a.NB % a.groups) return NBSS_EINVAL;
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     if (mg % 4 || ng % 4) return NBSS_EUNSUPPORTED;

@@ -60,7 +60,7 @@ def full(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
     return x + v.reshape(B, T, H, F).permute(0, 3, 1, 2)
 
 
-def mhsa(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int = 4) -> Tensor:
+def mhsa(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int = 4, return_saved: bool = False):
     """x + _tsa: LN -> nn.MultiheadAttention(H, heads, batch_first) self-attention over T for
     every (b,f); no mask, no dropout (SpatialNet.py:88,93-100,57-58)."""
     B, F, T, H = x.shape
@@ -73,8 +73,11 @@ def mhsa(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int = 4) -> Tensor:
     v = v.reshape(B * F, T, heads, dh).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
     o = (att @ v).transpose(1, 2).reshape(B * F, T, H)
-    o = o @ p[pre + ".mhsa.out_proj.weight"].t() + p[pre + ".mhsa.out_proj.bias"]
-    return x + o.reshape(B, F, T, H)
+    y = o @ p[pre + ".mhsa.out_proj.weight"].t() + p[pre + ".mhsa.out_proj.bias"]
+    if return_saved:  # what the HIP forward keeps for backward: O before out_proj, log2-sum-exp of the scaled score rows
+        lse2 = torch.logsumexp((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1) / math.log(2.0)  # [B*F, heads, T]
+        return x + y.reshape(B, F, T, H), o.reshape(B, F, T, H), lse2.transpose(1, 2).reshape(B, F, T, heads)
+    return x + y.reshape(B, F, T, H)
 
 
 def tconvffn(x: Tensor, p: Dict[str, Tensor], pre: str, groups: int = 8) -> Tensor:

@@ -74,6 +74,18 @@ def test_mhsa(backend, dtype):
         want = ref.mhsa(x64, cs.p64, "layers.0")
         assert rel_l2(y, want) < cs.tol
         assert rel_l2(y.double().cpu() - x64, want - x64) < 3 * cs.tol
+        # the save buffer backward reads: attention output before out_proj, then fp32 log2-sum-exp rows [B,F,T,heads]
+        save = ops.mhsa_save(cs.lib, cs.cfg, x.device)
+        y2 = ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=save)
+        assert torch.equal(y2, y)
+        _, o_want, lse_want = ref.mhsa(x64, cs.p64, "layers.0", return_saved=True)
+        n = B * F * T
+        esz = x.element_size()
+        o_got = save[: n * 96 * esz].view(x.dtype).view(B, F, T, 96)
+        lse_off = (n * 96 * esz + 255) // 256 * 256
+        lse_got = save[lse_off: lse_off + n * 4 * 4].view(torch.float32).view(B, F, T, 4)
+        assert rel_l2(o_got, o_want) < cs.tol
+        assert (lse_got.double().cpu() - lse_want).abs().max() < (2e-4 if dtype == NBSS_F32 else 5e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,10 +1,11 @@
 """Time the wgrad launches of one sub-block's backward (HIP-event profiler) — run under NBSS_WG_DEBUG=<bits> to knock out
-parts of wgrad_tr2_kernel (results are then wrong; this is a where-does-the-time-go probe only)."""
+parts of wgrad_tr3_kernel (diagnostic build: `python -m nbss_amd.build phase`; results are then wrong; this is a where-does-the-time-go probe only)."""
 import ctypes as C
 import os
 import sys
 from pathlib import Path
 
+os.environ.setdefault("NBSS_HIP_FLAVOUR", "phase")  # the probe bits only exist in the diagnostic build
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
