@@ -64,7 +64,8 @@ NBSS_DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* __restrict__ vr, int half
 }
 NBSS_DEV void v_frag_tr(Frag<float>&, const float*, int, int) {}
 
-template <class T, int HPP>
+// FULL: T in (240, 256]: every key tile exists, the tile tests fold at compile time (see mhsa_bwd.hip)
+template <class T, int HPP, bool FULL>
 __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
     constexpr bool WLDS = sizeof(T) == 2 && HPP == MH_HEADS;
     T* wl = Vt + HPP * MH_TP * MH_DH + 32;           // [48][512]
     float* prm = reinterpret_cast<float*>(wl + (WLDS ? 48 * 512 : 0));  // [3H in_proj bias | H out_proj bias | 2H LN gamma, beta]
-    const int T_ = c.T, nst = cdiv(T_, 16);
+    const int T_ = c.T, nst = FULL ? MH_NT : cdiv(T_, 16);
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const T* xb = x + (size_t)bf * T_ * MH_H;
@@ -326,22 +327,23 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
     }
 }
 
-template <class T, int HPP>
+template <class T, int HPP, bool FULL>
 static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
     if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
     // +64: the last transposing read overreaches its row by 16 B; bf16: 48-fragment weight window + biases
     const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T) + 64 + (sizeof(T) == 2 && HPP == MH_HEADS ? (size_t)48 * 512 * sizeof(T) + 4 * MH_H * sizeof(float) : 0);
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP>), lds);
+    int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP, FULL>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_MHSA_F, st);
-    NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
+    NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
                 pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, osave ? (float*)((char*)osave + mhsa_lse_offset(c)) : nullptr);
     return NBSS_CHECK_LAUNCH();
 }
 
 int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? mhsa_fwd_t<bf16_t, 4>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<float, 2>(c, P, packed, layer, x, y, osave, st);
+    if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false>(c, P, packed, layer, x, y, osave, st);
+    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<bf16_t, 4, false>(c, P, packed, layer, x, y, osave, st);
 }

@@ -86,13 +86,16 @@ NBSS_DEV void col_frag(Frag<T>& f, const T* __restrict__ base, int tp, int half,
     }
 }
 
-template <class T>
+// FULL: T in (240, 256] — all 16 strips of every wave exist, so the strip / tile-existence tests are compile-time true and the
+// tile loops have constant trip counts (wave-uniform but dynamic branches kept the compiler from scheduling across them: the same
+// effect cost wgrad 24 %, profiles/README.md row 27)
+template <class T, bool FULL>
 __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Win, const T* __restrict__ WinT, const T* __restrict__ WoutT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ osave,
                                                        const float* __restrict__ lse, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dqkv) {
     NBSS_LDS(smem);
-    const int T_ = c.T, nst = cdiv(T_, 16), tp = nst * 16, nkp = cdiv(nst, 2);
+    const int T_ = c.T, nst = FULL ? MB_NT : cdiv(T_, 16), tp = nst * 16, nkp = FULL ? MB_NT / 2 : cdiv(nst, 2);
     T* Qr = reinterpret_cast<T*>(smem);
     T* Kr = Qr + (size_t)tp * MB_DH;
     T* Vr = Kr + (size_t)tp * MB_DH;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     for (int si = 0; si < MB_NSW; ++si) {
         tt[si] = (w * MB_NSW + si) * 16 + l15;
         tv[si] = tt[si] < T_;
-        sact[si] = (w * MB_NSW + si) < nst;  // wave-uniform
+        sact[si] = FULL || (w * MB_NSW + si) < nst;  // wave-uniform
     }
 
     // Only the row statistics persist across the head loop: LN(x) and dy fragments are rebuilt per head and du is formed after
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 }
 PHASE_READER(nbss_phase_read_mhsa_bwd)
 
-template <class T>
+template <class T, bool FULL>
 static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                       void* dx, float* stats, void* dqkv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
@@ -516,11 +519,11 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + (sizeof(T) == 2 ? (size_t)96 * 512 * sizeof(T) : 0) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T>), lds);
+    int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T, FULL>), lds);
     if (e) return e;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_MHSA_B, st);
-    NBSS_LAUNCH((mhsa_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
+    NBSS_LAUNCH((mhsa_bwd_kernel<T, FULL>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
                 pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)),
                 (T*)dx, stats, (T*)dqkv);
     return NBSS_CHECK_LAUNCH();
@@ -533,8 +536,10 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     float* stats = (float*)ws;
     void* dqkv = (char*)ws + ws_align(N * 2 * sizeof(float));
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    int e = c.dtype == NBSS_BF16 ? mhsa_bwd_t<bf16_t>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
-                                 : mhsa_bwd_t<float>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st);
+    const bool full = cdiv(c.T, 16) == MB_NT;
+    int e = c.dtype != NBSS_BF16 ? mhsa_bwd_t<float, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+            : full               ? mhsa_bwd_t<bf16_t, true>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+                                 : mhsa_bwd_t<bf16_t, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st);
     if (e) return e;
     AffSegs sg;
     sg.n = 2;
