@@ -3,9 +3,10 @@
 // over the T frames of every (b,f) sequence (SpatialNet.py:88,93-100; nn.MultiheadAttention,
 // 4 heads, dh = 24, no mask, no dropout, need_weights always False).
 //
-// One workgroup = one (b,f) sequence (T <= 256 frames, 48 KB of bf16 stream).  K (row-major)
-// and V^T of every head are LDS resident; Q, the probabilities and the per-head outputs never
-// leave registers:
+// One workgroup = one (b,f) sequence (T <= 256 frames, 48 KB of bf16 stream).  K and V of every head are LDS resident
+// (bf16: both row-major, V fetched through transposing reads; fp32: V^T), the in_proj / out_proj fragments go through a
+// 48-fragment LDS window; Q, the probabilities and the per-head outputs never leave registers.  In training the kernel also
+// saves the attention output before out_proj and the log2-sum-exp of every score row (nbss_mhsa_save_bytes):
 //   * all projections are "form 2" GEMMs (weights = MFMA A operand, frames = N), so a C tile
 //     holds 4 consecutive channels of one frame per lane;
 //   * S^T = K Q^T is computed (not S), which makes the C tiles of S^T directly the B operand of

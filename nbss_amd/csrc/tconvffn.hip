@@ -3,12 +3,13 @@
 // with W1: 1x1 H->FFN, gconv: Conv1d(FFN,FFN,k=3,groups=8,'same') along T, GN = GroupNorm(8,FFN)
 // whose statistics span (24 channels x all T frames) of one (b,f) sequence, W2: 1x1 FFN->H.
 //
-// One workgroup (8 waves) = one (b,f) sequence; each wave owns two 16-frame strips.  The whole
-// chain between the two 1x1 convs is group-local (the 8 conv groups coincide with the 8 GN
-// groups), so the kernel walks the groups one at a time: only a [T+2][24] ping-pong pair of
-// the current group lives in LDS (25 KB), the H-wide input strip (as LN'ed B fragments) and the
-// H-wide output accumulators stay in registers for the whole kernel, and the FFN-wide (2S)
-// intermediates of the reference never exist in memory.
+// One workgroup = one (b,f) sequence; a wave owns 16-frame strips (forward, bf16: 16 waves x 1 strip; backward and fp32:
+// 8 waves x 2 strips).  The whole chain between the two 1x1 convs is group-local (the 8 conv groups coincide with the 8 GN
+// groups), so the kernel walks the groups one at a time: only [T+2][24] row buffers of the current group (2 forward,
+// 4 backward) and the group's weight fragments (double-buffered in forward) live in LDS, the H-wide input strip (as LN'ed
+// B fragments) and the H-wide output accumulators stay in registers, and the FFN-wide (2S) intermediates of the reference
+// never exist in memory.  Backward recomputes the forward chain per group and emits the eight wgrad operand tensors
+// group-major ([G][N][24], non-temporal stores); every global read of a group is issued before that group's stores.
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"
@@ -20,7 +21,7 @@
 #define TF_G 8
 #define TF_CG 24
 #define TF_TP 256
-#define TF_NSW 2     // strips per wave, 8 waves
+#define TF_NSW 2     // strips per wave of the backward kernel (8 waves); the forward kernel takes it as a template parameter
 #define TF_KS (TF_H / 32)
 #ifndef TF_FWD_WPS
 #define TF_FWD_WPS 2

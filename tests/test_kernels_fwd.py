@@ -91,7 +91,7 @@ def test_mhsa(backend, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_tconvffn(backend, dtype):
-    for (B, F, T) in shapes_for(backend):
+    for (B, F, T) in shapes_for(backend) + ([(1, 1, 251)] if backend.name != "hip" and dtype == NBSS_BF16 else []):  # all 16 strips on the emulator too
         cs = Case(backend, B, F, T, dtype)
         x, x64 = cs.stream(seed=10)
         y = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
