@@ -120,6 +120,12 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
                         void* stream);
 int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
                         const float* dout, void* ws, void* stream);
+/* The same walk in pieces, for overlapping the data-parallel gradient exchange with backward (the role of DDP's reverse-order
+ * buckets): layers [layer_lo, layer_hi), plus the decoder when layer_hi == L (dout needed only then) and the
+ * encoder when layer_lo == 0.  Calls must cover L..0 in descending, adjacent ranges; after a call the gradients of the layers
+ * it covered are final, except the LinearGroup shared through full_share, which is final after layer 0. */
+int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
+                              const float* dout, void* ws, int layer_hi, int layer_lo, void* stream);
 
 /* ---- signal front / back end (always fp32 arithmetic) ------------------------------------------
  * n_fft in {256, 512}, hop = n_fft/2, win_len = n_fft; window 0 = periodic hann, 1 = sqrt-hann

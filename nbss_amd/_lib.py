@@ -63,6 +63,7 @@ SIGNATURES = {
     "nbss_train_ws_bytes": (C.c_int64, [_CP]),
     "nbss_spatialnet_fwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P]),
     "nbss_spatialnet_bwd": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_spatialnet_bwd_range": (_I, [_CP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "nbss_stft_tables_bytes": (C.c_int64, [_I]),
     "nbss_stft_tables": (_I, [_I, _I, _P, _P]),
     "nbss_stft_norm_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -217,21 +217,26 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     return decoder_fwd_impl(c, params, packed, buf(k), out, st);
 }
 
-int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
-                        const float* dout, void* ws, void* stream) {
+int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
+                              const float* dout, void* ws, int layer_hi, int layer_lo, void* stream) {
     CHECK_CFG(cfg);
-    if (!params || !grads || !packed || !xin || !acts || !dout || !ws) return NBSS_EINVAL;
+    if (!params || !grads || !packed || !xin || !acts || !ws) return NBSS_EINVAL;
     const nbss_cfg& c = *cfg;
+    if (layer_lo < 0 || layer_hi > c.L || layer_lo >= layer_hi) return NBSS_EINVAL;
+    if (layer_hi == c.L && !dout) return NBSS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t sb = stream_bytes(c);
     auto act = [&](int i) -> const void* { return (const char*)acts + (size_t)i * sb; };
     char* gb = (char*)ws + workspace_bytes(c);
+    // the gradient stream ping-pongs between two buffers and swaps once per layer: which one is current follows from
+    // the number of layers already walked
     void* dA = gb;
     void* dB = gb + sb;
-    int k = 5 * c.L;
-    int e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, dA, ws, st);
-    if (e) return e;
-    for (int l = c.L - 1; l >= 0; --l) {
+    if ((c.L - layer_hi) & 1) { void* t = dA; dA = dB; dB = t; }
+    int k = 5 * layer_hi;
+    int e;
+    if (layer_hi == c.L && (e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, dA, ws, st))) return e;
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const void* osave = (const char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c);
         if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), dA, dB, ws, st))) return e;
         if ((e = mhsa_bwd_impl(c, params, grads, packed, l, act(k - 2), dB, osave, dA, ws, st))) return e;
@@ -241,7 +246,13 @@ int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, 
         void* t = dA; dA = dB; dB = t;
         k -= 5;
     }
-    return encoder_bwd_impl(c, grads, xin, dA, st);
+    return layer_lo == 0 ? encoder_bwd_impl(c, grads, xin, dA, st) : NBSS_OK;
+}
+
+int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
+                        const float* dout, void* ws, void* stream) {
+    if (!cfg || !dout) return NBSS_EINVAL;
+    return nbss_spatialnet_bwd_range(cfg, params, grads, packed, xin, acts, dout, ws, cfg->L, 0, stream);
 }
 
 int64_t nbss_stft_tables_bytes(int n_fft) {

@@ -88,17 +88,61 @@ class SpatialNetEngine:
                  ops._stream(lib, xin))
         return out
 
-    def backward(self, xin: Tensor, dout: Tensor, dtype: Optional[int] = None) -> None:
-        """accumulates parameter gradients of the LAST train-mode forward into self.grads"""
+    def backward(self, xin: Tensor, dout: Tensor, dtype: Optional[int] = None, on_bucket=None) -> None:
+        """accumulates parameter gradients of the LAST train-mode forward into self.grads.
+
+        on_bucket(lo, hi): when given, backward is walked one layer at a time (nbss_spatialnet_bwd_range) and the callback is
+        invoked as soon as grads[lo:hi] is final — the decoder with the last layer, the encoder and the shared LinearGroup with
+        layer 0 — so that a data-parallel caller can start reducing that slice while the remaining layers still run."""
         dtype = self.dtype if dtype is None else dtype
         B, F, T, _ = xin.shape
         if self._geom != (B, T, dtype, True):
             raise NbssError("backward() needs a preceding forward(train=True) with the same geometry")
         cfg = self.cfg_for(B, T, dtype)
         lib = self.lib
-        lib.call("nbss_spatialnet_bwd", C.byref(cfg), ops._ptr(lib, self.params), ops._ptr(lib, self.grads), ops._ptr(lib, self.packed_for(dtype)),
-                 ops._ptr(lib, xin, self.stream_dtype(dtype)), ops._ptr(lib, self.acts), ops._ptr(lib, dout, torch.float32), ops._ptr(lib, self.ws),
-                 ops._stream(lib, xin))
+        args = (C.byref(cfg), ops._ptr(lib, self.params), ops._ptr(lib, self.grads), ops._ptr(lib, self.packed_for(dtype)),
+                ops._ptr(lib, xin, self.stream_dtype(dtype)), ops._ptr(lib, self.acts), ops._ptr(lib, dout, torch.float32), ops._ptr(lib, self.ws))
+        if on_bucket is None:
+            lib.call("nbss_spatialnet_bwd", *args, ops._stream(lib, xin))
+            return
+        L = cfg.L
+        for l in range(L - 1, -1, -1):
+            lib.call("nbss_spatialnet_bwd_range", *args, l + 1, l, ops._stream(lib, xin))
+            for lo, hi in self.grad_buckets()[l]:
+                on_bucket(lo, hi)
+
+    def grad_buckets(self):
+        """per layer: the [lo, hi) ranges of the flat gradient buffer that are final once that layer's backward has run
+        (reverse-order buckets of SURVEY.md §8(e): last layer + decoder first, layer 0 + encoder + shared LinearGroup last)"""
+        if getattr(self, "_buckets", None) is None:
+            L = self.kw["L"]
+            owner = {}  # a tensor shared by several layers (full_share) is final only after the LOWEST layer that uses it
+            for name, (off, shape) in self.table.items():
+                if name.startswith("layers."):
+                    key = int(name.split(".")[1])
+                elif name.startswith("decoder"):
+                    key = L - 1
+                else:  # encoder
+                    key = 0
+                span = (off, off + _numel(shape))
+                owner[span] = min(owner.get(span, key), key)
+            spans = {}
+            for span, key in owner.items():
+                spans.setdefault(key, []).append(span)
+            buckets = []
+            covered = 0
+            for l in range(L):
+                merged = []
+                for lo, hi in sorted(spans.get(l, [])):
+                    if merged and merged[-1][1] == lo:
+                        merged[-1] = (merged[-1][0], hi)
+                    else:
+                        merged.append((lo, hi))
+                covered += sum(hi - lo for lo, hi in merged)
+                buckets.append(merged)
+            assert covered == self.params.numel(), "gradient buckets must tile the flat buffer"
+            self._buckets = buckets
+        return self._buckets
 
 
 def _numel(shape) -> int:
@@ -112,7 +156,7 @@ class TrainStep:
     """One full SpatialNet training step on the HIP path (the unit bench.py times)."""
 
     def __init__(self, engine: SpatialNetEngine, *, n_fft: int = 256, ref_channel: int = 0, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, clip: float = 5.0, process_group=None):
+                 weight_decay: float = 0.0, clip: float = 5.0, process_group=None, bucketed: bool = True):
         self.e = engine
         self.lib = engine.lib
         self.n_fft, self.ref = n_fft, ref_channel
@@ -123,6 +167,7 @@ class TrainStep:
         self.scratch = torch.zeros(512, dtype=torch.float32, device=engine.device)
         self.step_count = 0
         self.pg = process_group
+        self.bucketed = bucketed  # world > 1: per-layer gradient buckets reduced while backward is still running
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
@@ -142,14 +187,29 @@ class TrainStep:
         """forward + backward + (all-reduce) + clip + Adam + re-pack; returns the loss (device tensor [1])"""
         e = self.e
         loss, _, dout, xin, _ = self.forward_loss(x, yr, need_grad=True)
-        e.backward(xin, dout)
-        self.apply_gradients()
+        self.backward_and_update(xin, dout)
         return loss
 
-    def apply_gradients(self) -> None:
-        """[all-reduce] + clip + Adam + re-pack on whatever is in engine.grads"""
+    def backward_and_update(self, xin: Tensor, dout: Tensor) -> None:
+        """network backward + gradient exchange + clip/Adam/re-pack"""
         e = self.e
-        if self.world > 1:
+        if self.world > 1 and self.bucketed:
+            # data parallel, overlapped: one asynchronous all-reduce (SUM) per layer bucket, issued as soon as that layer's
+            # backward has been enqueued; RCCL runs them on its own stream behind the kernels already queued here
+            handles = []
+            e.backward(xin, dout, on_bucket=lambda lo, hi: handles.append(
+                torch.distributed.all_reduce(e.grads[lo:hi], group=self.pg, async_op=True)))
+            for h in handles:
+                h.wait()
+            self.apply_gradients(reduced=True)
+        else:
+            e.backward(xin, dout)
+            self.apply_gradients()
+
+    def apply_gradients(self, reduced: bool = False) -> None:
+        """[all-reduce] + clip + Adam + re-pack on whatever is in engine.grads (reduced=True: the buckets were summed already)"""
+        e = self.e
+        if self.world > 1 and not reduced:
             # data parallel: ONE all-reduce (SUM) of the flat fp32 gradient over RCCL; the mean is folded into the clip kernel
             torch.distributed.all_reduce(e.grads, group=self.pg)
         self.step_count += 1

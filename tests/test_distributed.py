@@ -58,3 +58,43 @@ def test_gradient_allreduce_matches_single_process_mean(tmp_path):
     opt.step()
     assert abs(float(outs[0]["norm"]) - float(norm)) < 1e-4 * float(norm)
     assert float((outs[0]["params"] - p.detach()).norm() / p.detach().norm()) < 1e-6
+
+
+def _step_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nbss_amd._lib import NBSS_F32, Lib
+    from nbss_amd.build import build_emu
+    from nbss_amd.engine import SpatialNetEngine, TrainStep
+    lib = Lib(build_emu())
+    g = torch.Generator().manual_seed(500 + rank)  # rank-dependent data
+    xin = torch.randn(1, 9, 21, 4, generator=g)
+    dout = torch.randn(1, 9, 21, 4, generator=g)
+    out = {}
+    for mode in ("bucketed", "single"):
+        torch.manual_seed(0)  # identical parameters on every rank and in both modes
+        eng = SpatialNetEngine(lib, "cpu", dim_input=4, dim_output=4, num_freqs=9, num_layers=3, dtype=NBSS_F32)
+        eng.params.copy_(torch.randn_like(eng.params) * 0.05)
+        eng.version += 1
+        ts = TrainStep(eng, lr=1e-2, clip=5.0, bucketed=mode == "bucketed")
+        assert ts.world == world and len(eng.grad_buckets()) == 3
+        eng.forward(xin, train=True)
+        ts.backward_and_update(xin, dout)  # network backward (+ per-layer async all-reduce) + clip + Adam
+        out[mode] = {"params": eng.params.clone(), "norm": float(ts.scratch[0])}
+    torch.save(out, f"{tmp}/s{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_equals_single_allreduce(tmp_path):
+    """per-layer gradient buckets reduced during backward (nbss_spatialnet_bwd_range + async all-reduce) give the same update as
+    one all-reduce after backward, and replicas stay bit-identical (atomicAdd order makes the two MODES agree to rounding only)"""
+    world, port = 2, 31500 + os.getpid() % 2000
+    mp.spawn(_step_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"s{r}.pt") for r in range(world)]
+    for mode in ("bucketed", "single"):
+        assert torch.equal(outs[0][mode]["params"], outs[1][mode]["params"])
+    a, b = outs[0]["bucketed"], outs[0]["single"]
+    assert abs(a["norm"] - b["norm"]) < 1e-5 * b["norm"] and b["norm"] > 0
+    assert float((a["params"] - b["params"]).norm() / b["params"].norm()) < 1e-6
