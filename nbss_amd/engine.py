@@ -70,8 +70,8 @@ class SpatialNetEngine:
         cfg = self.cfg_for(B, T, dtype)
         key = (B, T, dtype, train)
         if self._geom != key:
-            self.ws = torch.empty(self.lib.nbss_train_ws_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
-            self.acts = torch.empty(self.lib.nbss_acts_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device) if train else None
+            self.ws = ops.scratch(self.lib.nbss_train_ws_bytes(C.byref(cfg)), self.device)
+            self.acts = ops.scratch(self.lib.nbss_acts_bytes(C.byref(cfg)), self.device) if train else None
             self._geom = key
         return cfg
 

@@ -6,6 +6,7 @@ sources on CPU tensors.  There is no other code path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -92,9 +93,19 @@ def full_fwd(lib, cfg, flat, packed, layer, x):
     return y
 
 
+def scratch(nbytes: int, device) -> Tensor:
+    """caller-owned scratch for the library (workspaces, saved activations).  NBSS_POISON_SCRATCH=1 (set by tests/conftest.py)
+    fills it with 0xFF bytes — NaN in bf16 and fp32 — so that a kernel that reads scratch it has not written shows up as NaN in
+    the checked outputs instead of passing on freshly mapped, zeroed pages."""
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if os.environ.get("NBSS_POISON_SCRATCH") == "1":
+        t.fill_(0xFF)
+    return t
+
+
 def mhsa_save(lib, cfg, device) -> Tensor:
     """buffer for what mhsa_bwd needs from the forward pass (attention output before out_proj + log-sum-exp rows)"""
-    return torch.empty(lib.nbss_mhsa_save_bytes(C.byref(cfg)), dtype=torch.uint8, device=device)
+    return scratch(lib.nbss_mhsa_save_bytes(C.byref(cfg)), device)
 
 
 def mhsa_fwd(lib, cfg, flat, packed, layer, x, o_save=None):
@@ -119,7 +130,7 @@ def tconvffn_fwd(lib, cfg, flat, packed, layer, x):
 
 
 def workspace(lib, cfg, device) -> Tensor:
-    return torch.empty(lib.nbss_workspace_bytes(C.byref(cfg)), dtype=torch.uint8, device=device)
+    return scratch(lib.nbss_workspace_bytes(C.byref(cfg)), device)
 
 
 def tconvffn_bwd(lib, cfg, flat, grads, packed, layer, x, dy, ws):

@@ -18,6 +18,9 @@ if str(ROOT) not in sys.path:
 REFERENCE = Path("/root/reference")
 
 
+os.environ.setdefault("NBSS_POISON_SCRATCH", "1")  # scratch buffers start as NaN bytes in every test (nbss_amd/ops.py: scratch)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running emulator case")
