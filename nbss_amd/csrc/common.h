@@ -174,20 +174,6 @@ NBSS_DEV void store4_nt(bf16_t* p, float a, float b, float c, float d) {
     __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
 #endif
 }
-NBSS_DEV void store1_nt(float* p, float a) {
-#ifdef NBSS_EMU
-    *p = a;
-#else
-    __builtin_nontemporal_store(a, p);
-#endif
-}
-NBSS_DEV void store1_nt(bf16_t* p, float a) {
-#ifdef NBSS_EMU
-    *p = f2bf(a);
-#else
-    __builtin_nontemporal_store(f2bf(a), p);
-#endif
-}
 NBSS_DEV void store1(float* p, float a) { *p = a; }
 NBSS_DEV void store1(bf16_t* p, float a) { *p = f2bf(a); }
 NBSS_DEV float load1(const float* p) { return *p; }

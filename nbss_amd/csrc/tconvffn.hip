@@ -74,15 +74,8 @@ NBSS_DEV void conv_bfrags(const T* __restrict__ hin, int t, Frag<T> (&bq)[TF_CKS
     }
 }
 
-// cooperative copy of `nfrag` packed weight fragments (512 elements each) global -> LDS; 16-byte vectors
-template <class T>
-NBSS_DEV void stage_frags(T* __restrict__ dst, const T* __restrict__ src, int nfrag) {
-    constexpr int VN = 16 / sizeof(T);
-    for (int v = threadIdx.x; v < nfrag * 512 / VN; v += blockDim.x)
-        *reinterpret_cast<u32x4*>(dst + (size_t)v * VN) = *reinterpret_cast<const u32x4*>(src + (size_t)v * VN);
-}
-// Batched variants for the group loops: every 16-byte load of the group's fragments is in flight before the first LDS write
-// (one call of stage_frags per weight costs one exposed L2 latency each: 4 us per group when measured with phase timers).
+// Weight staging for the group loops: every 16-byte load of the group's fragments (512 elements each) is in flight before the
+// first LDS write (one copy loop per weight cost one exposed L2 latency each: 4 us per group when measured with phase timers).
 template <class T>
 struct StageSrcs {  // named members, not an array: a select between array elements becomes a per-lane scratch load
     const T *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
@@ -147,21 +140,6 @@ NBSS_DEV void stage_group(T* __restrict__ wl, const StageSrcs<T>& srcs, size_t g
 }
 template <class T>
 NBSS_DEV void lfrag(Frag<T>& f, const T* __restrict__ wl, int idx) { frag_load(f, wl + ((size_t)idx * 64 + lane_id()) * 8); }
-
-// LN(x) fragment k-step `ks` of one row, rebuilt on demand from x, the row statistics and gamma|beta in LDS
-template <class T>
-NBSS_DEV void u_frag_ks(Frag<T>& f, const T* __restrict__ xr, bool valid, float mean, float rstd, const float* __restrict__ lnp, int ks) {
-    const int c0 = ks * 32 + 8 * (lane_id() >> 4);
-    float v[8], gm[8], bt[8];
-    if (valid) load8(xr + c0, v);
-    else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    load8(lnp + c0, gm);
-    load8(lnp + TF_H + c0, bt);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) frag_set(f, j, (v[j] - mean) * rstd * gm[j] + bt[j]);
-}
 
 // one grouped conv for the wave's strips: out[si][half] (C tiles: lane = frame, rows = 4 channels)
 template <class T, int NSW>
