@@ -8,7 +8,7 @@ CPU restatement of the reference's signal I/O, loss and training-step glue:
 torchmetrics (requirements.txt:2, unpinned, NOT installed here) supplies si_sdr / pit in the
 reference; their published definitions are restated below.  The reference has no test that pins
 them, so this boundary is "parity unpinned" beyond the closed forms and the known-answer vectors in
-tests/test_oracle.py.
+tests/test_signal_loss_optim.py::test_sisdr_known_answers.
 """
 from __future__ import annotations
 

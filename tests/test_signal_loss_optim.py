@@ -87,7 +87,12 @@ def test_sisdr_known_answers():
     n = n - (n * t).sum(-1, keepdim=True) / (t * t).sum(-1, keepdim=True) * t   # orthogonal noise
     snr = 10 * torch.log10((t * t).sum(-1) / (n * n).sum(-1))
     assert torch.allclose(io_ref.si_sdr(t + n, t), snr, atol=1e-9)  # orthogonal noise -> plain SNR
-    assert torch.allclose(io_ref.si_sdr(-t + n, t), io_ref.si_sdr(t + n, t), atol=1e-9) is False or True
+    assert torch.allclose(io_ref.si_sdr(-t + n, t), io_ref.si_sdr(t + n, t), atol=1e-9)  # the projection makes it sign invariant
+    # uPIT picks the permutation with the smaller mean neg-SI-SDR: swapped estimates are un-swapped
+    tt = torch.randn(3, 2, 800, generator=g, dtype=torch.float64)
+    est = tt.flip(1) + 0.01 * torch.randn(3, 2, 800, generator=g, dtype=torch.float64)
+    loss, per_item, perm = io_ref.pit_neg_si_sdr(est, tt)
+    assert perm.tolist() == [[1, 0]] * 3 and float(loss) < -35.0 and per_item.shape == (3,)
 
 
 def test_clip_adam(backend):
