@@ -47,6 +47,28 @@ def _stream(lib: Lib, t: Tensor) -> Optional[int]:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def random_params(lib: Lib, cfg: Cfg, device, seed: int = 0) -> Tensor:
+    """flat fp32 parameter buffer with plausible random values (tools / micro-benchmarks: weights ~ N(0, fan_in^-1/2), norm
+    weights 1, biases small) — no state_dict needed"""
+    n = lib.nbss_param_count(C.byref(cfg))
+    if n <= 0:
+        raise NbssError("unsupported configuration")
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(n, dtype=torch.float32)
+    for name, (off, shape) in param_table(lib, cfg).items():
+        k = 1
+        for d in shape:
+            k *= d
+        if len(shape) == 1:
+            is_norm_w = name.endswith("weight") and ("norm" in name or name.split(".")[-2] in ("0", "6"))
+            v = torch.ones(k) if is_norm_w else (torch.full((k,), 0.25) if len(shape) == 1 and name.endswith(".2.weight") else 0.02 * torch.randn(k, generator=g))
+        else:
+            fan_in = k // shape[0]
+            v = torch.randn(k, generator=g) / fan_in ** 0.5
+        flat[off:off + k] = v
+    return flat.to(device)
+
+
 def flatten_params(lib: Lib, cfg: Cfg, p: Dict[str, Tensor], device) -> Tensor:
     """state_dict-style dict -> flat fp32 buffer in nbss_param_table order."""
     n = lib.nbss_param_count(C.byref(cfg))

@@ -11,7 +11,6 @@ import torch  # noqa: E402
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from nbss_amd import ops  # noqa: E402
 from nbss_amd._lib import NBSS_BF16, hip, make_cfg  # noqa: E402
-from oracle import spatialnet_ref as ref  # noqa: E402
 
 
 def main():
@@ -20,7 +19,7 @@ def main():
     dev = torch.device("cuda:0")
     lib = hip()
     cfg = make_cfg(B, 129, 251, 12, 4, L=1, dtype=NBSS_BF16)
-    flat = ops.flatten_params(lib, cfg, ref.init_params(num_layers=1), dev)
+    flat = ops.random_params(lib, cfg, dev)
     packed = ops.pack_params(lib, cfg, flat)
     x = torch.randn(B, 129, 251, 96, device=dev).bfloat16()
     dy = torch.randn(B, 129, 251, 96, device=dev).bfloat16()

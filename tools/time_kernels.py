@@ -8,7 +8,6 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from nbss_amd import ops  # noqa: E402
 from nbss_amd._lib import NBSS_BF16, NBSS_F32, hip, make_cfg  # noqa: E402
-from oracle import spatialnet_ref as ref  # noqa: E402
 
 
 def timeit(fn, n=20, warm=3):
@@ -31,8 +30,7 @@ def main():
     out = {}
     for dname, dt in (("bf16", NBSS_BF16), ("f32", NBSS_F32)):
         cfg = make_cfg(B, 129, 251, 12, 4, L=1, dtype=dt)
-        p = ref.init_params(num_layers=1)
-        flat = ops.flatten_params(lib, cfg, p, dev)
+        flat = ops.random_params(lib, cfg, dev)
         packed = ops.pack_params(lib, cfg, flat)
         sd = ops.stream_dtype(cfg)
         x = torch.randn(B, 129, 251, 96, device=dev).to(sd)
