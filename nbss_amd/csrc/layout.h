@@ -214,5 +214,7 @@ NBSS_HD int check_cfg(const nbss_cfg& c) {
     if (c.C_in % 4 != 0 || c.C_in > 16 || c.C_out > 16 || c.C_out <= 0) return NBSS_EUNSUPPORTED;
     if (c.F > 160 || c.T > 256) return NBSS_EUNSUPPORTED;
     if (c.full_share < 0 || c.full_share >= c.L) return NBSS_EINVAL;
+    // operand offsets inside the widest tensor ([N][3H] dqkv) are 32-bit in the weight-gradient kernels
+    if ((size_t)c.B * c.F * c.T * 3 * c.H >= ((size_t)1 << 31)) return NBSS_EUNSUPPORTED;
     return NBSS_OK;
 }
