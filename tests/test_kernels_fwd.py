@@ -14,8 +14,11 @@ DTYPES = [pytest.param(NBSS_F32, id="f32"), pytest.param(NBSS_BF16, id="bf16")]
 SHAPES = [(1, 5, 19), (2, 33, 40)]
 
 
+MAX_SHAPES = [(1, 160, 3), (1, 2, 256)]  # the largest F and T check_cfg accepts (10 frequency tiles / 16 full strips)
+
+
 def shapes_for(backend):
-    return SHAPES + ([(2, 129, 251)] if backend.name == "hip" else [])
+    return SHAPES + MAX_SHAPES + ([(2, 129, 251)] if backend.name == "hip" else [])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
