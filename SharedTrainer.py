@@ -171,6 +171,31 @@ def build_module(cfg: dict) -> TrainModule:
     return TrainModule(**kw)
 
 
+def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0) -> None:
+    """Lightning-shaped checkpoint (general_steps.py:189-199 reads `state_dict` with `arch.` keys): the arch weights under the
+    reference's names, plus the fused optimizer's flat Adam moments so that `fit --ckpt_path` resumes exactly."""
+    ck = {"epoch": epoch, "state_dict": {"arch." + k: v.detach().cpu().clone() for k, v in module.arch.state_dict().items()}}
+    if ts is not None:
+        ck["optimizer_states"] = [{"m": ts.m.detach().cpu().clone(), "v": ts.v.detach().cpu().clone(), "step": int(ts.step_count), "lr": float(ts.lr)}]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(ck, path)
+
+
+def load_checkpoint(path: str, module: "TrainModule", ts=None) -> int:
+    """weights (and, when `ts` is given and the file has them, the Adam moments / step / lr); returns the epoch to resume after"""
+    ck = torch.load(path, map_location="cpu")
+    sd = ck.get("state_dict", ck)
+    sd = {k.replace("_orig_mod.", "").removeprefix("arch."): v for k, v in sd.items() if not k.endswith("stft.window")}
+    module.arch.load_state_dict(sd, strict=True)
+    if ts is not None and ck.get("optimizer_states"):
+        o = ck["optimizer_states"][0]
+        if "m" in o:
+            ts.m.copy_(o["m"].to(ts.m.device))
+            ts.v.copy_(o["v"].to(ts.v.device))
+            ts.step_count, ts.lr = int(o["step"]), float(o["lr"])
+    return int(ck.get("epoch", -1))
+
+
 def fit(cfg: dict) -> Dict[str, Any]:
     from nbss_amd._lib import NBSS_BF16, NBSS_F32
     from nbss_amd.engine import TrainStep
@@ -190,6 +215,8 @@ def fit(cfg: dict) -> Dict[str, Any]:
     if data is None:
         from data_loaders.synthetic import SyntheticDataModule
         data = SyntheticDataModule()
+    if cfg.get("ckpt_path"):
+        load_checkpoint(cfg["ckpt_path"], module)  # weights first: the engine binds the parameters below
     eng = module.arch._engine_for(dev)
     eng.dtype = NBSS_BF16 if module.precision in ("bf16-mixed", "bf16") else NBSS_F32
     oname, okw = module.optimizer
@@ -198,8 +225,13 @@ def fit(cfg: dict) -> Dict[str, Any]:
                    betas=tuple(okw.get("betas", (0.9, 0.999))), eps=okw.get("eps", 1e-8), weight_decay=okw.get("weight_decay", 0.0),
                    clip=float(tr.get("gradient_clip_val") or 0.0))
     gamma = (module.lr_scheduler[1].get("gamma", 1.0) if module.lr_scheduler and module.lr_scheduler[0] == "ExponentialLR" else 1.0)
+    first_epoch = 0
+    if cfg.get("ckpt_path"):
+        first_epoch = load_checkpoint(cfg["ckpt_path"], module, ts) + 1  # (weights again: a no-op; now also the Adam state)
+        eng.version += 1
+    ckpt_dir = tr.get("default_root_dir")
     log = []
-    for epoch in range(int(tr.get("max_epochs", 1))):
+    for epoch in range(first_epoch, int(tr.get("max_epochs", 1))):
         t0, n, tot = time.time(), 0, 0.0
         for x, ys, _ in data.batches(0, rank, world, epoch):
             loss = ts.step(x[:, module.channels].to(dev).contiguous(), ys[:, :, module.ref_channel].to(dev).contiguous())
@@ -210,6 +242,8 @@ def fit(cfg: dict) -> Dict[str, Any]:
         log.append(rec)
         if rank == 0:
             print(json.dumps(rec), flush=True)
+            if ckpt_dir:
+                save_checkpoint(os.path.join(ckpt_dir, "checkpoints", "last.ckpt"), module, ts, epoch)
     if world > 1:
         torch.distributed.destroy_process_group()
     return {"log": log, "module": module}
@@ -228,12 +262,8 @@ def _setup(cfg: dict):
     torch.manual_seed(int(cfg.get("seed_everything", 2)))
     module = build_module(cfg).to(dev)
     module.precision = str(tr.get("precision", "32"))
-    ckpt = cfg.get("ckpt_path")
-    if ckpt:  # reference checkpoints: {"state_dict": {"arch.*": ...}} (general_steps.py:189-199 tolerates the _orig_mod. prefix)
-        sd = torch.load(ckpt, map_location="cpu")
-        sd = sd.get("state_dict", sd)
-        sd = {k.replace("_orig_mod.", "").removeprefix("arch."): v for k, v in sd.items() if not k.endswith("stft.window")}
-        module.arch.load_state_dict(sd, strict=True)
+    if cfg.get("ckpt_path"):  # reference-format checkpoints: {"state_dict": {"arch.*": ...}}
+        load_checkpoint(cfg["ckpt_path"], module)
     data = _instantiate(cfg["data"]) if "data" in cfg else None
     if data is None:
         from data_loaders.synthetic import SyntheticDataModule

@@ -57,6 +57,33 @@ def test_validate_test_predict_on_gpu(tmp_path):
     assert (tmp_path / "predict_00000.pt").exists()
 
 
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """save_checkpoint writes the reference's layout (`state_dict` with `arch.` keys, general_steps.py:189-199) plus the flat Adam
+    state; load_checkpoint restores both (and tolerates the `_orig_mod.` prefix of compiled modules)"""
+    from types import SimpleNamespace
+
+    from SharedTrainer import load_checkpoint, save_checkpoint
+    _, c = parse_cli(["fit", "--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml")] + ARGS
+                     + ["--model.arch.num_layers=2"])
+    torch.manual_seed(1)
+    m1 = build_module(c)
+    n = sum(p.numel() for p in m1.arch.parameters())
+    ts1 = SimpleNamespace(m=torch.randn(n), v=torch.rand(n), step_count=7, lr=5e-4)
+    path = str(tmp_path / "checkpoints" / "last.ckpt")
+    save_checkpoint(path, m1, ts1, epoch=3)
+    ck = torch.load(path)
+    assert set(ck) >= {"state_dict", "epoch", "optimizer_states"} and all(k.startswith("arch.") for k in ck["state_dict"])
+    ck["state_dict"] = {k.replace("arch.", "arch._orig_mod.", 1): v for k, v in ck["state_dict"].items()}
+    torch.save(ck, path)
+    torch.manual_seed(2)
+    m2 = build_module(c)
+    ts2 = SimpleNamespace(m=torch.zeros(n), v=torch.zeros(n), step_count=0, lr=1e-3)
+    assert load_checkpoint(path, m2, ts2) == 3
+    for (k1, v1), (k2, v2) in zip(m1.arch.state_dict().items(), m2.arch.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert torch.equal(ts2.m, ts1.m) and torch.equal(ts2.v, ts1.v) and ts2.step_count == 7 and ts2.lr == 5e-4
+
+
 def test_subcommands_fail_loudly_without_a_gpu():
     if torch.cuda.is_available():
         pytest.skip("HIP device present")
