@@ -54,6 +54,45 @@ def test_spatialnet_small_forward_and_grads(reference_modules):
     assert rel_l2(ref.tconvffn(h, p, "layers.3"), h + lay._tconvffn(h)) < 1e-10
 
 
+def test_state_dict_interchanges_with_the_reference(reference_modules, tmp_path):
+    """checkpoint contract: the drop-in module's state_dict loads strictly into the reference's SpatialNet and
+    back, through a file written by SharedTrainer.save_checkpoint"""
+    import importlib.util
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    RefNet = reference_modules["models.arch.SpatialNet"].SpatialNet
+    kw = dict(dim_input=12, dim_output=4, num_layers=3, dim_hidden=96, dim_ffn=192, num_heads=4, kernel_size=(5, 3), conv_groups=(8, 8),
+              norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=8, num_freqs=129, full_share=0)
+    spec = importlib.util.spec_from_file_location("dropin_spatialnet", root / "models" / "arch" / "SpatialNet.py")
+    mod = importlib.util.module_from_spec(spec)
+    saved = {k: v for k, v in sys.modules.items() if k == "models" or k.startswith("models.")}
+    for k in saved:  # the drop-in's own relative imports must resolve against THIS repo, not the reference on sys.path
+        del sys.modules[k]
+    sys.path.insert(0, str(root))
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(str(root))
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    torch.manual_seed(3)
+    ours = mod.SpatialNet(**kw)
+    refnet = RefNet(**kw)
+    sd = ours.state_dict()
+    assert list(sd.keys()) == list(refnet.state_dict().keys())
+    refnet.load_state_dict(sd, strict=True)           # ours -> reference
+    torch.manual_seed(4)
+    ours2 = mod.SpatialNet(**kw)
+    ours2.load_state_dict(refnet.state_dict(), strict=True)  # reference -> ours
+    for (k, a), (_, b) in zip(sd.items(), ours2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # and the oracle evaluated on these weights is the reference's forward (so the HIP path, pinned to the oracle, is too)
+    x = torch.randn(1, 129, 12, 12, dtype=torch.float64)
+    p = {k: v.detach().double() for k, v in sd.items()}
+    assert rel_l2(ref.spatialnet(x, p, 3), refnet.double()(x)) < 1e-10
+
+
 def test_stft_norm_istft(reference_modules):
     STFT, Norm = reference_modules["models.io.stft"].STFT, reference_modules["models.io.norm"].Norm
     stft, norm = STFT(n_fft=256, n_hop=128), Norm(mode="frequency")
