@@ -63,6 +63,11 @@ NBSS_DEV uint32_t pack2bf(float a, float b) {
 }
 #endif
 
+// `cond ? f(x) : 0` with an expensive f compiles to an exec-mask BRANCH around f (one basic block per use: the scheduler cannot move
+// loads or MFMAs across them; the narrow-band backward kernels had one branch per ~20 instructions).  Arguments of a call are
+// evaluated unconditionally, so keep_if(cond, f(x)) is a v_cndmask.
+NBSS_DEV float keep_if(bool c, float v) { return c ? v : 0.f; }
+
 NBSS_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 NBSS_DEV float dsilu_f(float x) {

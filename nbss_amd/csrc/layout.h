@@ -115,6 +115,12 @@ enum PackKind {
     K_TF_W2_T,   // dh5 = W2^T dy: rows = groups x (cg + pad to 32), K = H natural
     K_TF_W1_TN,  // du = W1^T da1 from the emitted [N][FFN] operand: rows = H, K = FFN natural
     K_INP_TN,    // du = Win^T dqkv from the emitted [N][3H] operand: rows = H, K = 3H natural
+    // ---- 32x32x16 fragments of the streaming T-ConvFFN kernels (tconvffn_s.hip): lane l = row l&31, K slots 8(l>>5)+j ----
+    K_TS_W1,     // per group: rows = cg (+pad to 32), K = H natural, 16 per k-step
+    K_TS_C1, K_TS_C2, K_TS_C3,  // t-conv per group: rows = cg out ch, K = (tap, 8-channel block) natural + bias slot (ts_conv_k)
+    K_TS_W2,     // 1x1 FFN->H: rows = H (3 tiles of 32), K = FFN natural
+    K_TS_C1_T, K_TS_C2_T, K_TS_C3_T,  // t-conv^T per group: rows = cg in ch, K = (flipped tap, 8-out-channel block), no bias
+    K_TS_W2_T,   // per group: dh5_g = W2[:, g]^T dy: rows = cg, K = H natural
     NUM_PACK_KINDS
 };
 
@@ -151,8 +157,25 @@ NBSS_HD PackGeom pack_geom(const nbss_cfg& c, int kind) {
         case K_TF_W2_T: g.MT = c.t_groups * cdiv(cg, 32) * 2; g.KS = c.H / 32; break;
         case K_TF_W1_TN: g.MT = c.H / 16; g.KS = c.FFN / 32; break;
         case K_INP_TN: g.MT = c.H / 16; g.KS = 3 * c.H / 32; break;
+        case K_TS_W1: g.MT = 1; g.KS = c.H / 16 + 1; g.NB = c.t_groups; break;  // + one k-step whose first slot is the bias
+        case K_TS_W2_T: g.MT = 1; g.KS = c.H / 16; g.NB = c.t_groups; break;
+        case K_TS_C1: case K_TS_C2: case K_TS_C3: case K_TS_C1_T: case K_TS_C2_T: case K_TS_C3_T:
+            g.MT = 1; g.KS = cdiv(c.t_ks * (cg / 8) + 1, 2); g.NB = c.t_groups; break;
+        case K_TS_W2: g.MT = c.H / 32; g.KS = c.FFN / 16 + 1; break;  // + bias k-step
     }
     return g;
+}
+// K order of the streaming t-conv fragments (32x32x16, tconvffn_s.hip): natural (tap, channel) order in blocks of 8 channels,
+// lane half h of k-step ks takes block 2 ks + h: blocks 0..8 = 3 taps x 3 channel blocks; block 9 (ks = 4, h = 1) carries the
+// BIAS in its first slot (the B operand holds a constant 1 there).  Returns 0 padding, 1 weight (tap, ch), 2 bias slot.
+NBSS_HD int ts_conv_k(int ks, int h, int j, int& tap, int& ch) {
+    const int blk = 2 * ks + h;
+    if (blk < 9) {
+        tap = blk / 3;
+        ch = (blk % 3) * 8 + j;
+        return 1;
+    }
+    return (blk == 9 && j == 0) ? 2 : 0;
 }
 NBSS_HD int64_t pack_numel(const nbss_cfg& c, int kind) {
     PackGeom g = pack_geom(c, kind);

@@ -2,7 +2,7 @@
 //
 // One workgroup (8 waves, two 16-frame strips each) = one (b,f) sequence, one head at a time.
 // Recomputed per head: Q' = q * log2(e)/sqrt(dh), K, V (from LN(x)) and dO = Wo_h^T dy.  LDS holds
-// Q', K, V, dO row-major [T][24] and Q', K, dO transposed [24][T]; nothing else is staged.
+// Q', K, V, dO row-major [T][24] and (fp32 stream only) Q', K transposed [24][T]; nothing else is staged.
 //   pass 1 (wave owns QUERY strips):  S^T = K Q'^T, P, D = rowsum(dO * O), dS^T = P (dP^T - D),
 //                                     dQ^T = K^T dS^T              (O = saved forward attention output)
 //   pass 2 (wave owns KEY strips):    S = Q' K^T, P = exp2(S - m)/l from the stored row statistics,
@@ -86,6 +86,24 @@ NBSS_DEV void col_frag(Frag<T>& f, const T* __restrict__ base, int tp, int half,
     }
 }
 
+// fp32 stream: the same operand gathered from the ROW-MAJOR [tp][24] array with scalar reads (dO has no transposed copy: seven
+// [tp][24] fp32 arrays would not fit 160 KB at tp = 256, and the YAML default `precision: 32` must train 4-s utterances)
+template <class T>
+NBSS_DEV void col_frag_rm(Frag<T>& f, const T* __restrict__ rowmajor, int half, int ks, bool hi_valid) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int d = half * 16 + l15;
+    if (d < MB_DH) {
+        const T* p = rowmajor + (size_t)(ks * 32 + 4 * g4) * MB_DH + d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            frag_set(f, j, load1(p + (size_t)j * MB_DH));
+            frag_set(f, 4 + j, hi_valid ? load1(p + (size_t)(16 + j) * MB_DH) : 0.f);
+        }
+    } else {
+        frag_zero(f);
+    }
+}
+
 // FULL: T in (240, 256] — all 16 strips of every wave exist, so the strip / tile-existence tests are compile-time true and the
 // tile loops have constant trip counts (wave-uniform but dynamic branches kept the compiler from scheduling across them: the same
 // effect cost wgrad 24 %, profiles/README.md row 27)
@@ -103,8 +121,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     constexpr bool TR = sizeof(T) == 2;  // bf16: transposing LDS reads replace the transposed copies
     T* Qt = dOr + (size_t)tp * MB_DH;
     T* Kt = Qt + (size_t)tp * MB_DH;
-    T* dOt = Kt + (size_t)tp * MB_DH;
-    float* m2s = reinterpret_cast<float*>(TR ? Qt : dOt + (size_t)tp * MB_DH);
+    float* m2s = reinterpret_cast<float*>(TR ? Qt : Kt + (size_t)tp * MB_DH);
     float* lis = m2s + tp;
     float* Dds = lis + tp;
     float* aff = Dds + tp;  // [2H] per-workgroup LN weight | bias gradient sums
@@ -295,7 +312,6 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 } else {
                     frag_from_c2(dof[si], ct[si][0], ct[si][1]);
                     store_row24<T>(dOr + (size_t)t * MB_DH, ct[si][0], ct[si][1]);
-                    if (!TR) store_col24<T>(dOt, tp, t, ct[si][0], ct[si][1]);
                     // D = rowsum(dO * O) with the saved forward attention output
                     float dsum = 0.f;
 #pragma unroll
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                         col_frag_tr(ado[half], dOr, half, jp, hi_valid);
                         col_frag_tr(aq[half], Qr, half, jp, hi_valid);
                     } else {
-                        col_frag<T>(ado[half], dOt, tp, half, jp, hi_valid);
+                        col_frag_rm<T>(ado[half], dOr, half, jp, hi_valid);
                         col_frag<T>(aq[half], Qt, tp, half, jp, hi_valid);
                     }
                 }
@@ -516,8 +532,8 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int tp = cdiv(c.T, 16) * 16;
     if (tp > 256) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 7) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + (sizeof(T) == 2 ? (size_t)96 * 512 * sizeof(T) : 0) + PHASE_LDS_BYTES;
-    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // fp32 stream: T <= 224 frames
+    const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 6) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + (sizeof(T) == 2 ? (size_t)96 * 512 * sizeof(T) : 0) + PHASE_LDS_BYTES;
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T, FULL>), lds);
     if (e) return e;

@@ -28,12 +28,56 @@ static int64_t pack_src_base(const nbss_cfg& c, int kind, int layer) {
         case K_TF_W2: case K_TF_W2_T: return param_off(c, layer, P_TF_W2);
         case K_TF_W1_TN: return param_off(c, layer, P_TF_W1);
         case K_INP_TN: return param_off(c, layer, P_INP_W);
+        case K_TS_W1: return param_off(c, layer, P_TF_W1);
+        case K_TS_C1: case K_TS_C1_T: return param_off(c, layer, P_TF_C1W);
+        case K_TS_C2: case K_TS_C2_T: return param_off(c, layer, P_TF_C2W);
+        case K_TS_C3: case K_TS_C3_T: return param_off(c, layer, P_TF_C3W);
+        case K_TS_W2: case K_TS_W2_T: return param_off(c, layer, P_TF_W2);
     }
     return 0;
 }
 
 // value of A[m-tile mt, row i=lane&15][kstep ks, lane group g4, slot j] for (kind, layer, block nb)
-NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the source weight tensor */, int kind, int nb, int mt, int ks, int lane, int j) {
+// flat-buffer offset of the bias a pack kind folds into a spare K slot (-1: none)
+static int64_t pack_src2_base(const nbss_cfg& c, int kind, int layer) {
+    switch (kind) {
+        case K_TS_W1: return param_off(c, layer, P_TF_B1);
+        case K_TS_C1: return param_off(c, layer, P_TF_C1B);
+        case K_TS_C2: return param_off(c, layer, P_TF_C2B);
+        case K_TS_C3: return param_off(c, layer, P_TF_C3B);
+        case K_TS_W2: return param_off(c, layer, P_TF_B2);
+    }
+    return -1;
+}
+
+NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the source weight tensor */, const float* __restrict__ P2 /* its bias */, int kind, int nb,
+                          int mt, int ks, int lane, int j) {
+    if (kind >= K_TS_W1) {  // 32x32x16 fragments: row = lane & 31, K slots 8 (lane >> 5) + j
+        const int m = mt * 32 + (lane & 31), h = lane >> 5, knat = 16 * ks + 8 * h + j;
+        const int cg = c.FFN / c.t_groups;
+        int tap, ch;
+        switch (kind) {
+            case K_TS_W1:
+                if (m >= cg) return 0.f;
+                if (ks == c.H / 16) return (h == 0 && j == 0) ? P2[nb * cg + m] : 0.f;
+                return P[(int64_t)(nb * cg + m) * c.H + knat];
+            case K_TS_W2:
+                if (ks == c.FFN / 16) return (h == 0 && j == 0) ? P2[m] : 0.f;
+                return P[(int64_t)m * c.FFN + knat];
+            case K_TS_W2_T: return m < cg ? P[(int64_t)knat * c.FFN + nb * cg + m] : 0.f;
+            case K_TS_C1: case K_TS_C2: case K_TS_C3: {
+                if (m >= cg) return 0.f;
+                const int kk = ts_conv_k(ks, h, j, tap, ch);
+                if (kk == 2) return P2[nb * cg + m];
+                return kk == 1 ? P[((int64_t)(nb * cg + m) * cg + ch) * c.t_ks + tap] : 0.f;
+            }
+            case K_TS_C1_T: case K_TS_C2_T: case K_TS_C3_T:
+                // dh[t][i] = sum_{tap',o} W[o][i][ks-1-tap'] da[t + tap' - 1][o]
+                if (m >= cg || ts_conv_k(ks, h, j, tap, ch) != 1) return 0.f;
+                return P[((int64_t)(nb * cg + ch) * cg + m) * c.t_ks + (c.t_ks - 1 - tap)];
+        }
+        return 0.f;
+    }
     const int l15 = lane & 15, g4 = lane >> 4;
     const int m = mt * 16 + l15;
     const int knat = ks * 32 + 8 * g4 + j;
@@ -141,7 +185,7 @@ NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the 
 // per-kind source / destination offsets of one layer, resolved on the host (the offset arithmetic loops
 // over layers and kinds: never inside a kernel)
 struct PackTable {
-    long long src[NUM_PACK_KINDS], dst[NUM_PACK_KINDS];
+    long long src[NUM_PACK_KINDS], src2[NUM_PACK_KINDS], dst[NUM_PACK_KINDS];
     int skip[NUM_PACK_KINDS];
 };
 
@@ -153,13 +197,14 @@ __global__ void pack_kernel(nbss_cfg c, PackTable tb, const float* __restrict__ 
     const int64_t n = (int64_t)g.NB * g.MT * g.KS * 512;
     T* dst = out + tb.dst[kind];
     const float* W = P + tb.src[kind];
+    const float* W2 = P + (tb.src2[kind] >= 0 ? tb.src2[kind] : 0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t r = e >> 9;
         const int ks = (int)(r % g.KS);
         r /= g.KS;
         const int mt = (int)(r % g.MT), nb = (int)(r / g.MT);
-        store1(dst + e, pack_value(c, W, kind, nb, mt, ks, lane, j));
+        store1(dst + e, pack_value(c, W, W2, kind, nb, mt, ks, lane, j));
     }
 }
 
@@ -171,6 +216,7 @@ int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipSt
         for (int k = 0; k < NUM_PACK_KINDS; ++k) {
             tb.skip[k] = pack_is_global(k) && layer != 0;
             tb.src[k] = pack_src_base(c, k, layer);
+            tb.src2[k] = pack_src2_base(c, k, layer);
             tb.dst[k] = pack_off(c, layer, k);
         }
         if (c.dtype == NBSS_BF16)

@@ -168,13 +168,8 @@ template <class T>
 NBSS_DEV void store_rows(T* __restrict__ h, int t, bool valid, const f32x4& lo, const f32x4& hi) {
     const int g4 = lane_id() >> 4;
     T* r = h + (size_t)(t + 1) * TF_CG;
-    if (valid) {
-        store4(r + 4 * g4, lo[0], lo[1], lo[2], lo[3]);
-        if (g4 < 2) store4(r + 16 + 4 * g4, hi[0], hi[1], hi[2], hi[3]);
-    } else {
-        store4(r + 4 * g4, 0.f, 0.f, 0.f, 0.f);
-        if (g4 < 2) store4(r + 16 + 4 * g4, 0.f, 0.f, 0.f, 0.f);
-    }
+    store4(r + 4 * g4, keep_if(valid, lo[0]), keep_if(valid, lo[1]), keep_if(valid, lo[2]), keep_if(valid, lo[3]));
+    if (g4 < 2) store4(r + 16 + 4 * g4, keep_if(valid, hi[0]), keep_if(valid, hi[1]), keep_if(valid, hi[2]), keep_if(valid, hi[3]));
 }
 
 // NSW = 16-frame strips per wave: 2 with 8 waves (fp32), 1 with 16 waves (bf16: 4 waves per SIMD to hide the LDS / MFMA chains)
@@ -310,7 +305,7 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f(ct[si][0][r] + b1[cbase + d0 + r]);
-                ct[si][1][r] = v1 ? silu_f(ct[si][1][r] + b1[cbase + d1 + r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(ct[si][1][r] + b1[cbase + d1 + r]));
             }
             store_rows<T>(ha, tt[si], tv[si], ct[si][0], ct[si][1]);
         }
@@ -322,7 +317,7 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f(ct[si][0][r] + cb1[cbase + d0 + r]);
-                ct[si][1][r] = v1 ? silu_f(ct[si][1][r] + cb1[cbase + d1 + r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(ct[si][1][r] + cb1[cbase + d1 + r]));
             }
             store_rows<T>(hb, tt[si], tv[si], ct[si][0], ct[si][1]);
         }
@@ -364,7 +359,7 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f((ct[si][0][r] - mean) * rstd * gnw[cbase + d0 + r] + gnb[cbase + d0 + r]);
-                ct[si][1][r] = v1 ? silu_f((ct[si][1][r] - mean) * rstd * gnw[cbase + d1 + r] + gnb[cbase + d1 + r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f((ct[si][1][r] - mean) * rstd * gnw[cbase + d1 + r] + gnb[cbase + d1 + r]));
             }
             store_rows<T>(ha, tt[si], tv[si], ct[si][0], ct[si][1]);
         }
@@ -377,7 +372,7 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = silu_f(ct[si][0][r] + cb3[cbase + d0 + r]);
-                ct[si][1][r] = v1 ? silu_f(ct[si][1][r] + cb3[cbase + d1 + r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(ct[si][1][r] + cb3[cbase + d1 + r]));
             }
             frag_from_c2(h5[si], ct[si][0], ct[si][1]);
         }
@@ -487,12 +482,13 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         }
     }
 
-    int tt[TF_NSW];
+    int tt[TF_NSW], tc[TF_NSW];
     bool tv[TF_NSW];
 #pragma unroll
     for (int si = 0; si < TF_NSW; ++si) {
         tt[si] = (w * TF_NSW + si) * 16 + l15;
         tv[si] = tt[si] < T_;
+        tc[si] = tv[si] ? tt[si] : T_ - 1;
     }
     // strips beyond the padded length do nothing but must still hit every barrier
     const bool wact = (w * TF_NSW) * 16 < tp;
@@ -511,10 +507,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         float v[TF_KS][8], sum = 0.f;
 #pragma unroll
         for (int ks = 0; ks < TF_KS; ++ks) {
-            if (tv[si]) load8(xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4, v[ks]);
-            else
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+            load8(xb + (size_t)tc[si] * TF_H + ks * 32 + 8 * g4, v[ks]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += v[ks][j];
         }
@@ -558,13 +551,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         for (int si = 0; si < TF_NSW; ++si)
 #pragma unroll
             for (int ks = 0; ks < TF_KS; ++ks) {
-                if (tv[si]) {
-                    frag_load(xr[si][ks], xb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * TF_H + ks * 32 + 8 * g4);
-                } else {
-                    frag_zero(xr[si][ks]);
-                    frag_zero(dr[si][ks]);
-                }
+                // unconditional (clamped) loads: frames beyond T re-read the last frame; LN(x) of such frames is replaced by beta below
+                // and every product of their dy is masked where it is used
+                frag_load(xr[si][ks], xb + (size_t)tc[si] * TF_H + ks * 32 + 8 * g4);
+                frag_load(dr[si][ks], dyb + (size_t)tc[si] * TF_H + ks * 32 + 8 * g4);
+                if (!tv[si]) frag_zero(dr[si][ks]);
             }
         if (STAGE) {
             const StageSrcs<T> wsrc = {W1, Wc1, Wc2, Wc3, W2t, Wc3t, Wc2t, Wc1t};
@@ -612,7 +603,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 a1[si][0][r] += b1[cbase + d0 + r];
                 a1[si][1][r] = v1 ? a1[si][1][r] + b1[cbase + d1 + r] : 0.f;
                 ct[si][0][r] = silu_f(a1[si][0][r]);
-                ct[si][1][r] = v1 ? silu_f(a1[si][1][r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(a1[si][1][r]));
             }
             store_rows<T>(buf0, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.h1, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
@@ -628,7 +619,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 a2[si][0][r] += cb1[cbase + d0 + r];
                 a2[si][1][r] = v1 ? a2[si][1][r] + cb1[cbase + d1 + r] : 0.f;
                 ct[si][0][r] = silu_f(a2[si][0][r]);
-                ct[si][1][r] = v1 ? silu_f(a2[si][1][r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(a2[si][1][r]));
             }
             store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.h2, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
@@ -679,7 +670,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 a3h[si][0][r] = (a3h[si][0][r] - mean) * rstd;                   // \hat a3
                 a3h[si][1][r] = v1 ? (a3h[si][1][r] - mean) * rstd : 0.f;
                 ct[si][0][r] = silu_f(a3h[si][0][r] * gw0[r] + gnb[cbase + d0 + r]);
-                ct[si][1][r] = v1 ? silu_f(a3h[si][1][r] * gw1[r] + gnb[cbase + d1 + r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(a3h[si][1][r] * gw1[r] + gnb[cbase + d1 + r]));
             }
             store_rows<T>(buf2, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.h4, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
@@ -695,7 +686,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
                 a5[si][0][r] += cb3[cbase + d0 + r];
                 a5[si][1][r] = v1 ? a5[si][1][r] + cb3[cbase + d1 + r] : 0.f;
                 ct[si][0][r] = silu_f(a5[si][0][r]);
-                ct[si][1][r] = v1 ? silu_f(a5[si][1][r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, silu_f(a5[si][1][r]));
             }
             store_op<T>(ops.h5, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
         }
@@ -707,7 +698,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = dh5[si][0][r] * dsilu_f(a5[si][0][r]);
-                ct[si][1][r] = v1 ? dh5[si][1][r] * dsilu_f(a5[si][1][r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, dh5[si][1][r] * dsilu_f(a5[si][1][r]));
             }
             store_rows<T>(buf3, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.da5, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
@@ -727,8 +718,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
             for (int r = 0; r < 4; ++r) {
                 const float n30 = a3h[si][0][r] * gw0[r] + gnb[cbase + d0 + r];
                 const float n31 = v1 ? a3h[si][1][r] * gw1[r] + gnb[cbase + d1 + r] : 0.f;
-                ct[si][0][r] = tv[si] ? ct[si][0][r] * dsilu_f(n30) : 0.f;            // dn3
-                ct[si][1][r] = (tv[si] && v1) ? ct[si][1][r] * dsilu_f(n31) : 0.f;
+                ct[si][0][r] = keep_if(tv[si], ct[si][0][r] * dsilu_f(n30));            // dn3
+                ct[si][1][r] = keep_if((tv[si] && v1), ct[si][1][r] * dsilu_f(n31));
                 dgw[0][r] += ct[si][0][r] * a3h[si][0][r];
                 dgw[1][r] += ct[si][1][r] * a3h[si][1][r];
                 dgb[0][r] += ct[si][0][r];
@@ -786,7 +777,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] *= dsilu_f(a2[si][0][r]);
-                ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a2[si][1][r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, ct[si][1][r] * dsilu_f(a2[si][1][r]));
             }
             store_rows<T>(buf1, tt[si], tv[si], ct[si][0], ct[si][1]);
             store_op<T>(ops.da2, n0 + tt[si], tv[si], gr, ntok, ct[si][0], ct[si][1]);
@@ -801,7 +792,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] *= dsilu_f(a1[si][0][r]);
-                ct[si][1][r] = v1 ? ct[si][1][r] * dsilu_f(a1[si][1][r]) : 0.f;
+                ct[si][1][r] = keep_if(v1, ct[si][1][r] * dsilu_f(a1[si][1][r]));
             }
             // the da1 store is deferred until the next group's loads have been issued (they would queue behind it in vmcnt)
             pend[si][0] = ct[si][0];
@@ -826,9 +817,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         for (int k6 = 0; k6 < TF_FFN / 32; ++k6) {
             Frag<T> df;
             const int ch = k6 * 32 + 8 * g4;  // 8-channel pieces never straddle a 24-channel group
-            if (tv[si]) frag_load(df, TF_OPS_GM(T) ? ops.da1 + ((size_t)(ch / TF_CG) * ntok + n0 + tt[si]) * TF_CG + ch % TF_CG
-                                                   : ops.da1 + (n0 + tt[si]) * TF_FFN + ch);
-            else frag_zero(df);
+            frag_load(df, TF_OPS_GM(T) ? ops.da1 + ((size_t)(ch / TF_CG) * ntok + n0 + tc[si]) * TF_CG + ch % TF_CG
+                                       : ops.da1 + (n0 + tc[si]) * TF_FFN + ch);  // (frames beyond T: clamped, their du is discarded)
 #pragma unroll
             for (int mt = 0; mt < TF_H / 16; ++mt) {
                 Frag<T> a;
@@ -851,8 +841,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
         float sum = 0.f;
 #pragma unroll
         for (int mt = 0; mt < TF_H / 16; ++mt) {
-            if (tv[si]) load4(xb + (size_t)tt[si] * TF_H + 16 * mt + 4 * g4, xv[mt]);
-            else xv[mt][0] = xv[mt][1] = xv[mt][2] = xv[mt][3] = 0.f;
+            load4(xb + (size_t)tc[si] * TF_H + 16 * mt + 4 * g4, xv[mt]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum += xv[mt][r];
         }
@@ -1001,6 +990,9 @@ static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed,
     return NBSS_CHECK_LAUNCH();
 }
 
+int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, float* gn_save, hipStream_t st);
+
 int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t, 1>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float, 2>(c, P, packed, layer, x, y, st);
+    // bf16 stream: the streaming wave-per-group kernel (tconvffn_s.hip); fp32 stream: the group-serial kernel above
+    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, nullptr, st) : tconvffn_fwd_t<float, 2>(c, P, packed, layer, x, y, st);
 }

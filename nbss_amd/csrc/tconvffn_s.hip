@@ -1,0 +1,441 @@
+// tconvffn_s.hip — T-ConvFFN kernels for the bf16 stream (SpatialNet.py:90,102-114,61-73):
+//   y = x + W2 * SiLU(gconv3(SiLU(GN(gconv2(SiLU(gconv1(SiLU(W1 * LN(x) + b1))))))))
+//
+// One workgroup (8 waves) = one (b,f) sequence.  The FFN-wide activations of the WHOLE sequence live in ONE bf16 LDS image
+// [T + 4][192] that every stage updates in place; two kinds of phases alternate:
+//   * strip phases (wave w owns frames 32w..32w+31, all channels): LayerNorm + W1 at the start, W2 + residual at the end;
+//   * group phases (wave g owns the 24 channels of conv group g = GroupNorm group g, ALL frames): the three k=3 grouped convs
+//     and GroupNorm.  A group's chain touches only its own 48-byte column slice of the image, so the group phases need NO
+//     workgroup barrier: each conv stage walks the sequence in blocks of strips (independent MFMA chains -> ILP), reads its
+//     three taps as row-shifted 16-byte LDS reads and writes its output ONE ROW LOWER than its input — the rows a later block
+//     still needs are never overwritten.  The group's conv weights stay in registers for the whole kernel, GroupNorm statistics
+//     are a wave-local reduction.
+// Products are v_mfma_f32_32x32x16_bf16: weights = A (24 of 32 rows), 32 frames = N; a D tile gives a lane 12 valid channels
+// (rows (r&3) + 8(r>>2) + 4(lane>>5), r < 12) of frame lane&31, i.e. three 8-byte pieces of an image row.  Biases ride in spare
+// K slots of the packed weights (layout.h: ts_conv_k) against a constant-1 slot of the B operand.
+// The fp32 stream keeps the group-serial kernels of tconvffn.hip.
+#include "launch.h"
+#include "layout.h"
+#include "prof.h"
+
+#define TS_H 96
+#define TS_FFN 192
+#define TS_G 8
+#define TS_CG 24
+#define TS_RS 200   // image row stride in elements (400 B: 16 consecutive frames hit 16 distinct 16-byte bank groups)
+#define TS_PAD 4    // rows: 3 for the three downward shifts of the conv stages + 1 zero row above the last frame
+#define TS_ONE 0x3F80u  // bf16 1.0 in the low half of a dword
+#define TS_WL_FR 56  // fragments in the LDS weight window (W1: 8 groups x 7; W2: 3 x 13 = 39)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef Frag<bf16_t> FragH;
+
+NBSS_DEV f32x16 mma32(const FragH& a, const FragH& b, f32x16 c) {
+#ifdef NBSS_EMU
+    return hipemu::mfma_32x32x16_bf16(a.v, b.v, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+#endif
+}
+NBSS_DEV f32x16 f32x16_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// LDS written by one lane and read by another lane of the SAME wave: the hardware executes a wave's LDS instructions in order;
+// the compiler must not reorder across this point and the emulator's fibers must meet here
+NBSS_DEV void wave_lds_sync() {
+#ifdef NBSS_EMU
+    hipemu::wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+NBSS_DEV float bf_lo(uint32_t d) { return __builtin_bit_cast(float, d << 16); }
+NBSS_DEV float bf_hi(uint32_t d) { return __builtin_bit_cast(float, d & 0xFFFF0000u); }
+
+// the 12 valid values of a D tile packed pairwise: d[2q], d[2q+1] = channels 8q + 4h + 0..3 (one 8-byte piece of an image row)
+struct P6 {
+    uint32_t d[6];
+};
+NBSS_DEV void p6_store(bf16_t* r, const P6& p) {  // r = &img[row][24 g + 4 h]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x2 v = {p.d[2 * q], p.d[2 * q + 1]};
+        *reinterpret_cast<u32x2*>(r + 8 * q) = v;
+    }
+}
+NBSS_DEV void p6_load(const bf16_t* r, P6& p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(r + 8 * q);
+        p.d[2 * q] = v[0];
+        p.d[2 * q + 1] = v[1];
+    }
+}
+// Masking is ALWAYS a bitwise AND with an all-ones / zero lane mask: `valid ? f(x) : 0` around a transcendental compiles to
+// exec-mask branches, which cut a stage into small basic blocks that the scheduler cannot move loads or MFMAs across.
+NBSS_DEV uint32_t lane_mask(bool valid) { return valid ? 0xFFFFFFFFu : 0u; }
+NBSS_DEV void silu_pack(const f32x16& a, uint32_t vm, P6& out) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out.d[i] = pack2bf(silu_f(a[2 * i]), silu_f(a[2 * i + 1])) & vm;
+}
+
+NBSS_DEV FragH frag_const_one() {  // K slot 0 = 1.0, the rest 0: the B side of a bias slot
+    u32x4 v = {TS_ONE, 0u, 0u, 0u};
+    FragH f;
+    f.v = __builtin_bit_cast(s16x8, v);
+    return f;
+}
+
+// per-lane vector of a per-channel parameter in D-register order (rows >= 24 of the tile are padding)
+NBSS_DEV void chan_vec12(const float* __restrict__ p, int h, float (&v)[12]) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) load4(p + 8 * q + 4 * h, &v[4 * q]);
+}
+
+template <int N>
+NBSS_DEV void load_wfrags(FragH (&w)[N], const bf16_t* __restrict__ base, int blk, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < N; ++ks) frag_load(w[ks], base + ((size_t)(blk * N + ks) * 64 + lane) * 8);
+}
+
+struct TsLane {
+    int lane, n, h;
+    NBSS_DEV TsLane() {
+        lane = lane_id();
+        n = lane & 31;
+        h = lane >> 5;
+    }
+};
+
+// B fragments of a k=3 grouped conv for one strip: k-step ks, lane half h = block 2ks + h of (tap, 8 channels); block 9 = bias slot.
+// `row0` = &img[in_off + 32 s + n][24 g]  (the frame's own row in the stage's input numbering)
+NBSS_DEV void conv_bfrags(const TsLane& L, const bf16_t* row0, FragH (&b)[5]) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int b0 = 2 * ks, b1 = ks < 4 ? 2 * ks + 1 : 8;  // (k-step 4: both halves read block 8; h = 1 is overridden below)
+        const bf16_t* p = row0 + (L.h ? ((b1 / 3 - 1) * TS_RS + (b1 % 3) * 8) : ((b0 / 3 - 1) * TS_RS + (b0 % 3) * 8));
+        frag_load(b[ks], p);
+    }
+    const FragH one = frag_const_one();
+    if (L.h) b[4].v = one.v;
+}
+
+NBSS_DEV f32x16 conv_mma(const FragH (&w)[5], const FragH (&b)[5]) {
+    f32x16 acc = mma32(w[0], b[0], f32x16_zero());
+#pragma unroll
+    for (int ks = 1; ks < 5; ++ks) acc = mma32(w[ks], b[ks], acc);
+    return acc;
+}
+
+struct TsFwdW {  // packed fragment bases of one layer
+    const bf16_t *W1, *C1, *C2, *C3, *W2;
+};
+
+#define TS_SB 2  // strips per block of a group phase (independent MFMA chains in flight)
+
+// gn_save: optional [B*F][G][2] (mean, rstd) of every GroupNorm group for the backward pass
+__global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPtrs lp, TsFwdW W, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                             float* __restrict__ gn_save) {
+    NBSS_LDS(smem);
+    const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32;
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem);  // [NT + TS_PAD][TS_RS]
+    bf16_t* wl = img + (size_t)(NT + TS_PAD) * TS_RS;  // [56 | 39 fragments][512]: W1 during strip phase 0, then W2
+    PHASE_BEGIN(wl + (size_t)TS_WL_FR * 512);
+    const TsLane L;
+    const int w = wave_id_u(), tid = threadIdx.x;
+    // the group's conv weights for the group phases: requested first, resident for the whole kernel
+    FragH wc1[5], wc2[5], wc3[5];
+    load_wfrags<5>(wc1, W.C1, w, L.lane);
+    load_wfrags<5>(wc2, W.C2, w, L.lane);
+    load_wfrags<5>(wc3, W.C3, w, L.lane);
+    // One workgroup per sequence.  (A persistent grid of 256 workgroups looping over sequences was measured SLOWER, 675 vs 524 us
+    // per launch at batch 31: all CUs then march through the HBM-latency and the VALU-bound phases in lock step.)
+    const int bf = blockIdx.x;
+    {
+    const bf16_t* xb = x + (size_t)bf * T_ * TS_H;
+    bf16_t* yb = y + (size_t)bf * T_ * TS_H;
+
+    // ---- strip phase 0: h1 = SiLU(W1 LN(x) + b1) for the wave's 32 frames, all 8 groups -> image rows 3 + t -------------------
+    // (rows 0..2 are the "frame -1" rows of the three conv stages; row NT + 3 is "frame NT" of the first one)
+    // The 56 W1 fragments go global -> LDS ONCE per workgroup: eight waves fetching them separately is 448 KB per sequence through
+    // a 64 B/clk L1 (7k cycles); the same holds for the 39 W2 fragments of the last phase.
+    {
+        constexpr int NV = TS_G * 7 * 64;  // 16-byte vectors
+        u32x4 wr[NV / 512];
+#pragma unroll
+        for (int i = 0; i < NV / 512; ++i) wr[i] = reinterpret_cast<const u32x4*>(W.W1)[tid + i * 512];
+#pragma unroll
+        for (int i = 0; i < NV / 512; ++i) reinterpret_cast<u32x4*>(wl)[tid + i * 512] = wr[i];
+    }
+    for (int i = tid; i < 3 * TS_RS / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(img)[i] = 0u;
+    for (int i = tid; i < TS_RS / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(img + (size_t)(NT + 3) * TS_RS)[i] = 0u;
+    u32x4 raw[6];
+    {
+        const int t = 32 * w + L.n, tc = t < T_ ? t : T_ - 1;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) raw[ks] = *reinterpret_cast<const u32x4*>(xb + (size_t)tc * TS_H + 16 * ks + 8 * L.h);
+    }
+    lds_barrier();  // W1 fragments are in LDS
+    if (w < NS) {
+        const int t = 32 * w + L.n;
+        const bool tv = t < T_;
+        // LN(x) of the frame as natural-order B fragments: lane half h holds channels 16 ks + 8 h + j
+        float v[6][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[ks][2 * j] = bf_lo(raw[ks][j]);
+                v[ks][2 * j + 1] = bf_hi(raw[ks][j]);
+                sum += v[ks][2 * j] + v[ks][2 * j + 1];
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / TS_H);
+        float sq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[ks][j] -= mean;
+                sq += v[ks][j] * v[ks][j];
+            }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / TS_H) + 1e-5f);
+        FragH u[7];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            float gam[8], bet[8], o[8];
+            load8(lp.p[P_TF_LN_W] + 16 * ks + 8 * L.h, gam);
+            load8(lp.p[P_TF_LN_B] + 16 * ks + 8 * L.h, bet);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[ks][j] * rstd * gam[j] + bet[j];
+            frag_from(u[ks], o);
+        }
+        {
+            const FragH one = frag_const_one();
+            FragH zero;
+            frag_zero(zero);
+            u[6].v = L.h ? zero.v : one.v;  // bias k-step of K_TS_W1: slot (h = 0, j = 0)
+        }
+        bf16_t* orow = img + (size_t)(3 + t) * TS_RS + 4 * L.h;
+        const uint32_t vm = lane_mask(tv);
+#pragma unroll 2
+        for (int g = 0; g < TS_G; ++g) {
+            FragH w1[7];
+            load_wfrags<7>(w1, wl, g, L.lane);
+            f32x16 a1 = mma32(w1[0], u[0], f32x16_zero());
+#pragma unroll
+            for (int ks = 1; ks < 7; ++ks) a1 = mma32(w1[ks], u[ks], a1);
+            P6 h1;
+            silu_pack(a1, vm, h1);
+            p6_store(orow + g * TS_CG, h1);
+        }
+    }
+    PHASE(0);
+    lds_barrier();
+    PHASE(1);
+    // W2 fragments: requested now, parked in registers during conv1, written over W1 after it (visible after the last barrier)
+    constexpr int NV2 = 3 * (TS_FFN / 16 + 1) * 64;
+    u32x4 w2r[(NV2 + 511) / 512];
+#pragma unroll
+    for (int i = 0; i < (NV2 + 511) / 512; ++i) {
+        const int v = tid + i * 512;
+        w2r[i] = reinterpret_cast<const u32x4*>(W.W2)[v < NV2 ? v : NV2 - 1];
+    }
+
+    // ---- group phases: wave g owns channels 24g..24g+23 of every row ------------------------------------------------------------
+    const int g = w, cbase = g * TS_CG;
+    bf16_t* col = img + cbase;  // &img[0][24 g]
+    // conv1: h1 (rows 3 + t) -> h2 = SiLU(.) (rows 2 + t)
+#pragma unroll 1
+    for (int s0 = 0; s0 < NS; s0 += TS_SB) {
+        FragH b[TS_SB][5];
+#pragma unroll
+        for (int k = 0; k < TS_SB; ++k)
+            if (s0 + k < NS) conv_bfrags(L, col + (size_t)(3 + 32 * (s0 + k) + L.n) * TS_RS, b[k]);
+#pragma unroll
+        for (int k = 0; k < TS_SB; ++k)
+            if (s0 + k < NS) {
+                const f32x16 a2 = conv_mma(wc1, b[k]);
+                P6 h2;
+                silu_pack(a2, lane_mask(32 * (s0 + k) + L.n < T_), h2);
+                p6_store(col + (size_t)(2 + 32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, h2);
+            }
+    }
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(col + (size_t)(2 + NT) * TS_RS + 4 * L.lane) = (u32x2){0u, 0u};  // "frame NT" of the next stage
+#pragma unroll
+    for (int i = 0; i < (NV2 + 511) / 512; ++i) {
+        const int v = tid + i * 512;
+        if (v < NV2) reinterpret_cast<u32x4*>(wl)[v] = w2r[i];
+    }
+    wave_lds_sync();
+    PHASE(2);
+    // conv2: h2 (rows 2 + t) -> a3 (bf16, rows 1 + t); GroupNorm statistics over the valid frames
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+    for (int s0 = 0; s0 < NS; s0 += TS_SB) {
+        FragH b[TS_SB][5];
+#pragma unroll
+        for (int k = 0; k < TS_SB; ++k)
+            if (s0 + k < NS) conv_bfrags(L, col + (size_t)(2 + 32 * (s0 + k) + L.n) * TS_RS, b[k]);
+#pragma unroll
+        for (int k = 0; k < TS_SB; ++k)
+            if (s0 + k < NS) {
+                const f32x16 a3 = conv_mma(wc2, b[k]);
+                const uint32_t vm = lane_mask(32 * (s0 + k) + L.n < T_);
+                P6 a3p;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    a3p.d[i] = pack2bf(a3[2 * i], a3[2 * i + 1]) & vm;
+                    const float v0 = bf_lo(a3p.d[i]), v1 = bf_hi(a3p.d[i]);  // statistics of the bf16 values GroupNorm sees (0 beyond T)
+                    s1 += v0 + v1;
+                    s2 += v0 * v0 + v1 * v1;
+                }
+                p6_store(col + (size_t)(1 + 32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, a3p);
+            }
+    }
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(col + (size_t)(1 + NT) * TS_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    s1 = wave_sum64(s1);
+    s2 = wave_sum64(s2);
+    const float cnt = (float)(TS_CG * T_);
+    const float mean = s1 / cnt;
+    const float rstd = rsqrtf(fmaxf(s2 / cnt - mean * mean, 0.f) + 1e-5f);
+    if (gn_save && L.lane == 0) {
+        gn_save[((size_t)bf * TS_G + g) * 2] = mean;
+        gn_save[((size_t)bf * TS_G + g) * 2 + 1] = rstd;
+    }
+    PHASE(3);
+    // GroupNorm + SiLU in place (each lane rewrites the values it wrote: no cross-lane hazard)
+    {
+        float gsc[12], gsh[12];
+        chan_vec12(lp.p[P_TF_GN_W] + cbase, L.h, gsc);
+        chan_vec12(lp.p[P_TF_GN_B] + cbase, L.h, gsh);
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            gsc[r] *= rstd;
+            gsh[r] -= mean * gsc[r];
+        }
+#pragma unroll 2
+        for (int s = 0; s < NS; ++s) {
+            bf16_t* r = col + (size_t)(1 + 32 * s + L.n) * TS_RS + 4 * L.h;
+            P6 a3p, h4;
+            p6_load(r, a3p);
+            const uint32_t vm = lane_mask(32 * s + L.n < T_);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float n0 = bf_lo(a3p.d[i]) * gsc[2 * i] + gsh[2 * i], n1 = bf_hi(a3p.d[i]) * gsc[2 * i + 1] + gsh[2 * i + 1];
+                h4.d[i] = pack2bf(silu_f(n0), silu_f(n1)) & vm;
+            }
+            p6_store(r, h4);
+        }
+    }
+    wave_lds_sync();
+    PHASE(4);
+    // conv3: h4 (rows 1 + t) -> h5 = SiLU(.) (rows t)
+#pragma unroll 1
+    for (int s0 = 0; s0 < NS; s0 += TS_SB) {
+        FragH b[TS_SB][5];
+#pragma unroll
+        for (int k = 0; k < TS_SB; ++k)
+            if (s0 + k < NS) conv_bfrags(L, col + (size_t)(1 + 32 * (s0 + k) + L.n) * TS_RS, b[k]);
+#pragma unroll
+        for (int k = 0; k < TS_SB; ++k)
+            if (s0 + k < NS) {
+                const f32x16 a5 = conv_mma(wc3, b[k]);
+                P6 h5;
+                silu_pack(a5, lane_mask(32 * (s0 + k) + L.n < T_), h5);
+                p6_store(col + (size_t)(32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, h5);
+            }
+    }
+    PHASE(5);
+    // ---- strip phase 1: y = x + W2 h5 + b2 for the wave's 32 frames.  The branch output goes back into the wave's own image rows
+    // (bf16) and leaves as full-row 16-byte pieces (12 per frame, lane-contiguous) together with the residual rows, which are
+    // requested before the barrier ---------------------------------------------------------------------------------------------
+    const int s = w;
+    constexpr int K2 = TS_FFN / 16 + 1;
+    u32x4 xres[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int idx = L.lane + 64 * k, tr = 32 * s + idx / 12, trc = tr < T_ ? tr : T_ - 1;
+        xres[k] = *reinterpret_cast<const u32x4*>(xb + (size_t)trc * TS_H + 8 * (idx % 12));
+    }
+    lds_barrier();
+    PHASE(6);
+    if (s < NS) {
+    const int t = 32 * s + L.n;
+    f32x16 acc[3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) acc[mt] = f32x16_zero();
+    bf16_t* hrow = img + (size_t)t * TS_RS;
+#pragma unroll
+    for (int ks = 0; ks < K2; ++ks) {
+        FragH b;
+        if (ks < K2 - 1) frag_load(b, hrow + 16 * ks + 8 * L.h);
+        else {
+            const FragH one = frag_const_one();
+            FragH zero;
+            frag_zero(zero);
+            b.v = L.h ? zero.v : one.v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            FragH a;
+            frag_load(a, wl + ((size_t)(mt * K2 + ks) * 64 + L.lane) * 8);
+            acc[mt] = mma32(a, b, acc[mt]);
+        }
+    }
+    PHASE(7);
+    wave_lds_sync();  // every lane has read its h5 row before the rows are overwritten
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x2 v = {pack2bf(acc[mt][4 * q], acc[mt][4 * q + 1]), pack2bf(acc[mt][4 * q + 2], acc[mt][4 * q + 3])};
+            *reinterpret_cast<u32x2*>(hrow + 32 * mt + 8 * q + 4 * L.h) = v;
+        }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int idx = L.lane + 64 * k, tr = 32 * s + idx / 12, pc = idx % 12;
+        const u32x4 br = *reinterpret_cast<const u32x4*>(img + (size_t)tr * TS_RS + 8 * pc);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pack2bf(bf_lo(xres[k][j]) + bf_lo(br[j]), bf_hi(xres[k][j]) + bf_hi(br[j]));
+        if (tr < T_) *reinterpret_cast<u32x4*>(yb + (size_t)tr * TS_H + 8 * pc) = o;
+    }
+    }
+    PHASE(8);
+    }
+    PHASE_END();
+}
+PHASE_READER(nbss_phase_read_tconvffn_fwd)
+
+size_t tconvffn_s_fwd_lds(int T) {
+    const size_t NT = (size_t)((T + 31) / 32) * 32;
+    return (NT + TS_PAD) * TS_RS * sizeof(bf16_t) + (size_t)TS_WL_FR * 512 * sizeof(bf16_t) + PHASE_LDS_BYTES;
+}
+
+// bf16 stream only; returns NBSS_EUNSUPPORTED when the sequence does not fit the LDS image
+int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, float* gn_save, hipStream_t st) {
+    if (c.dtype != NBSS_BF16) return NBSS_EUNSUPPORTED;
+    const size_t lds = tconvffn_s_fwd_lds(c.T);
+    if (lds > 160 * 1024 || c.T > 256) return NBSS_EUNSUPPORTED;
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const bf16_t* pk = (const bf16_t*)packed;
+    TsFwdW W = {pk + pack_off(c, layer, K_TS_W1), pk + pack_off(c, layer, K_TS_C1), pk + pack_off(c, layer, K_TS_C2), pk + pack_off(c, layer, K_TS_C3),
+                pk + pack_off(c, layer, K_TS_W2)};
+    int e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel, lds);
+    if (e) return e;
+    dim3 grid(c.B * c.F), block(512);
+    ProfScope ps(PK_TCF_F, st);
+    NBSS_LAUNCH(tconvffn_fwd_s_kernel, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, gn_save);
+    return NBSS_CHECK_LAUNCH();
+}

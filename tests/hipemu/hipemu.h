@@ -147,6 +147,33 @@ inline f32x4_t mfma_16x16x4_f32(float a, float b, f32x4_t c) {
     return d;
 }
 
+
+// v_mfma_f32_32x32x16_bf16:  A lane l holds A[l&31][(l>>5)*8 + j], B lane l holds B[(l>>5)*8 + j][l&31],
+// C/D lane l reg r holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+inline f32x16_t mfma_32x32x16_bf16(s16x8_t a, s16x8_t b, f32x16_t c) {
+    Wave& w = cur_wave();
+    int l = g_fiber->lane;
+    std::memcpy(w.scratch[l], &a, 16);
+    std::memcpy(w.scratch[l] + 16, &b, 16);
+    wave_sync();
+    int col = l & 31, hf = l >> 5;
+    f32x16_t d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        float acc = d[r];
+        for (int g = 0; g < 2; ++g) {
+            unsigned short av[8], bv[8];
+            std::memcpy(av, w.scratch[g * 32 + row], 16);
+            std::memcpy(bv, w.scratch[g * 32 + col] + 16, 16);
+            for (int j = 0; j < 8; ++j) acc = std::fmaf(bf16_bits_to_f32(av[j]), bf16_bits_to_f32(bv[j]), acc);
+        }
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
+
 // ds_read_b64_tr_b16 (gfx950), semantics pinned on hardware by tools/probe/tr_read.cpp: every lane loads 4 x b16 from ITS
 // address; within each 16-lane group  out[l][j] = in[lane 4j + (l>>2)][l & 3]  — a 4-row x 16-column block whose lane p holds
 // row p>>2, columns 4(p&3)..+3 comes back as lane = column, elements = the 4 rows.

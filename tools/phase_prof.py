@@ -15,7 +15,7 @@ from nbss_amd._lib import NBSS_BF16, hip, make_cfg  # noqa: E402
 
 def main():
     name = sys.argv[1]
-    B, iters = 8, 3
+    B, iters = (int(sys.argv[2]) if len(sys.argv) > 2 else 8), 3
     dev = torch.device("cuda:0")
     lib = hip()
     cfg = make_cfg(B, 129, 251, 12, 4, L=1, dtype=NBSS_BF16)
