@@ -66,12 +66,18 @@ class TrainModule(nn.Module):
     def _fusable(self) -> bool:
         return self.norm.mode == "frequency" and self.norm.online and self.loss.mask is None
 
+    def _fused_path(self, x: Tensor) -> bool:
+        from models.arch.SpatialNet import SpatialNet
+        return isinstance(self.arch, SpatialNet) and x.is_cuda and self._fusable() and self.stft.hip_ok
+
     def forward(self, x: Tensor, istft: bool = True):
-        """x [B,C,N] -> (yr_hat [B,Spk,N], loss_paras)   (reference :104-132)"""
+        """x [B,C,N] -> (yr_hat [B,Spk,N], loss_paras)   (reference :104-132).  SpatialNet on a HIP device with the shipped I/O
+        configuration takes the fused kernels (STFT+norm, network, inorm+iSTFT); every other combination — the narrow-band archs,
+        other Norm modes, host tensors — walks the reference's module sequence (stft -> norm -> arch -> inorm -> istft)."""
+        if not self._fused_path(x):
+            return self._forward_modules(x, istft)
         from nbss_amd import ops
         from nbss_amd._lib import NBSS_BF16, NBSS_F32, hip
-        if not self._fusable():
-            raise NotImplementedError("TrainModule on MI355X serves Norm('frequency', online=True) + non-mask losses (configs/SpatialNet.yaml)")
         xs = x[:, self.channels].float().contiguous()
         N = xs.shape[-1]
         tables = self.stft._tables(xs.device)
@@ -83,6 +89,22 @@ class TrainModule(nn.Module):
             B, F, T, S2 = out.shape
             return out.float() * xrmm[..., None], {"XrMM": xrmm}
         return _FusedIO.apply(out, xrmm, tables, self.stft.n_fft, N), {"XrMM": xrmm}
+
+    def _forward_modules(self, x: Tensor, istft: bool = True):
+        X, length = self.stft.stft(x[:, self.channels])  # [B,C,F,T] complex
+        B, C, F, T = X.shape
+        X, (Xr, XrMM) = self.norm.norm(X, ref_channel=self.channels.index(self.ref_channel))
+        feats = torch.view_as_real(X.permute(0, 2, 3, 1).contiguous()).reshape(B, F, T, 2 * C)
+        bf16 = self.precision in ("bf16-mixed", "bf16") and x.is_cuda
+        with torch.autocast(x.device.type, dtype=torch.bfloat16, enabled=bf16):
+            out = self.arch(feats)
+        if not torch.is_complex(out):
+            out = torch.view_as_complex(out.float().reshape(B, F, T, -1, 2).contiguous())
+        out = out.permute(0, 3, 1, 2)  # [B,Spk,F,T]
+        Yr_hat, loss_paras = self.loss.to_CC(out=out, Xr=Xr, XrMM=XrMM, stft=self.stft)
+        if self.loss.mask is None:
+            Yr_hat = self.norm.inorm(out, (Xr, XrMM))
+        return (self.stft.istft(Yr_hat, length) if istft else torch.view_as_real(Yr_hat)), loss_paras
 
     def training_step(self, batch, batch_idx=0):
         x, ys, paras = batch
@@ -171,37 +193,99 @@ def build_module(cfg: dict) -> TrainModule:
     return TrainModule(**kw)
 
 
-def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0) -> None:
-    """Lightning-shaped checkpoint (general_steps.py:189-199 reads `state_dict` with `arch.` keys): the arch weights under the
-    reference's names, plus the fused optimizer's flat Adam moments so that `fit --ckpt_path` resumes exactly."""
-    ck = {"epoch": epoch, "state_dict": {"arch." + k: v.detach().cpu().clone() for k, v in module.arch.state_dict().items()}}
+def _unique_params(module: "TrainModule"):
+    """(name, parameter) in torch.optim order: what `Adam(module.parameters())` indexes its state by (shared tensors once)"""
+    return list(module.named_parameters())
+
+
+def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, global_step: int = 0) -> None:
+    """Lightning-shaped checkpoint that the reference's trainer can load: `state_dict` with the reference's keys (`arch.*` and the
+    persistent `stft.window` buffer, general_steps.py:189-199), `optimizer_states[0]` as a torch.optim.Adam state_dict (per-parameter
+    `exp_avg` / `exp_avg_sq` / `step` sliced out of the fused optimizer's flat buffers, in `module.parameters()` order),
+    `lr_schedulers`, `epoch`, `global_step`, `pytorch-lightning_version`."""
+    sd = {"arch." + k: v.detach().cpu().clone() for k, v in module.arch.state_dict().items()}
+    sd["stft.window"] = module.stft.window.detach().cpu().clone()
+    ck = {"epoch": epoch, "global_step": global_step, "pytorch-lightning_version": "2.0.0", "state_dict": sd, "loops": {}, "callbacks": {},
+          "hyper_parameters": {}}
     if ts is not None:
-        ck["optimizer_states"] = [{"m": ts.m.detach().cpu().clone(), "v": ts.v.detach().cpu().clone(), "step": int(ts.step_count), "lr": float(ts.lr)}]
+        eng = ts.e
+        state = {}
+        for i, (name, p) in enumerate(_unique_params(module)):
+            off, _ = eng.table[name.removeprefix("arch.")]
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(ts.step_count)), "exp_avg": ts.m[off:off + n].view_as(p).detach().cpu().clone(),
+                        "exp_avg_sq": ts.v[off:off + n].view_as(p).detach().cpu().clone()}
+        group = {"lr": float(ts.lr), "betas": tuple(ts.betas), "eps": ts.eps, "weight_decay": ts.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
+        ck["optimizer_states"] = [{"state": state, "param_groups": [group]}]
+        ck["lr_schedulers"] = [{"last_epoch": epoch + 1, "_last_lr": [float(ts.lr)]}]
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ck, path)
 
 
 def load_checkpoint(path: str, module: "TrainModule", ts=None) -> int:
-    """weights (and, when `ts` is given and the file has them, the Adam moments / step / lr); returns the epoch to resume after"""
-    ck = torch.load(path, map_location="cpu")
+    """weights and — when `ts` is given — the Adam moments / step / decayed lr of a checkpoint written by save_checkpoint OR by the
+    reference's Lightning trainer (same layout: torch.optim state indexed in `module.parameters()` order); returns the epoch to resume
+    after.  A checkpoint without optimizer state resumes with fresh moments and says so."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
     sd = ck.get("state_dict", ck)
     sd = {k.replace("_orig_mod.", "").removeprefix("arch."): v for k, v in sd.items() if not k.endswith("stft.window")}
     module.arch.load_state_dict(sd, strict=True)
-    if ts is not None and ck.get("optimizer_states"):
-        o = ck["optimizer_states"][0]
-        if "m" in o:
-            ts.m.copy_(o["m"].to(ts.m.device))
-            ts.v.copy_(o["v"].to(ts.v.device))
-            ts.step_count, ts.lr = int(o["step"]), float(o["lr"])
+    if ts is not None:
+        opt = (ck.get("optimizer_states") or [None])[0]
+        if opt and "state" in opt and len(opt["state"]) > 0:
+            eng = ts.e
+            names = _unique_params(module)
+            if len(opt["state"]) != len(names):
+                raise RuntimeError(f"{path}: optimizer state has {len(opt['state'])} entries, the model has {len(names)} parameters")
+            for i, (name, p) in enumerate(names):
+                st = opt["state"][i]
+                off, _ = eng.table[name.removeprefix("arch.")]
+                ts.m[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1).to(ts.m.device))
+                ts.v[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1).to(ts.v.device))
+            ts.step_count = int(float(opt["state"][0]["step"]))
+            ts.lr = float(opt["param_groups"][0]["lr"])
+        else:
+            print(f"[SharedTrainer] {path} has no optimizer state: Adam moments, step count and learning rate start fresh", flush=True)
     return int(ck.get("epoch", -1))
 
 
-def fit(cfg: dict) -> Dict[str, Any]:
+def _fused_step_for(module: "TrainModule", cfg: dict, dev):
+    """engine.TrainStep for a TrainModule whose configuration the fused HIP step implements; everything else raises HERE (the fused
+    step hard-wires Norm('frequency', online) + uPIT neg-SI-SDR, so a different YAML must not train a different model silently)"""
     from nbss_amd._lib import NBSS_BF16, NBSS_F32
     from nbss_amd.engine import TrainStep
+    from models.arch.SpatialNet import SpatialNet
+    tr = cfg.get("trainer", {})
+    if not isinstance(module.arch, SpatialNet):
+        raise NotImplementedError(f"the fused MI355X step serves models.arch.SpatialNet.SpatialNet, not {type(module.arch).__name__}")
+    if not module._fusable() or not module.loss.pit:
+        raise NotImplementedError("the fused MI355X step implements norm = Norm('frequency', online=True) and loss = Loss(neg_si_sdr, pit=True) "
+                                  f"(configs/SpatialNet.yaml); got norm=({module.norm.mode}, online={module.norm.online}), pit={module.loss.pit}")
+    eng = module.arch._engine_for(dev)
+    eng.dtype = NBSS_BF16 if module.precision in ("bf16-mixed", "bf16") else NBSS_F32
+    oname, okw = module.optimizer
+    if oname not in ("Adam", "AdamW"):
+        raise NotImplementedError(f"optimizer {oname}: the fused kernel implements torch.optim.Adam and torch.optim.AdamW")
+    wd = okw.get("weight_decay", 0.01 if oname == "AdamW" else 0.0)
+    gamma = 1.0
+    if module.lr_scheduler:
+        sname, skw = module.lr_scheduler
+        if sname != "ExponentialLR":
+            raise NotImplementedError(f"lr_scheduler {sname}: only ExponentialLR (configs/SpatialNet.yaml) is implemented")
+        gamma = float(skw.get("gamma", 1.0))
+    ts = TrainStep(eng, n_fft=module.stft.n_fft, ref_channel=module.channels.index(module.ref_channel), lr=okw.get("lr", 1e-3),
+                   betas=tuple(okw.get("betas", (0.9, 0.999))), eps=okw.get("eps", 1e-8), weight_decay=wd,
+                   decoupled_weight_decay=oname == "AdamW", clip=float(tr.get("gradient_clip_val") or 0.0),
+                   window=0 if module.stft.win == "hann_window" else 1)
+    return eng, ts, gamma
+
+
+def fit(cfg: dict) -> Dict[str, Any]:
     tr = cfg.get("trainer", {})
     if tr.get("accelerator", "gpu") == "cpu" or not torch.cuda.is_available():
-        raise RuntimeError("SharedTrainer fit: the SpatialNet path runs on MI355X HIP kernels only (no CPU path)")
+        from nbss_amd.host_trainer import fit_generic
+        return fit_generic(cfg, build_module, _instantiate)  # plumbing path of the non-SpatialNet archs (BASELINE config 1)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -217,14 +301,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
         data = SyntheticDataModule()
     if cfg.get("ckpt_path"):
         load_checkpoint(cfg["ckpt_path"], module)  # weights first: the engine binds the parameters below
-    eng = module.arch._engine_for(dev)
-    eng.dtype = NBSS_BF16 if module.precision in ("bf16-mixed", "bf16") else NBSS_F32
-    oname, okw = module.optimizer
-    assert oname in ("Adam", "AdamW"), "the fused optimizer kernel implements Adam"
-    ts = TrainStep(eng, n_fft=module.stft.n_fft, ref_channel=module.channels.index(module.ref_channel), lr=okw.get("lr", 1e-3),
-                   betas=tuple(okw.get("betas", (0.9, 0.999))), eps=okw.get("eps", 1e-8), weight_decay=okw.get("weight_decay", 0.0),
-                   clip=float(tr.get("gradient_clip_val") or 0.0))
-    gamma = (module.lr_scheduler[1].get("gamma", 1.0) if module.lr_scheduler and module.lr_scheduler[0] == "ExponentialLR" else 1.0)
+    eng, ts, gamma = _fused_step_for(module, cfg, dev)
     first_epoch = 0
     if cfg.get("ckpt_path"):
         first_epoch = load_checkpoint(cfg["ckpt_path"], module, ts) + 1  # (weights again: a no-op; now also the Adam state)
@@ -243,7 +320,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
         if rank == 0:
             print(json.dumps(rec), flush=True)
             if ckpt_dir:
-                save_checkpoint(os.path.join(ckpt_dir, "checkpoints", "last.ckpt"), module, ts, epoch)
+                save_checkpoint(os.path.join(ckpt_dir, "checkpoints", "last.ckpt"), module, ts, epoch, global_step=ts.step_count)
     if world > 1:
         torch.distributed.destroy_process_group()
     return {"log": log, "module": module}
@@ -251,8 +328,6 @@ def fit(cfg: dict) -> Dict[str, Any]:
 
 def _setup(cfg: dict):
     """device, module, data module and a TrainStep for the non-training subcommands (inference path: no activations kept)"""
-    from nbss_amd._lib import NBSS_BF16, NBSS_F32
-    from nbss_amd.engine import TrainStep
     tr = cfg.get("trainer", {})
     if tr.get("accelerator", "gpu") == "cpu" or not torch.cuda.is_available():
         raise RuntimeError("SharedTrainer: the SpatialNet path runs on MI355X HIP kernels only (no CPU path)")
@@ -268,9 +343,7 @@ def _setup(cfg: dict):
     if data is None:
         from data_loaders.synthetic import SyntheticDataModule
         data = SyntheticDataModule()
-    eng = module.arch._engine_for(dev)
-    eng.dtype = NBSS_BF16 if module.precision in ("bf16-mixed", "bf16") else NBSS_F32
-    ts = TrainStep(eng, n_fft=module.stft.n_fft, ref_channel=module.channels.index(module.ref_channel))
+    _, ts, _ = _fused_step_for(module, cfg, dev)
     return dev, module, data, ts
 
 

@@ -157,10 +157,10 @@ int nbss_pit_neg_sisdr(int B, int S, int N, const float* preds, const float* tar
 /* clip_grad_norm_(max_norm, L2) + torch.optim.Adam(W) step on the flat fp32 buffers
  * (configs/SpatialNet.yaml:3-4,44; general_steps.py:243-271).  grads are first multiplied by
  * grad_scale (1/world_size after a SUM all-reduce).  scratch: >= 258 floats; scratch[0] returns the
- * (scaled) gradient norm.  step counts from 1.  zero_grad != 0 clears grads for the next step.
- * weight_decay follows torch.optim.Adam (L2 added to the gradient). */
+ * (scaled) gradient norm.  step counts from 1.  flags: bit 0 clears grads for the next step; bit 1 selects
+ * torch.optim.AdamW's decoupled weight decay (p *= 1 - lr*wd) instead of torch.optim.Adam's L2 term in the gradient. */
 int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* scratch, float max_norm,
-                        float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
+                        float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int flags,
                         void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------*/

@@ -1,0 +1,139 @@
+"""NBC — drop-in for the reference's models/arch/NBC.py (narrow-band conformer with Transformer-XL relative-position attention,
+NBC.py:73-293): same constructor, same forward [B,F,T,dim_input] -> [B,F,T,dim_output], same state_dict keys
+(`encoder`, `sa_layers.N.self_attn.{query,key,value,pos,out}_proj / u_bias / v_bias / rel_pos.pe`, `linear1/2`, `norm1/2`,
+`conv.*`, `decoder`).  The position term of the scores is computed as one [T, 2T-1] product per head followed by a gather along
+the relative offset (the reference materialises a [T, T, heads, d] tensor).  Plain PyTorch."""
+import math
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+
+class Linear(nn.Linear):
+    """nn.Linear with Xavier-uniform weights and a zero bias"""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True) -> None:
+        super().__init__(in_features, out_features, bias=bias)
+        nn.init.xavier_uniform_(self.weight)
+        if bias:
+            nn.init.zeros_(self.bias)
+
+
+class RelativePositionalEncoding(nn.Module):
+    """sinusoidal table for relative offsets -max_len..max_len; forward(x [B,T,F]) -> [1, 2T-1, F] (offsets -(T-1)..T-1)"""
+
+    def __init__(self, input_size, max_len=1000):
+        super().__init__()
+        self.max_len = self.zero_index = max_len
+        pos = torch.arange(-max_len, max_len + 1, dtype=torch.float32)[:, None]
+        freq = torch.exp(torch.arange(0, input_size, 2, dtype=torch.float32) * (-math.log(10000.0) / input_size))
+        pe = torch.zeros(2 * max_len + 1, input_size)
+        pe[:, 0::2] = torch.sin(pos * freq)
+        pe[:, 1::2] = torch.cos(pos * freq)
+        self.register_buffer("pe", pe[None])
+
+    def forward(self, x: Tensor) -> Tensor:
+        T = x.shape[1]
+        return self.pe[:, self.zero_index - (T - 1): self.zero_index + T].detach()
+
+
+class RelativePositionalMultiHeadAttention(nn.Module):
+    def __init__(self, d_model: int = 256, num_heads: int = 8, dropout: float = 0.1):
+        super().__init__()
+        assert d_model % num_heads == 0, "d_model % num_heads should be zero."
+        self.d_model, self.num_heads, self.d_head = d_model, num_heads, d_model // num_heads
+        self.sqrt_dim = math.sqrt(d_model)  # (the reference scales by sqrt(d_model), not sqrt(d_head))
+        self.query_proj, self.key_proj, self.value_proj = Linear(d_model, d_model), Linear(d_model, d_model), Linear(d_model, d_model)
+        self.pos_proj = Linear(d_model, d_model, bias=False)
+        self.rel_pos = RelativePositionalEncoding(d_model)
+        self.dropout = nn.Dropout(p=dropout)
+        self.u_bias = nn.Parameter(torch.empty(num_heads, self.d_head))
+        self.v_bias = nn.Parameter(torch.empty(num_heads, self.d_head))
+        nn.init.xavier_uniform_(self.u_bias)
+        nn.init.xavier_uniform_(self.v_bias)
+        self.out_proj = Linear(d_model, d_model)
+
+    def forward(self, query: Tensor, key: Optional[Tensor] = None, value: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None):
+        key = query if key is None else key
+        value = query if value is None else value
+        B, T, _ = value.shape
+        H, D = self.num_heads, self.d_head
+        q = self.query_proj(query).view(B, -1, H, D).transpose(1, 2)  # [B,H,T,D]
+        k = self.key_proj(key).view(B, -1, H, D).transpose(1, 2)
+        v = self.value_proj(value).view(B, -1, H, D).transpose(1, 2)
+        content = (q + self.u_bias[None, :, None, :]) @ k.transpose(-1, -2)  # [B,H,T,T]
+        # position term: score(i, j) = (q_i + v_bias) . P[i - j], P = pos_proj(pe[-(T-1)..T-1])
+        P = self.pos_proj(self.rel_pos(value)).view(2 * T - 1, H, D).permute(1, 2, 0)  # [H, D, 2T-1]
+        qp = (q + self.v_bias[None, :, None, :]) @ P  # [B,H,T,2T-1]
+        idx = torch.arange(T, device=q.device)
+        rel = (idx[:, None] - idx[None, :] + (T - 1)).expand(B, H, T, T)  # offset i - j -> column of P
+        score = (content + qp.gather(-1, rel)) / self.sqrt_dim
+        if attn_mask is not None:
+            score = score + attn_mask
+        attn = self.dropout(F.softmax(score, -1))
+        out = (attn @ v).transpose(1, 2).reshape(B, -1, self.d_model)
+        return self.out_proj(out), attn
+
+
+class NBCBlock(nn.Module):
+    def __init__(self, dim_model: int = 192, num_head: int = 8, dim_ffn: int = 384, dropout: float = 0.1, activation: Callable = F.silu,
+                 layer_norm_eps: float = 1e-5, norm_first: bool = True, n_conv_groups: int = 384, conv_kernel_size: int = 3, conv_bias: bool = True,
+                 n_conv_layers: int = 3, conv_mid_norm: str = "GN") -> None:
+        super().__init__()
+        self.self_attn = RelativePositionalMultiHeadAttention(dim_model, num_head, dropout=dropout)
+        self.linear1 = Linear(dim_model, dim_ffn)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = Linear(dim_ffn, dim_model)
+        self.norm_first = norm_first
+        self.norm1 = nn.LayerNorm(dim_model, eps=layer_norm_eps)
+        self.norm2 = nn.LayerNorm(dim_model, eps=layer_norm_eps)
+        self.dropout1, self.dropout2 = nn.Dropout(dropout), nn.Dropout(dropout)
+        self.activation = activation
+        mods = []
+        for _ in range(n_conv_layers):
+            mods.append(nn.Conv1d(dim_ffn, dim_ffn, kernel_size=conv_kernel_size, padding="same", groups=n_conv_groups, bias=conv_bias))
+            if conv_mid_norm is not None:
+                if conv_mid_norm != "GN":
+                    raise ValueError("unsupported mid norm " + str(conv_mid_norm))
+                mods.append(nn.GroupNorm(8, dim_ffn))
+            mods.append(nn.SiLU())
+        self.conv = nn.Sequential(*mods)
+
+    def _ffn(self, x: Tensor) -> Tensor:
+        h = self.conv(self.activation(self.linear1(x)).transpose(-1, -2)).transpose(-1, -2)
+        return self.dropout2(self.linear2(self.dropout(h)))
+
+    def forward(self, x: Tensor, att_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        if self.norm_first:
+            a, attn = self.self_attn(self.norm1(x), attn_mask=att_mask)
+            x = x + self.dropout1(a)
+            return x + self._ffn(self.norm2(x)), attn
+        a, attn = self.self_attn(x, attn_mask=att_mask)
+        x = self.norm1(x + self.dropout1(a))
+        return self.norm2(x + self._ffn(x)), attn
+
+
+class NBC(nn.Module):
+    def __init__(self, dim_input: int = 16, dim_output: int = 4, n_layers: int = 4, encoder_kernel_size: int = 4, n_heads: int = 8,
+                 activation: Optional[str] = "", hidden_size: int = 192, norm_first: bool = True, ffn_size: int = 384, inner_conv_kernel_size: int = 3,
+                 inner_conv_groups: int = 8, inner_conv_bias: bool = True, inner_conv_layers: int = 3, inner_conv_mid_norm: str = "GN"):
+        super().__init__()
+        assert activation == "", "not implemented"
+        # un-padded conv shortens the sequence by k-1 frames; the transposed conv of the decoder restores them
+        self.encoder = nn.Conv1d(dim_input, hidden_size, kernel_size=encoder_kernel_size, stride=1)
+        self.sa_layers = nn.ModuleList([
+            NBCBlock(dim_model=hidden_size, num_head=n_heads, norm_first=norm_first, dim_ffn=ffn_size, n_conv_groups=inner_conv_groups,
+                     conv_kernel_size=inner_conv_kernel_size, conv_bias=inner_conv_bias, n_conv_layers=inner_conv_layers,
+                     conv_mid_norm=inner_conv_mid_norm) for _ in range(n_layers)])
+        self.decoder = nn.ConvTranspose1d(hidden_size, dim_output, kernel_size=encoder_kernel_size, stride=1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        B, Fq, T, _ = x.shape
+        h = self.encoder(x.reshape(B * Fq, T, -1).transpose(1, 2)).transpose(1, 2)
+        for block in self.sa_layers:
+            h, _ = block(h)
+        y = self.decoder(h.transpose(1, 2)).transpose(1, 2)
+        return y.reshape(B, Fq, T, -1).contiguous()

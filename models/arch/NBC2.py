@@ -1,0 +1,141 @@
+"""NBC2 — drop-in for the reference's models/arch/NBC2.py: narrow-band conformer (NBC2.py:152-289), same constructor arguments,
+same forward [B,F,T,dim_input] -> [B,F,T,dim_output], same state_dict keys (`encoder`, `sa_layers.N.{norm1,self_attn,norm2,linear1,
+conv.{1,3,4,6},linear2}`, `decoder`).  Each T-F sequence goes through `n_layers` blocks of pre-norm self-attention over time and a
+convolutional feed-forward (1x1 -> 3 grouped k=3 convs along T with a norm in the middle -> 1x1).  GroupBatchNorm (:57-145)
+normalises with statistics shared by the `group_size` (= num_freqs) sequences of one utterance, in training AND evaluation.
+Plain PyTorch."""
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.nn import MultiheadAttention
+
+
+class LayerNorm(nn.LayerNorm):
+    """LayerNorm over the feature axis of [B,T,H] (transpose=False) or [B,H,T] (transpose=True)"""
+
+    def __init__(self, transpose: bool, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.transpose = transpose
+
+    def forward(self, input: Tensor) -> Tensor:
+        if not self.transpose:
+            return super().forward(input)
+        return super().forward(input.transpose(-1, -2)).transpose(-1, -2)
+
+
+class BatchNorm1d(nn.Module):
+    def __init__(self, transpose: bool, **kwargs) -> None:
+        super().__init__()
+        self.transpose = transpose
+        self.bn = nn.BatchNorm1d(**kwargs)
+
+    def forward(self, input: Tensor) -> Tensor:  # nn.BatchNorm1d wants [B,H,T]
+        return self.bn(input) if self.transpose else self.bn(input.transpose(-1, -2)).transpose(-1, -2)
+
+
+class GroupNorm(nn.GroupNorm):
+    def __init__(self, transpose: bool, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.transpose = transpose
+
+    def forward(self, input: Tensor) -> Tensor:
+        return super().forward(input) if self.transpose else super().forward(input.transpose(-1, -2)).transpose(-1, -2)
+
+
+class GroupBatchNorm(nn.Module):
+    """statistics over (group of `group_size` consecutive batch items) x (feature axis) [x (time axis) when
+    share_along_sequence_dim], always computed from the input itself; per-feature affine"""
+
+    def __init__(self, dim_hidden: int, group_size: int, share_along_sequence_dim: bool = False, transpose: bool = False, affine: bool = True,
+                 eps: float = 1e-5) -> None:
+        super().__init__()
+        self.dim_hidden, self.group_size, self.eps, self.affine = dim_hidden, group_size, eps, affine
+        self.transpose, self.share_along_sequence_dim = transpose, share_along_sequence_dim
+        if affine:
+            shape = [dim_hidden, 1] if transpose else [dim_hidden]
+            self.weight = nn.Parameter(torch.ones(shape))
+            self.bias = nn.Parameter(torch.zeros(shape))
+
+    def forward(self, input: Tensor) -> Tensor:
+        Bt = input.shape[0]
+        if Bt % self.group_size:
+            raise ValueError(f"batch size {Bt} is not divisible by group size {self.group_size}")
+        g = input.reshape(Bt // self.group_size, self.group_size, *input.shape[1:])  # [G, gs, T, H] or [G, gs, H, T]
+        feat = 2 if self.transpose else 3
+        dims = (1, 2, 3) if self.share_along_sequence_dim else (1, feat)
+        var, mean = torch.var_mean(g, dim=dims, unbiased=False, keepdim=True)
+        out = (g - mean) * torch.rsqrt(var + self.eps)
+        if self.affine:
+            out = out * self.weight + self.bias
+        return out.reshape(input.shape)
+
+    def extra_repr(self) -> str:
+        return (f"{self.dim_hidden}, {self.group_size}, share_along_sequence_dim={self.share_along_sequence_dim}, transpose={self.transpose}, "
+                f"eps={self.eps}, affine={self.affine}")
+
+
+def _make_norm(kind: str, dim: int, transpose: bool, n_groups: int, **gbn_kwargs) -> nn.Module:
+    if kind == "LN":
+        return LayerNorm(normalized_shape=dim, transpose=transpose)
+    if kind == "GBN":
+        return GroupBatchNorm(dim_hidden=dim, transpose=transpose, **gbn_kwargs)
+    if kind == "BN":
+        return BatchNorm1d(num_features=dim, transpose=transpose)
+    if kind == "GN":
+        return GroupNorm(num_groups=n_groups, num_channels=dim, transpose=transpose)
+    raise ValueError(f"unknown norm {kind}")
+
+
+class NBC2Block(nn.Module):
+    def __init__(self, dim_hidden: int, dim_ffn: int, n_heads: int, dropout: float = 0, conv_kernel_size: int = 3, n_conv_groups: int = 8,
+                 norms: Tuple[str, str, str] = ("LN", "GBN", "GBN"),
+                 group_batch_norm_kwargs: Dict[str, Any] = {"group_size": 257, "share_along_sequence_dim": False}) -> None:
+        super().__init__()
+        gk = dict(group_batch_norm_kwargs)
+        self.norm1 = _make_norm(norms[0], dim_hidden, False, n_conv_groups, **gk)
+        self.self_attn = MultiheadAttention(embed_dim=dim_hidden, num_heads=n_heads, batch_first=True)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm2 = _make_norm(norms[1], dim_hidden, False, n_conv_groups, **gk)
+        self.linear1 = nn.Linear(dim_hidden, dim_ffn)
+
+        def gconv():
+            return nn.Conv1d(dim_ffn, dim_ffn, kernel_size=conv_kernel_size, padding="same", groups=n_conv_groups, bias=True)
+
+        self.conv = nn.Sequential(nn.SiLU(), gconv(), nn.SiLU(), gconv(), _make_norm(norms[2], dim_ffn, True, n_conv_groups, **gk), nn.SiLU(), gconv(),
+                                  nn.SiLU(), nn.Dropout(dropout))
+        self.linear2 = nn.Linear(dim_ffn, dim_hidden)
+        self.dropout2 = nn.Dropout(dropout)
+        for lin in (self.linear1, self.linear2):
+            nn.init.xavier_uniform_(lin.weight)
+            nn.init.zeros_(lin.bias)
+
+    def forward(self, x: Tensor, att_mask: Optional[Tensor] = None):
+        """x [batch, seq, feature] -> (x, attention [batch, head, seq, seq])"""
+        u = self.norm1(x)
+        a, attn = self.self_attn(u, u, u, average_attn_weights=False, attn_mask=att_mask)
+        x = x + self.dropout1(a)
+        h = self.linear1(self.norm2(x)).transpose(-1, -2)  # [B, ffn, T] for the convs along time
+        x = x + self.dropout2(self.linear2(self.conv(h).transpose(-1, -2)))
+        return x, attn
+
+
+class NBC2(nn.Module):
+    def __init__(self, dim_input: int, dim_output: int, n_layers: int, encoder_kernel_size: int = 5, dim_hidden: int = 192, dim_ffn: int = 384,
+                 num_freqs: int = 257,
+                 block_kwargs: Dict[str, Any] = {"n_heads": 2, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 8, "norms": ("LN", "GBN", "GBN"),
+                                                 "group_batch_norm_kwargs": {"share_along_sequence_dim": False}}):
+        super().__init__()
+        bk = dict(block_kwargs)
+        bk["group_batch_norm_kwargs"] = dict(bk.get("group_batch_norm_kwargs", {}), group_size=num_freqs)  # one group = one utterance's bins
+        self.encoder = nn.Conv1d(dim_input, dim_hidden, kernel_size=encoder_kernel_size, stride=1, padding="same")
+        self.sa_layers = nn.ModuleList([NBC2Block(dim_hidden=dim_hidden, dim_ffn=dim_ffn, **bk) for _ in range(n_layers)])
+        self.decoder = nn.Linear(dim_hidden, dim_output)
+
+    def forward(self, x: Tensor) -> Tensor:
+        B, F, T, _ = x.shape
+        h = self.encoder(x.reshape(B * F, T, -1).transpose(1, 2)).transpose(1, 2)
+        for block in self.sa_layers:
+            h, _ = block(h)
+        return self.decoder(h).reshape(B, F, T, -1).contiguous()

@@ -71,7 +71,9 @@ class _SpatialNetFn(torch.autograd.Function):
         xin = x.detach().to(eng.stream_dtype(dtype)).contiguous()
         train = module._want_grad  # grad mode is always off inside Function.forward: the module samples it before apply()
         out = eng.forward(xin, train=train, dtype=dtype)
-        ctx.module, ctx.dtype, ctx.train = module, dtype, train
+        if train:
+            eng.forward_serial = getattr(eng, "forward_serial", 0) + 1
+        ctx.module, ctx.dtype, ctx.train, ctx.serial = module, dtype, train, getattr(eng, "forward_serial", 0)
         ctx.save_for_backward(xin)
         return out
 
@@ -82,6 +84,10 @@ class _SpatialNetFn(torch.autograd.Function):
             raise RuntimeError("SpatialNet: backward through a forward that ran without gradient tracking")
         (xin,) = ctx.saved_tensors
         eng = module._engine
+        if ctx.serial != getattr(eng, "forward_serial", 0):
+            # the engine keeps the activations of its LAST train-mode forward only
+            raise RuntimeError("SpatialNet: backward of a forward whose saved activations were overwritten by a later forward "
+                               "(run forward -> backward pairs one at a time)")
         eng.grads.zero_()
         eng.backward(xin, dout.contiguous().float(), dtype=ctx.dtype)
         g = eng.grads.clone()

@@ -33,7 +33,7 @@ int inorm_istft_bwd_impl(int nfft, int B, int S, int N, const float* tab, const 
 size_t pit_ws_floats(int B, int S);
 int pit_sisdr_impl(int B, int S, int N, const float* p, const float* t, float* loss, int* perm, float* dp, float* ws, hipStream_t st);
 int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal, float max_norm, float grad_scale, float lr, float beta1,
-                   float beta2, float eps, float wd, int step, int zero_grad, hipStream_t st);
+                   float beta2, float eps, float wd, int step, int flags, hipStream_t st);
 
 #define CHECK_CFG(cfg)                         \
     if (!(cfg)) return NBSS_EINVAL;            \
@@ -299,11 +299,11 @@ int nbss_pit_neg_sisdr(int B, int S, int N, const float* preds, const float* tar
 }
 
 int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* scratch, float max_norm,
-                        float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int zero_grad,
+                        float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int flags,
                         void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n <= 0) return NBSS_EINVAL;
     return clip_adam_impl((size_t)n, params, grads, exp_avg, exp_avg_sq, scratch, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
-                          zero_grad, (hipStream_t)stream);
+                          flags, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

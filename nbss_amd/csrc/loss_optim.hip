@@ -193,12 +193,14 @@ __global__ void clip_coef_kernel(int nparts, const float* __restrict__ part, flo
 
 __global__ void adam_kernel(size_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ scal, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                            int zero_grad) {
+                            int flags) {
     const float coef = scal[1];
+    const bool zero_grad = flags & 1, decoupled = flags & 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float gi = g[i] * coef;
-        const float pi = p[i];
-        if (wd != 0.f) gi += wd * pi;
+        float pi = p[i];
+        if (decoupled) pi -= lr * wd * pi;       // torch.optim.AdamW: p *= 1 - lr * wd before the Adam update
+        else if (wd != 0.f) gi += wd * pi;       // torch.optim.Adam: L2 term added to the gradient
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
@@ -209,7 +211,7 @@ __global__ void adam_kernel(size_t n, float* __restrict__ p, float* __restrict__
 }
 
 int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal /* >= 2 + OP_BLOCKS floats */, float max_norm, float grad_scale,
-                   float lr, float beta1, float beta2, float eps, float wd, int step, int zero_grad, hipStream_t st) {
+                   float lr, float beta1, float beta2, float eps, float wd, int step, int flags, hipStream_t st) {
     if (step < 1) return NBSS_EINVAL;
     float* part = scal + 2;
     ProfScope ps(PK_ADAM, st);
@@ -219,6 +221,6 @@ int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal
     NBSS_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, st, OP_BLOCKS, (const float*)part, max_norm, grad_scale, scal);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    NBSS_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, st, n, p, g, m, v, (const float*)scal, lr, beta1, beta2, eps, wd, bc1, bc2s, zero_grad);
+    NBSS_LAUNCH(adam_kernel, dim3(1024), dim3(256), 0, st, n, p, g, m, v, (const float*)scal, lr, beta1, beta2, eps, wd, bc1, bc2s, flags);
     return NBSS_CHECK_LAUNCH();
 }

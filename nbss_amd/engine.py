@@ -156,12 +156,14 @@ class TrainStep:
     """One full SpatialNet training step on the HIP path (the unit bench.py times)."""
 
     def __init__(self, engine: SpatialNetEngine, *, n_fft: int = 256, ref_channel: int = 0, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, clip: float = 5.0, process_group=None, bucketed: bool = True):
+                 weight_decay: float = 0.0, clip: float = 5.0, process_group=None, bucketed: bool = True, force_collectives: bool = False,
+                 decoupled_weight_decay: bool = False, window: int = 0):
         self.e = engine
         self.lib = engine.lib
         self.n_fft, self.ref = n_fft, ref_channel
         self.lr, self.betas, self.eps, self.wd, self.clip = lr, betas, eps, weight_decay, clip
-        self.tables = ops.stft_tables(self.lib, n_fft, 0, engine.device)
+        self.tables = ops.stft_tables(self.lib, n_fft, window, engine.device)  # window: 0 hann, 1 sqrt-hann (models/io/stft.py)
+        self.decoupled_wd = decoupled_weight_decay
         self.m = torch.zeros_like(engine.params)
         self.v = torch.zeros_like(engine.params)
         self.scratch = torch.zeros(512, dtype=torch.float32, device=engine.device)
@@ -171,6 +173,8 @@ class TrainStep:
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+        # collectives run when world > 1; tests force them on a 1-rank RCCL group to exercise the stream ordering on hardware
+        self.collectives = self.world > 1 or force_collectives
 
     def forward_loss(self, x: Tensor, yr: Tensor, need_grad: bool = True):
         """x [B,C,N] fp32 mixture, yr [B,S,N] fp32 targets -> (loss [1], yr_hat [B,S,N], dout or None, xin, xrmm)"""
@@ -193,7 +197,7 @@ class TrainStep:
     def backward_and_update(self, xin: Tensor, dout: Tensor) -> None:
         """network backward + gradient exchange + clip/Adam/re-pack"""
         e = self.e
-        if self.world > 1 and self.bucketed:
+        if self.collectives and self.bucketed:
             # data parallel, overlapped: one asynchronous all-reduce (SUM) per layer bucket, issued as soon as that layer's
             # backward has been enqueued; RCCL runs them on its own stream behind the kernels already queued here
             handles = []
@@ -209,11 +213,11 @@ class TrainStep:
     def apply_gradients(self, reduced: bool = False) -> None:
         """[all-reduce] + clip + Adam + re-pack on whatever is in engine.grads (reduced=True: the buckets were summed already)"""
         e = self.e
-        if self.world > 1 and not reduced:
+        if self.collectives and not reduced:
             # data parallel: ONE all-reduce (SUM) of the flat fp32 gradient over RCCL; the mean is folded into the clip kernel
             torch.distributed.all_reduce(e.grads, group=self.pg)
         self.step_count += 1
         ops.clip_adam_step(self.lib, e.params, e.grads, self.m, self.v, self.scratch, self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
-                           weight_decay=self.wd, max_norm=self.clip, grad_scale=1.0 / self.world, zero_grad=True)
+                           weight_decay=self.wd, max_norm=self.clip, grad_scale=1.0 / self.world, zero_grad=True, decoupled_weight_decay=self.decoupled_wd)
         e.version += 1
         e.packed_for(e.dtype)  # re-pack inside the step: the next forward needs fresh fragments

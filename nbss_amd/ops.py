@@ -228,8 +228,8 @@ def inorm_istft_bwd(lib, n_fft, tables, dy, xrmm):
     return dout
 
 
-def pit_neg_sisdr(lib, preds, target, need_grad=True):
-    """-> (loss [1], perm [B,S] int32, dpreds or None)"""
+def pit_neg_sisdr(lib, preds, target, need_grad=True, return_items=False):
+    """-> (loss [1], perm [B,S] int32, dpreds or None[, per-item losses [B]])"""
     B, S, N = preds.shape
     dev = preds.device
     loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -238,14 +238,16 @@ def pit_neg_sisdr(lib, preds, target, need_grad=True):
     ws = torch.empty(lib.nbss_pit_ws_bytes(B, S) // 4, dtype=torch.float32, device=dev)
     lib.call("nbss_pit_neg_sisdr", B, S, N, _ptr(lib, preds, torch.float32), _ptr(lib, target, torch.float32), _ptr(lib, loss), _ptr(lib, perm),
              _ptr(lib, dp), _ptr(lib, ws), _stream(lib, preds))
+    if return_items:  # workspace tail (include/nbss_hip.h): ... | per-item loss [B] | pairing coefficients [3 B S]
+        return loss, perm, dp, ws[ws.numel() - B - 3 * B * S: ws.numel() - 3 * B * S].clone()
     return loss, perm, dp
 
 
 def clip_adam_step(lib, params, grads, exp_avg, exp_avg_sq, scratch, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                   max_norm=5.0, grad_scale=1.0, zero_grad=True):
+                   max_norm=5.0, grad_scale=1.0, zero_grad=True, decoupled_weight_decay=False):
     lib.call("nbss_clip_adam_step", params.numel(), _ptr(lib, params, torch.float32), _ptr(lib, grads, torch.float32), _ptr(lib, exp_avg, torch.float32),
              _ptr(lib, exp_avg_sq, torch.float32), _ptr(lib, scratch, torch.float32), float(max_norm), float(grad_scale), float(lr), float(betas[0]),
-             float(betas[1]), float(eps), float(weight_decay), int(step), int(bool(zero_grad)), _stream(lib, params))
+             float(betas[1]), float(eps), float(weight_decay), int(step), int(bool(zero_grad)) | (2 if decoupled_weight_decay else 0), _stream(lib, params))
 
 
 def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:

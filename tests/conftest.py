@@ -26,6 +26,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running emulator case")
 
 
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (run with -m gpu on the GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     from nbss_amd.build import build_emu

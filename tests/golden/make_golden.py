@@ -58,7 +58,50 @@ def main():
     back = stft.istft(X, n)
     np.savez_compressed(HERE / "stft_norm_n1500.npz", sig=sig.numpy(), X_re=X.real.numpy(), X_im=X.imag.numpy(), Xl=Xl.numpy(),
                         XrMM=XrMM.numpy(), back=back.numpy())
+    nb_models()
     print("written:", [p.name for p in HERE.glob("*.npz")])
+
+
+def nb_models():
+    """tiny seeded instances of the reference's narrow-band models (blstm2_fc1.py, NBC2.py, NBC.py) and of the NBSS time-domain
+    wrapper: input, every state_dict tensor, output and the gradient of sum(y * r) w.r.t. every parameter.  NBSS.py imports
+    si_sdr / pit from torchmetrics (absent here) at module level only for its loss helper: a stub module lets it import; the
+    forward pass stored below does not touch it."""
+    import types
+    tm = types.ModuleType("torchmetrics"); tmf = types.ModuleType("torchmetrics.functional"); tma = types.ModuleType("torchmetrics.functional.audio")
+    tma.permutation_invariant_training = tma.scale_invariant_signal_distortion_ratio = lambda *a, **k: None
+    sys.modules.update({"torchmetrics": tm, "torchmetrics.functional": tmf, "torchmetrics.functional.audio": tma})
+    from models.arch.blstm2_fc1 import BLSTM2_FC1  # noqa: E402  (reference)
+    from models.arch.NBC import NBC  # noqa: E402
+    from models.arch.NBC2 import NBC2  # noqa: E402
+    from models.arch.NBSS import NBSS  # noqa: E402
+    assert "/root/reference" in sys.modules["models.arch.NBSS"].__file__
+    torch.manual_seed(1)
+    bk = {"n_heads": 2, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 4, "norms": ("LN", "GBN", "GBN"),
+          "group_batch_norm_kwargs": {"share_along_sequence_dim": False}}
+    cases = {
+        "blstm": (BLSTM2_FC1(dim_input=4, dim_output=4, hidden_size=(8, 6)), torch.randn(2, 5, 11, 4)),
+        "nbc2": (NBC2(dim_input=4, dim_output=4, n_layers=2, dim_hidden=16, dim_ffn=32, num_freqs=5, block_kwargs=bk), torch.randn(2, 5, 11, 4)),
+        "nbc": (NBC(dim_input=4, dim_output=4, n_layers=2, encoder_kernel_size=4, n_heads=4, hidden_size=16, ffn_size=32), torch.randn(2, 5, 11, 4)),
+        "nbss": (NBSS(n_channel=2, n_speaker=2, n_fft=64, n_overlap=32, ref_channel=1, arch="NB_BLSTM", arch_kwargs={"hidden_size": (8, 6)}),
+                 torch.randn(2, 2, 700)),
+    }
+    out = {}
+    for name, (net, x) in cases.items():
+        net.eval()  # NBC's blocks carry dropout 0.1 by default (NBC.py:170): eval mode makes the fixture deterministic
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+        y = net(x)
+        r = torch.randn_like(y)
+        (y * r).sum().backward()
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/r"] = x.numpy(), y.detach().numpy(), r.numpy()
+        for k, v in net.state_dict().items():
+            out[f"{name}/param/{k}"] = v.numpy()
+        for k, p in net.named_parameters():
+            out[f"{name}/grad/{k}"] = p.grad.numpy()
+    np.savez_compressed(HERE / "nb_models_tiny.npz", **out)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,95 @@
+"""End-to-end parity at the configuration bench.py times (BASELINE config 2): SpatialNet-small, 8 layers, 6 channels -> 2 speakers,
+4-s 8-kHz utterances (F = 129, T = 251), batch 2.  One fp64 oracle run (forward + autograd) is the reference for
+  (i)   the fp32 stream forward: relative error of the STFT MAGNITUDES of the separated signals <= 1e-3 (BASELINE north_star),
+  (ii)  the fp32 stream backward (the YAML default `precision: 32`, incl. the attention backward at T = 251),
+  (iii) the bf16 stream (the benchmarked precision): loss, separated signals and EVERY parameter gradient, tolerances of DESIGN.md §5.
+GPU only: the oracle alone takes a minute of host time."""
+import pytest
+import torch
+
+from nbss_amd._lib import NBSS_BF16, NBSS_F32
+from nbss_amd.engine import SpatialNetEngine, TrainStep
+from oracle import io_ref
+from oracle import spatialnet_ref as ref
+from util import rel_l2
+
+B, C, S, N, L = 2, 6, 2, 32000, 8
+
+
+def _inputs(seed=3):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, S, N, generator=g)
+    k = torch.hann_window(33)[None, None]
+    src = torch.nn.functional.conv1d(src.reshape(B * S, 1, N), k / k.sum(), padding=16).reshape(B, S, N) * 3.0
+    gains = 0.5 + torch.rand(B, C, S, generator=g)
+    mix = torch.einsum("bcs,bsn->bcn", gains, src) + 0.01 * torch.randn(B, C, N, generator=g)
+    return mix, (src * gains[:, 0, :, None]).contiguous()
+
+
+@pytest.fixture(scope="module")
+def oracle_run():
+    p = ref.init_params(num_layers=L, num_freqs=129, dim_input=2 * C, dim_output=2 * S, seed=0)
+    mix, yr = _inputs()
+    p64, seen = {}, {}
+    for k, v in p.items():
+        if id(v) not in seen:
+            seen[id(v)] = v.double().clone().requires_grad_(True)
+        p64[k] = seen[id(v)]
+    loss, yr_hat, _ = io_ref.train_forward(mix.double(), yr.double(), p64, L)
+    loss.backward()
+    return p, mix, yr, loss.detach(), yr_hat.detach(), {k: v.grad for k, v in p64.items()}
+
+
+def _stft_mag(y):
+    return io_ref.stft(y.double().cpu()).abs()
+
+
+def _run(hip_lib, dtype, p, mix, yr):
+    dev = torch.device("cuda:0")
+    eng = SpatialNetEngine(hip_lib, dev, dim_input=2 * C, dim_output=2 * S, num_freqs=129, num_layers=L, dtype=dtype)
+    eng.load_params(p)
+    ts = TrainStep(eng)
+    loss, yr_hat, dout, xin, _ = ts.forward_loss(mix.to(dev), yr.to(dev))
+    eng.backward(xin, dout)
+    torch.cuda.synchronize()
+    return float(loss), yr_hat.cpu(), {k: v.cpu() for k, v in eng.param_views(eng.grads).items()}
+
+
+def _grad_errors(got, want):
+    return {k: rel_l2(got[k], g) for k, g in want.items() if float(g.abs().max()) > 0}
+
+
+@pytest.mark.gpu
+def test_fp32_stream_headline(hip_lib, oracle_run):
+    p, mix, yr, wl, wy, wg = oracle_run
+    loss, yr_hat, grads = _run(hip_lib, NBSS_F32, p, mix, yr)
+    mag, wmag = _stft_mag(yr_hat), _stft_mag(wy)
+    err = float((mag - wmag).norm() / wmag.norm())
+    worst = float((mag - wmag).abs().max() / wmag.abs().max())
+    print(f"fp32 stream: |STFT| rel-L2 {err:.2e}, max-abs/peak {worst:.2e}, loss {loss:.5f} vs {float(wl):.5f}")
+    assert err <= 1e-3 and worst <= 1e-3  # BASELINE north_star: 1e-3 relative on STFT magnitudes in fp32
+    assert abs(loss - float(wl)) <= 1e-3 * max(1.0, abs(float(wl)))
+    assert rel_l2(yr_hat, wy) <= 1e-3
+    errs = _grad_errors(grads, wg)
+    bad = {k: e for k, e in errs.items() if e > 5e-3}
+    print("fp32 stream: worst parameter-gradient rel-L2", max(errs.values()))
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_bf16_stream_headline(hip_lib, oracle_run):
+    p, mix, yr, wl, wy, wg = oracle_run
+    loss, yr_hat, grads = _run(hip_lib, NBSS_BF16, p, mix, yr)
+    mag, wmag = _stft_mag(yr_hat), _stft_mag(wy)
+    err = float((mag - wmag).norm() / wmag.norm())
+    errs = _grad_errors(grads, wg)
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f"bf16 stream: |STFT| rel-L2 {err:.2e}, yr_hat rel-L2 {rel_l2(yr_hat, wy):.2e}, loss {loss:.4f} vs {float(wl):.4f}; worst grads {top}")
+    # stated bf16 tolerances: 40 residual blocks of bf16 stream / bf16 MFMA operands against the fp64 oracle
+    assert err <= 3e-2
+    assert rel_l2(yr_hat, wy) <= 5e-2
+    assert abs(loss - float(wl)) <= 5e-2 * max(1.0, abs(float(wl)))
+    bad = {k: e for k, e in errs.items() if e > 0.15}
+    assert not bad, bad
+    import statistics
+    assert statistics.median(errs.values()) <= 5e-2

@@ -115,3 +115,24 @@ def test_clip_adam(backend):
         assert abs(float(scratch[0]) - float(norm)) < 1e-4 * float(norm)
         assert float(gdev.abs().max()) == 0.0  # gradient buffer re-zeroed
         assert rel_l2(p, ref_p.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("decoupled", [False, True])
+def test_clip_adam_weight_decay(backend, decoupled):
+    """weight decay: torch.optim.Adam adds wd * p to the gradient, torch.optim.AdamW shrinks p by lr * wd (configs of the online
+    models use AdamW): the kernel's flag bit 1 selects the decoupled form"""
+    n = 4099
+    g = torch.Generator().manual_seed(7)
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref_p], lr=1e-2, weight_decay=0.05)
+    p = p0.clone().to(backend.device)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    scratch = torch.zeros(300, device=backend.device)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 0.01
+        ref_p.grad = grad.clone()
+        opt.step()
+        ops.clip_adam_step(backend.lib, p, grad.clone().to(backend.device), m, v, scratch, step, lr=1e-2, weight_decay=0.05, max_norm=0.0,
+                           decoupled_weight_decay=decoupled)
+        assert rel_l2(p, ref_p.detach()) < 1e-6

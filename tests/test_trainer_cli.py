@@ -57,31 +57,76 @@ def test_validate_test_predict_on_gpu(tmp_path):
     assert (tmp_path / "predict_00000.pt").exists()
 
 
-def test_checkpoint_roundtrip_reference_format(tmp_path):
-    """save_checkpoint writes the reference's layout (`state_dict` with `arch.` keys, general_steps.py:189-199) plus the flat Adam
-    state; load_checkpoint restores both (and tolerates the `_orig_mod.` prefix of compiled modules)"""
+def test_checkpoint_roundtrip_reference_format(tmp_path, emu_lib):
+    """save_checkpoint writes what the reference's Lightning trainer reads: `state_dict` with `arch.` keys + `stft.window`
+    (general_steps.py:189-199), `optimizer_states[0]` as a torch.optim.Adam state_dict sliced out of the fused optimizer's flat
+    moments, `lr_schedulers`, version keys.  load_checkpoint restores weights AND Adam state from such a file (also from one written
+    by torch itself), and tolerates the `_orig_mod.` prefix of compiled modules."""
+    import ctypes as C
     from types import SimpleNamespace
 
     from SharedTrainer import load_checkpoint, save_checkpoint
+    from nbss_amd._lib import make_cfg
+    from nbss_amd.params import param_table
     _, c = parse_cli(["fit", "--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml")] + ARGS
                      + ["--model.arch.num_layers=2"])
     torch.manual_seed(1)
     m1 = build_module(c)
     n = sum(p.numel() for p in m1.arch.parameters())
-    ts1 = SimpleNamespace(m=torch.randn(n), v=torch.rand(n), step_count=7, lr=5e-4)
+    table = param_table(emu_lib, make_cfg(1, 129, 16, 12, 4, L=2))
+    eng = SimpleNamespace(table=table)
+
+    def fake_ts(m, v, step, lr):
+        return SimpleNamespace(e=eng, m=m, v=v, step_count=step, lr=lr, betas=(0.9, 0.999), eps=1e-8, wd=0.0)
+
+    ts1 = fake_ts(torch.randn(n), torch.rand(n), 7, 5e-4)
     path = str(tmp_path / "checkpoints" / "last.ckpt")
-    save_checkpoint(path, m1, ts1, epoch=3)
-    ck = torch.load(path)
-    assert set(ck) >= {"state_dict", "epoch", "optimizer_states"} and all(k.startswith("arch.") for k in ck["state_dict"])
+    save_checkpoint(path, m1, ts1, epoch=3, global_step=7)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) >= {"state_dict", "epoch", "global_step", "optimizer_states", "lr_schedulers", "pytorch-lightning_version"}
+    assert "stft.window" in ck["state_dict"] and all(k.startswith("arch.") or k == "stft.window" for k in ck["state_dict"])
+    # the optimizer state is a genuine torch.optim.Adam state_dict for `module.parameters()`
+    opt = torch.optim.Adam(m1.parameters(), lr=1e-3)
+    opt.load_state_dict(ck["optimizer_states"][0])
+    assert opt.param_groups[0]["lr"] == 5e-4
+    first = next(iter(m1.parameters()))
+    off = table["encoder.weight"][0]
+    assert torch.equal(opt.state[first]["exp_avg"].reshape(-1), ts1.m[off:off + first.numel()]) and float(opt.state[first]["step"]) == 7
+    # ... and a checkpoint whose optimizer state was written by torch (what Lightning stores) loads into the flat buffers
+    ck["optimizer_states"] = [opt.state_dict()]
     ck["state_dict"] = {k.replace("arch.", "arch._orig_mod.", 1): v for k, v in ck["state_dict"].items()}
     torch.save(ck, path)
     torch.manual_seed(2)
     m2 = build_module(c)
-    ts2 = SimpleNamespace(m=torch.zeros(n), v=torch.zeros(n), step_count=0, lr=1e-3)
+    ts2 = fake_ts(torch.zeros(n), torch.zeros(n), 0, 1e-3)
     assert load_checkpoint(path, m2, ts2) == 3
     for (k1, v1), (k2, v2) in zip(m1.arch.state_dict().items(), m2.arch.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     assert torch.equal(ts2.m, ts1.m) and torch.equal(ts2.v, ts1.v) and ts2.step_count == 7 and ts2.lr == 5e-4
+    # weights-only checkpoint: loads, says that the optimizer starts fresh
+    torch.save({"state_dict": ck["state_dict"], "epoch": 1}, path)
+    ts3 = fake_ts(torch.zeros(n), torch.zeros(n), 0, 1e-3)
+    assert load_checkpoint(path, m2, ts3) == 1 and ts3.step_count == 0
+
+
+def test_unsupported_training_configs_fail_loudly():
+    """the fused step hard-wires Norm('frequency', online) + uPIT: any other YAML must raise instead of training another model"""
+    from SharedTrainer import _fused_step_for
+    base = ["fit", "--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml")] + ARGS
+    for extra, msg in (["--model.norm.mode=utterance"], "Norm"), (["--model.loss.pit=false"], "pit"):
+        _, c = parse_cli(base + extra)
+        with pytest.raises(NotImplementedError, match=msg):
+            _fused_step_for(build_module(c), c, torch.device("cpu"))
+    for extra, msg in (["--model.optimizer=[SGD,{lr: 0.1}]"], "optimizer"), (["--model.lr_scheduler=[StepLR,{step_size: 1}]"], "lr_scheduler"):
+        _, c = parse_cli(base + extra)
+        m = build_module(c)
+        m.arch._engine_for = lambda dev: SimpleNamespaceEngine()  # reach the optimizer / scheduler checks without a device
+        with pytest.raises(NotImplementedError, match=msg):
+            _fused_step_for(m, c, torch.device("cpu"))
+
+
+class SimpleNamespaceEngine:
+    dtype = 0
 
 
 def test_subcommands_fail_loudly_without_a_gpu():
