@@ -905,6 +905,140 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 }
 PHASE_READER(nbss_phase_read_tconvffn_bwd)
 
+// ---------------------------------------------------------------------------------------------
+// Tail of the backward pass as its own kernel (bf16 stream, after tconvffn_s.hip's data-gradient kernel): du = W1^T da1 over all
+// FFN channels from the group-major [G][N][24] operand, LayerNorm backward + residual in registers, row statistics for the weight-
+// gradient kernel, and the LayerNorm affine partial sums of the workgroup (entries [2 FFN, 2 FFN + 2 H) of its `part` row; the
+// GroupNorm entries are written by the data-gradient kernel).  One workgroup = one (b,f) sequence, 16 waves x one 16-frame strip
+// (4 waves per SIMD, <= 128 VGPRs: the first version ran 8 waves x 2 strips at 256 VGPRs with 181 spilled registers).
+template <class T>
+__global__ __launch_bounds__(1024) void tconvffn_du_kernel(nbss_cfg c, LayerPtrs lp, float* __restrict__ part, const T* __restrict__ W1tn,
+                                                           const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                           float* __restrict__ stats, const T* __restrict__ da1) {
+    NBSS_LDS(smem);
+    T* wl = reinterpret_cast<T*>(smem);  // the 36 W1^T fragments, once per workgroup
+    float* aff = reinterpret_cast<float*>(wl + 36 * 512);  // [2H] LN weight | bias gradient sums of this workgroup
+    const int T_ = c.T;
+    const int bf = blockIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)bf * T_, ntok = (size_t)c.B * c.F * T_;
+    const T* xb = x + n0 * TF_H;
+    const T* dyb = dy + n0 * TF_H;
+    T* dxb = dx + n0 * TF_H;
+    const float* lnw = lp.p[P_TF_LN_W];
+    {
+        constexpr int NV = 36 * 512 * (int)sizeof(T) / 16;
+        for (int v = tid; v < NV; v += 1024) reinterpret_cast<u32x4*>(wl)[v] = reinterpret_cast<const u32x4*>(W1tn)[v];
+    }
+    for (int i = tid; i < 2 * TF_H; i += blockDim.x) aff[i] = 0.f;
+    // this wave's first strip: every global read issued before the barrier
+    for (int s16 = w; s16 * 16 < T_ || s16 == w; s16 += 16) {
+        const int tt = s16 * 16 + l15;
+        const bool tv = tt < T_;
+        const int tc = tv ? tt : T_ - 1;
+        Frag<T> df[TF_FFN / 32];
+        u32x2 xr[TF_H / 16], dr[TF_H / 16];
+#pragma unroll
+        for (int k6 = 0; k6 < TF_FFN / 32; ++k6) {  // 8-channel pieces never straddle a 24-channel group
+            const int ch = k6 * 32 + 8 * g4;
+            frag_load(df[k6], da1 + ((size_t)(ch / TF_CG) * ntok + n0 + tc) * TF_CG + ch % TF_CG);
+        }
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) {
+            xr[mt] = *reinterpret_cast<const u32x2*>(xb + (size_t)tc * TF_H + 16 * mt + 4 * g4);
+            dr[mt] = *reinterpret_cast<const u32x2*>(dyb + (size_t)tc * TF_H + 16 * mt + 4 * g4);
+        }
+        if (s16 == w) lds_barrier();  // the fragments are in LDS, aff is zeroed (every wave passes here exactly once)
+        f32x4 du[TF_H / 16];
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) du[mt] = F32X4_ZERO;
+#pragma unroll
+        for (int k6 = 0; k6 < TF_FFN / 32; ++k6)
+#pragma unroll
+            for (int mt = 0; mt < TF_H / 16; ++mt) {
+                Frag<T> a;
+                frag_load(a, wl + ((size_t)(mt * (TF_FFN / 32) + k6) * 64 + lane) * 8);
+                du[mt] = mma(a, df[k6], du[mt]);
+            }
+        float xv[TF_H / 16][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt) {
+            xv[mt][0] = bf2f((bf16_t)(xr[mt][0] & 0xFFFF)); xv[mt][1] = bf2f((bf16_t)(xr[mt][0] >> 16));
+            xv[mt][2] = bf2f((bf16_t)(xr[mt][1] & 0xFFFF)); xv[mt][3] = bf2f((bf16_t)(xr[mt][1] >> 16));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += xv[mt][r];
+        }
+        const float mean = wave_sum16(sum) * (1.0f / TF_H);
+        float q = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xv[mt][r] -= mean;
+                q += xv[mt][r] * xv[mt][r];
+            }
+        const float rstd = rsqrtf(wave_sum16(q) * (1.0f / TF_H) + 1e-5f);
+        if (tv && g4 == 0) {
+            stats[(n0 + tt) * 2] = mean;
+            stats[(n0 + tt) * 2 + 1] = rstd;
+        }
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xv[mt][r] *= rstd;  // \hat x
+                du[mt][r] = keep_if(tv, du[mt][r]);
+                const float gq = du[mt][r] * lnw[16 * mt + 4 * g4 + r];
+                m1 += gq;
+                m2 += gq * xv[mt][r];
+            }
+        m1 = wave_sum16(m1) * (1.0f / TF_H);
+        m2 = wave_sum16(m2) * (1.0f / TF_H);
+        if (tv) {
+#pragma unroll
+            for (int mt = 0; mt < TF_H / 16; ++mt) {
+                const float dd[4] = {bf2f((bf16_t)(dr[mt][0] & 0xFFFF)), bf2f((bf16_t)(dr[mt][0] >> 16)), bf2f((bf16_t)(dr[mt][1] & 0xFFFF)),
+                                     bf2f((bf16_t)(dr[mt][1] >> 16))};
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = dd[r] + rstd * (du[mt][r] * lnw[16 * mt + 4 * g4 + r] - m1 - xv[mt][r] * m2);
+                store4(dxb + (size_t)tt * TF_H + 16 * mt + 4 * g4, o[0], o[1], o[2], o[3]);
+            }
+        }
+        // LayerNorm affine gradients of the strip: reduced over its 16 frames, added to the workgroup sums
+#pragma unroll
+        for (int mt = 0; mt < TF_H / 16; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = sum_l15(du[mt][r] * xv[mt][r]), b = sum_l15(du[mt][r]);
+                if (l15 == 0) {
+                    atomicAdd(aff + 16 * mt + 4 * g4 + r, a);
+                    atomicAdd(aff + TF_H + 16 * mt + 4 * g4 + r, b);
+                }
+            }
+    }
+    lds_barrier();
+    for (int i = tid; i < 2 * TF_H; i += blockDim.x) part[(size_t)blockIdx.x * TF_AFF + 2 * TF_FFN + i] = aff[i];
+}
+
+int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* x, const void* dy,
+                          void* const* opsv, hipStream_t st);
+
+// bf16 stream: data-gradient kernel of tconvffn_s.hip + the tail kernel above (same operand tensors, same `part` rows as the group-serial kernel)
+static int tconvffn_bwd_bf16(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                             float* stats, void* const* opsv, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, st);
+    if (e) return e;
+    const bf16_t* pk = (const bf16_t*)packed;
+    ProfScope ps(PK_TCF_B, st);
+    NBSS_LAUNCH((tconvffn_du_kernel<bf16_t>), dim3(c.B * c.F), dim3(1024), 36 * 512 * sizeof(bf16_t) + 2 * TF_H * sizeof(float), st, c, lp, part, pk + pack_off(c, layer, K_TF_W1_TN),
+                (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, stats, (const bf16_t*)opsv[4]);
+    return NBSS_CHECK_LAUNCH();
+}
+
 template <class T>
 static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                           float* stats, void* const* opsv, hipStream_t st) {
@@ -937,7 +1071,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     void* ops[8];
     for (int i = 0; i < 8; ++i) ops[i] = base + (size_t)i * ws_align(N * TF_FFN * esz);
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_t<bf16_t>(c, P, part, packed, layer, x, dy, dx, stats, ops, st)
+    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_bf16(c, P, part, packed, layer, x, dy, dx, stats, ops, st)
                                  : tconvffn_bwd_t<float>(c, P, part, packed, layer, x, dy, dx, stats, ops, st);
     if (e) return e;
     AffSegs sg;

@@ -439,3 +439,577 @@ int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, i
     NBSS_LAUNCH(tconvffn_fwd_s_kernel, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, gn_save);
     return NBSS_CHECK_LAUNCH();
 }
+
+// =====================================================================================================================================
+// Backward (data gradient) for the bf16 stream.  Same phases as the forward kernel, but the backward chain needs more than the spatial
+// image at a time (dSiLU(a2) and the GroupNorm-normalised a3), so the work of one sequence is split over TWO workgroups of 4 conv
+// groups each; a workgroup holds three half-width [T][96] bf16 images: S (the spatial chain, updated in place), A = dSiLU(a2), B = a3hat.
+//   * 8 waves = 4 groups x 2 halves of the sequence.  The lower half shifts its image rows DOWN by one per forward conv and walks the
+//     strips upwards, the upper half shifts UP and walks downwards (mirrored in the backward convs): the two rows either wave reads
+//     across the middle are never overwritten inside a stage, so the pair needs no intra-stage synchronisation, only the barrier
+//     between stages.
+//   * SiLU and its derivative are evaluated together where the pre-activation exists (one sigmoid): a2 -> (h2, dSiLU) with the derivative
+//     parked in image A; a5 -> (h5, dSiLU) consumed on the spot; a1 in the strip phase, its derivative parked in the da1 operand buffer
+//     (global, L2-hot) until the last stage turns it into da1; likewise dh5 = W2^T dy waits in the da5 operand buffer.
+//   * GroupNorm statistics: the two waves of a group exchange partial sums through LDS at the stage barriers (forward statistics are
+//     recomputed, nothing needs to be saved by the forward pass).
+// Emits the same eight group-major [G][N][24] operand tensors as the group-serial kernel (h1 h2 h4 h5 | da1 da2 da3 da5) for wgrad.hip;
+// du = W1^T da1, the LayerNorm backward and dx are tconvffn.hip's tail kernel.
+#define TB_RS 104   // half-width image row stride in elements (208 B)
+#define TB_PAD 9    // spatial image: 4 rows below frame 0 + 5 rows above the last frame
+#define TB_SB 2     // strips per block
+
+struct TsBwdW {
+    const bf16_t *W1, *W2T, *C1, *C2, *C3, *C1T, *C2T, *C3T;
+};
+struct TsOps {
+    bf16_t *h1, *h2, *h4, *h5, *da1, *da2, *da3, *da5;
+};
+
+NBSS_DEV void silu_dsilu(float a, float& h, float& d) {  // one sigmoid for SiLU and its derivative s (1 + a (1 - s)) = s + h (1 - s)
+    const float s = 1.0f / (1.0f + __expf(-a));
+    h = a * s;
+    d = s + h * (1.0f - s);
+}
+NBSS_DEV float dsilu_only(float a) {
+    const float s = 1.0f / (1.0f + __expf(-a));
+    return s * (1.0f + a * (1.0f - s));
+}
+NBSS_DEV void p6_unpack(const P6& p, float (&v)[12]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v[2 * i] = bf_lo(p.d[i]);
+        v[2 * i + 1] = bf_hi(p.d[i]);
+    }
+}
+NBSS_DEV void p6_pack(const float (&v)[12], uint32_t vm, P6& p) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.d[i] = pack2bf(v[2 * i], v[2 * i + 1]) & vm;
+}
+NBSS_DEV void p6_gstore(bf16_t* __restrict__ g, const P6& p, bool ok, bool nt) {  // g = &op[group][token][4 h]
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x2 v = {p.d[2 * q], p.d[2 * q + 1]};
+#ifndef NBSS_EMU
+        if (nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(g + 8 * q));
+        else
+#endif
+            *reinterpret_cast<u32x2*>(g + 8 * q) = v;
+    }
+}
+NBSS_DEV void p6_gload(const bf16_t* __restrict__ g, P6& p) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(g + 8 * q);
+        p.d[2 * q] = v[0];
+        p.d[2 * q + 1] = v[1];
+    }
+}
+// sum over the 32 lanes of each wave half (lanes sharing lane >> 5)
+NBSS_DEV float half_sum32(float v) {
+    v = row_sum16(v);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+// B fragments of a k=3 grouped conv from three row pointers (frames t-1, t, t+1 at the group's column)
+NBSS_DEV void conv_bfrags3(const TsLane& L, const bf16_t* r0, const bf16_t* r1, const bf16_t* r2, FragH (&b)[5]) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int b0 = 2 * ks, b1 = ks < 4 ? 2 * ks + 1 : 8;
+        const bf16_t* p0 = (b0 / 3 == 0 ? r0 : b0 / 3 == 1 ? r1 : r2) + (b0 % 3) * 8;
+        const bf16_t* p1 = (b1 / 3 == 0 ? r0 : b1 / 3 == 1 ? r1 : r2) + (b1 % 3) * 8;
+        frag_load(b[ks], L.h ? p1 : p0);
+    }
+    const FragH one = frag_const_one();
+    if (L.h) b[4].v = one.v;  // bias slot of the forward convs; the transposed convs carry zeros there
+}
+
+__global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPtrs lp, TsBwdW W, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             float* __restrict__ part, TsOps ops) {
+    NBSS_LDS(smem);
+    const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
+    bf16_t* S = reinterpret_cast<bf16_t*>(smem);             // [NT + TB_PAD][TB_RS]
+    bf16_t* A = S + (size_t)(NT + TB_PAD) * TB_RS;          // [NT][TB_RS]  dSiLU(a2)   (first: the weight window of the strip phase)
+    // (short sequences: the 52-fragment weight window of the strip phase is larger than the image it aliases)
+    const size_t a_el = (size_t)NT * TB_RS > (size_t)52 * 512 ? (size_t)NT * TB_RS : (size_t)52 * 512;
+    bf16_t* Bi = A + a_el;                                  // [NT][TB_RS]  a3hat   (first: dh5 = W2^T dy of the strip phase)
+    float* red = reinterpret_cast<float*>(Bi + (size_t)NT * TB_RS);  // [4 groups][2 halves][2]
+    float* gnp = red + 16;                                   // [2 halves][2 kinds][96] GroupNorm affine partial sums
+    bf16_t* wl = A;
+    PHASE_BEGIN(gnp + 4 * 96);
+    const TsLane L;
+    const int w = wave_id_u(), tid = threadIdx.x;
+    const int row = blockIdx.x >> 1, gh = blockIdx.x & 1;
+    const size_t n0 = (size_t)row * T_, ntok = (size_t)c.B * c.F * T_;
+    const bf16_t* xb = x + n0 * TS_H;
+    const bf16_t* dyb = dy + n0 * TS_H;
+
+    // ---- strip phase: h1 (-> S, operand), dSiLU(a1) (-> da1 buffer), dh5 = W2^T dy (-> da5 buffer) for the 4 groups of this workgroup
+    {
+        constexpr int NV = 52 * 64;  // 28 W1 + 24 W2^T fragments
+        u32x4 wr[(NV + 511) / 512];
+#pragma unroll
+        for (int i = 0; i < (NV + 511) / 512; ++i) {
+            const int v = tid + i * 512;
+            const u32x4* src = v < 28 * 64 ? reinterpret_cast<const u32x4*>(W.W1 + (size_t)gh * 28 * 512) + v
+                                           : reinterpret_cast<const u32x4*>(W.W2T + (size_t)gh * 24 * 512) + (v < NV ? v - 28 * 64 : 0);
+            wr[i] = *src;
+        }
+#pragma unroll
+        for (int i = 0; i < (NV + 511) / 512; ++i) {
+            const int v = tid + i * 512;
+            if (v < NV) reinterpret_cast<u32x4*>(wl)[v] = wr[i];
+        }
+    }
+    for (int i = tid; i < 4 * TB_RS / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(S)[i] = 0u;
+    for (int i = tid; i < 5 * TB_RS / 2; i += blockDim.x) reinterpret_cast<uint32_t*>(S + (size_t)(NT + 4) * TB_RS)[i] = 0u;
+    P6 d1keep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d1keep[k].d[i] = 0u;
+    u32x4 rawx[6], rawd[6];
+    {
+        const int t = 32 * w + L.n, tc = t < T_ ? t : T_ - 1;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            rawx[ks] = *reinterpret_cast<const u32x4*>(xb + (size_t)tc * TS_H + 16 * ks + 8 * L.h);
+            rawd[ks] = *reinterpret_cast<const u32x4*>(dyb + (size_t)tc * TS_H + 16 * ks + 8 * L.h);
+        }
+    }
+    PHASE(0);
+    lds_barrier();
+    PHASE(1);
+    if (w < NS) {
+        const int t = 32 * w + L.n;
+        const bool tv = t < T_;
+        const uint32_t vm = lane_mask(tv);
+        float v[6][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[ks][2 * j] = bf_lo(rawx[ks][j]);
+                v[ks][2 * j + 1] = bf_hi(rawx[ks][j]);
+                sum += v[ks][2 * j] + v[ks][2 * j + 1];
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / TS_H);
+        float sq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[ks][j] -= mean;
+                sq += v[ks][j] * v[ks][j];
+            }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / TS_H) + 1e-5f);
+        FragH u[7], dq[6];
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            float gam[8], bet[8], o[8];
+            load8(lp.p[P_TF_LN_W] + 16 * ks + 8 * L.h, gam);
+            load8(lp.p[P_TF_LN_B] + 16 * ks + 8 * L.h, bet);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[ks][j] * rstd * gam[j] + bet[j];
+            frag_from(u[ks], o);
+            dq[ks].v = __builtin_bit_cast(s16x8, rawd[ks]);
+        }
+        {
+            const FragH one = frag_const_one();
+            FragH zero;
+            frag_zero(zero);
+            u[6].v = L.h ? zero.v : one.v;
+        }
+        bf16_t* srow = S + (size_t)(4 + t) * TB_RS + 4 * L.h;
+        bf16_t* brow = Bi + (size_t)t * TB_RS + 4 * L.h;
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl) {
+            FragH w1[7], w2t[6];
+            load_wfrags<7>(w1, wl, gl, L.lane);
+            load_wfrags<6>(w2t, wl + 28 * 512, gl, L.lane);
+            f32x16 a1 = mma32(w1[0], u[0], f32x16_zero());
+#pragma unroll
+            for (int ks = 1; ks < 7; ++ks) a1 = mma32(w1[ks], u[ks], a1);
+            f32x16 d5 = mma32(w2t[0], dq[0], f32x16_zero());
+#pragma unroll
+            for (int ks = 1; ks < 6; ++ks) d5 = mma32(w2t[ks], dq[ks], d5);
+            float hv[12], dv[12], d5v[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                silu_dsilu(a1[r], hv[r], dv[r]);
+                d5v[r] = d5[r];
+            }
+            P6 ph, pd, p5;
+            p6_pack(hv, vm, ph);
+            p6_pack(dv, vm, pd);
+            p6_pack(d5v, vm, p5);
+            p6_store(srow + gl * TS_CG, ph);
+            p6_store(brow + gl * TS_CG, p5);  // dh5: picked up by the group waves right after the barrier (image B is free until F2b)
+            d1keep[gl] = pd;                  // dSiLU(a1) stays in this wave's registers until the last strip phase
+            p6_gstore(ops.h1 + ((size_t)(4 * gh + gl) * ntok + n0 + t) * TS_CG + 4 * L.h, ph, tv, true);
+        }
+    }
+    PHASE(2);
+    lds_barrier();  // S and the dh5 image are complete; the weight window is dead
+
+    // ---- group phases: wave = (group gl, half th) -------------------------------------------------------------------------------
+    const int gl = w >> 1, th = w & 1, g = 4 * gh + gl;
+    const int s_beg = th ? NSL : 0, s_end = th ? NS : NSL, nblk = (s_end - s_beg + TB_SB - 1) / TB_SB;
+    bf16_t* Sc = S + gl * TS_CG;
+    bf16_t* Ac = A + gl * TS_CG + 4 * L.h;
+    bf16_t* Bc = Bi + gl * TS_CG + 4 * L.h;
+    const size_t gbase = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;
+    auto rowp = [&](int tt, int bl, int bu) -> const bf16_t* { return Sc + (size_t)((tt < TS ? bl : bu) + tt) * TB_RS; };
+    auto orow = [&](int tt, int bl, int bu) -> bf16_t* { return Sc + (size_t)((th ? bu : bl) + tt) * TB_RS + 4 * L.h; };
+    float gw[12], gb[12];
+    chan_vec12(lp.p[P_TF_GN_W] + g * TS_CG, L.h, gw);
+    chan_vec12(lp.p[P_TF_GN_B] + g * TS_CG, L.h, gb);
+    const float cnt = (float)(TS_CG * T_);
+
+    FragH wa[5], wb[5], wc[5];
+    load_wfrags<5>(wa, W.C1, g, L.lane);
+    load_wfrags<5>(wb, W.C2, g, L.lane);
+    load_wfrags<5>(wc, W.C3, g, L.lane);
+    // dh5 of the wave's strips: out of image B into registers now (the image becomes a3hat in F2b), consumed in F3.  (Parking such rows in
+    // the operand buffers instead costs a vmcnt(0) drain of the strip phase's stores: 16 % of the wave time when measured.)
+    constexpr int TB_MAXS = 4;  // strips per wave (T <= 256)
+    P6 park[TB_MAXS];
+#pragma unroll
+    for (int k = 0; k < TB_MAXS; ++k) {
+        const int t = 32 * (s_beg + k) + L.n;
+        if (s_beg + k < s_end) p6_load(Bc + (size_t)t * TB_RS, park[k]);
+    }
+
+#define TB_BLOCKS(fwd_dir)                                                   \
+    for (int bi_ = 0; bi_ < nblk; ++bi_)                                     \
+        for (int s0 = s_beg + TB_SB * (((fwd_dir) == (th == 0)) ? bi_ : nblk - 1 - bi_), once_ = 1; once_; once_ = 0)
+
+    PHASE(3);
+    // F1: conv1: h1 (bases 4,4) -> h2 = SiLU(a2) (bases 3,5), dSiLU(a2) -> A
+#pragma unroll 1
+    TB_BLOCKS(true) {
+        FragH b[TB_SB][5];
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowp(t - 1, 4, 4), rowp(t, 4, 4), rowp(t + 1, 4, 4), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const bool tv = t < T_;
+                const uint32_t vm = lane_mask(tv);
+                const f32x16 a2 = conv_mma(wa, b[k]);
+                float hv[12], dv[12];
+#pragma unroll
+                for (int r = 0; r < 12; ++r) silu_dsilu(a2[r], hv[r], dv[r]);
+                P6 ph, pd;
+                p6_pack(hv, vm, ph);
+                p6_pack(dv, vm, pd);
+                p6_store(orow(t, 3, 5), ph);
+                p6_store(Ac + (size_t)t * TB_RS, pd);
+                p6_gstore(ops.h2 + gbase + (size_t)t * TS_CG, ph, tv, true);
+            }
+    }
+    PHASE(4);
+    lds_barrier();
+    PHASE(5);
+    // F2a: conv2: h2 (3,5) -> a3 (bf16, bases 2,6) + partial GroupNorm sums
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+        TB_BLOCKS(true) {
+            FragH b[TB_SB][5];
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    conv_bfrags3(L, rowp(t - 1, 3, 5), rowp(t, 3, 5), rowp(t + 1, 3, 5), b[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    const uint32_t vm = lane_mask(t < T_);
+                    const f32x16 a3 = conv_mma(wb, b[k]);
+                    P6 pa;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        pa.d[i] = pack2bf(a3[2 * i], a3[2 * i + 1]) & vm;
+                        const float v0 = bf_lo(pa.d[i]), v1 = bf_hi(pa.d[i]);
+                        s1 += v0 + v1;
+                        s2 += v0 * v0 + v1 * v1;
+                    }
+                    p6_store(orow(t, 2, 6), pa);
+                }
+        }
+        s1 = wave_sum64(s1);
+        s2 = wave_sum64(s2);
+        if (L.lane == 0) {
+            red[(gl * 2 + th) * 2] = s1;
+            red[(gl * 2 + th) * 2 + 1] = s2;
+        }
+    }
+    PHASE(6);
+    lds_barrier();
+    PHASE(7);
+    const float gmean = (red[gl * 4] + red[gl * 4 + 2]) / cnt;
+    const float grstd = rsqrtf(fmaxf((red[gl * 4 + 1] + red[gl * 4 + 3]) / cnt - gmean * gmean, 0.f) + 1e-5f);
+    // F2b (in place, own values): a3hat -> B, h4 = SiLU(a3hat * gw + gb) -> S (2,6)
+#pragma unroll 2
+    for (int s = s_beg; s < s_end; ++s) {
+        const int t = 32 * s + L.n;
+        const bool tv = t < T_;
+        const uint32_t vm = lane_mask(tv);
+        bf16_t* r = orow(t, 2, 6);
+        P6 pa, pn, ph;
+        p6_load(r, pa);
+        float a3[12], hv[12];
+        p6_unpack(pa, a3);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) a3[q] = (a3[q] - gmean) * grstd;
+        p6_pack(a3, vm, pn);
+        p6_unpack(pn, a3);  // the bf16 values the backward pass will see
+#pragma unroll
+        for (int q = 0; q < 12; ++q) hv[q] = silu_f(a3[q] * gw[q] + gb[q]);
+        p6_pack(hv, vm, ph);
+        p6_store(Bc + (size_t)t * TB_RS, pn);
+        p6_store(r, ph);
+        p6_gstore(ops.h4 + gbase + (size_t)t * TS_CG, ph, tv, true);
+    }
+    PHASE(8);
+    lds_barrier();
+    PHASE(9);
+    // F3: conv3: h4 (2,6) -> a5; h5 = SiLU(a5) (operand only); da5 = dh5 * dSiLU(a5) -> S (1,7)
+#pragma unroll 1
+    TB_BLOCKS(true) {
+        FragH b[TB_SB][5];
+        P6 p5[TB_SB];
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowp(t - 1, 2, 6), rowp(t, 2, 6), rowp(t + 1, 2, 6), b[k]);
+                p5[k] = (s0 + k - s_beg) == 0 ? park[0] : (s0 + k - s_beg) == 1 ? park[1] : (s0 + k - s_beg) == 2 ? park[2] : park[3];
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const bool tv = t < T_;
+                const uint32_t vm = lane_mask(tv);
+                const f32x16 a5 = conv_mma(wc, b[k]);
+                float hv[12], dv[12], d5[12];
+                p6_unpack(p5[k], d5);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) {
+                    silu_dsilu(a5[r], hv[r], dv[r]);
+                    dv[r] *= d5[r];
+                }
+                P6 ph, pd;
+                p6_pack(hv, vm, ph);
+                p6_pack(dv, vm, pd);
+                p6_store(orow(t, 1, 7), pd);
+                p6_gstore(ops.h5 + gbase + (size_t)t * TS_CG, ph, tv, true);
+                p6_gstore(ops.da5 + gbase + (size_t)t * TS_CG, pd, tv, true);
+            }
+    }
+    // transposed conv weights replace the forward ones
+    load_wfrags<5>(wa, W.C1T, g, L.lane);
+    load_wfrags<5>(wb, W.C2T, g, L.lane);
+    load_wfrags<5>(wc, W.C3T, g, L.lane);
+    PHASE(10);
+    lds_barrier();
+    PHASE(11);
+    // B3: conv3^T: da5 (1,7) -> dh4; dn3 = dh4 * dSiLU(n3) -> S (2,6); GroupNorm backward sums and affine gradients
+    {
+        float sa = 0.f, sb = 0.f, dgw[12], dgb[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) dgw[r] = dgb[r] = 0.f;
+#pragma unroll 1
+        TB_BLOCKS(false) {
+            FragH b[TB_SB][5];
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    conv_bfrags3(L, rowp(t - 1, 1, 7), rowp(t, 1, 7), rowp(t + 1, 1, 7), b[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    const uint32_t vm = lane_mask(t < T_);
+                    const f32x16 dh4 = conv_mma(wc, b[k]);
+                    P6 pn, pd;
+                    p6_load(Bc + (size_t)t * TB_RS, pn);
+                    float ah[12], dn[12];
+                    p6_unpack(pn, ah);
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) dn[r] = dh4[r] * dsilu_only(ah[r] * gw[r] + gb[r]);
+                    p6_pack(dn, vm, pd);
+                    p6_unpack(pd, dn);  // masked, bf16 (what the next stage reads back)
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) {
+                        dgw[r] += dn[r] * ah[r];
+                        dgb[r] += dn[r];
+                        sa += gw[r] * dn[r];
+                        sb += gw[r] * dn[r] * ah[r];
+                    }
+                    p6_store(orow(t, 2, 6), pd);
+                }
+        }
+        sa = wave_sum64(sa);
+        sb = wave_sum64(sb);
+        if (L.lane == 0) {
+            red[(gl * 2 + th) * 2] = sa;
+            red[(gl * 2 + th) * 2 + 1] = sb;
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const float a = half_sum32(dgw[r]), bq = half_sum32(dgb[r]);
+            if (L.n == 0) {
+                const int ch = gl * TS_CG + (r & 3) + 8 * (r >> 2) + 4 * L.h;
+                gnp[(th * 2 + 0) * 96 + ch] = a;
+                gnp[(th * 2 + 1) * 96 + ch] = bq;
+            }
+        }
+        // the next stage's "frame -1" / "frame NT" row held this stage's input: clear it (only this wave read it)
+        if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 6 : 1) * TB_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    }
+    PHASE(12);
+    lds_barrier();
+    PHASE(13);
+    // B3b (in place, own values): da3 = rstd (gw dn3 - mean(gw dn3) - a3hat mean(gw dn3 a3hat)) -> S (2,6)
+    {
+        const float msa = (red[gl * 4] + red[gl * 4 + 2]) / cnt, msb = (red[gl * 4 + 1] + red[gl * 4 + 3]) / cnt;
+#pragma unroll 2
+        for (int s = s_beg; s < s_end; ++s) {
+            const int t = 32 * s + L.n;
+            const bool tv = t < T_;
+            const uint32_t vm = lane_mask(tv);
+            bf16_t* r = orow(t, 2, 6);
+            P6 pd, pn, po;
+            p6_load(r, pd);
+            p6_load(Bc + (size_t)t * TB_RS, pn);
+            float dn[12], ah[12];
+            p6_unpack(pd, dn);
+            p6_unpack(pn, ah);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) dn[q] = grstd * (gw[q] * dn[q] - msa - ah[q] * msb);
+            p6_pack(dn, vm, po);
+            p6_store(r, po);
+            p6_gstore(ops.da3 + gbase + (size_t)t * TS_CG, po, tv, true);
+        }
+    }
+    PHASE(14);
+    lds_barrier();
+    PHASE(15);
+    // B2: conv2^T: da3 (2,6) -> dh2; da2 = dh2 * dSiLU(a2) (image A) -> S (3,5)
+#pragma unroll 1
+    TB_BLOCKS(false) {
+        FragH b[TB_SB][5];
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowp(t - 1, 2, 6), rowp(t, 2, 6), rowp(t + 1, 2, 6), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const bool tv = t < T_;
+                const uint32_t vm = lane_mask(tv);
+                const f32x16 dh2 = conv_mma(wb, b[k]);
+                P6 pd2, po;
+                p6_load(Ac + (size_t)t * TB_RS, pd2);
+                float d2[12], o[12];
+                p6_unpack(pd2, d2);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) o[r] = dh2[r] * d2[r];
+                p6_pack(o, vm, po);
+                p6_store(orow(t, 3, 5), po);
+                p6_gstore(ops.da2 + gbase + (size_t)t * TS_CG, po, tv, true);
+            }
+    }
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 5 : 2) * TB_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    PHASE(16);
+    lds_barrier();
+    PHASE(17);
+    // B1: conv1^T: da2 (3,5) -> dh1 -> S (4,4): the halves meet again, strip-contiguous
+#pragma unroll 1
+    TB_BLOCKS(false) {
+        FragH b[TB_SB][5];
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowp(t - 1, 3, 5), rowp(t, 3, 5), rowp(t + 1, 3, 5), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const f32x16 dh1 = conv_mma(wa, b[k]);
+                float o[12];
+#pragma unroll
+                for (int r = 0; r < 12; ++r) o[r] = dh1[r];
+                P6 po;
+                p6_pack(o, 0xFFFFFFFFu, po);
+                p6_store(orow(t, 4, 4), po);
+            }
+    }
+    PHASE(18);
+    lds_barrier();
+    // last strip phase: da1 = dh1 * dSiLU(a1) for the wave's 32 frames (the derivative never left this wave's registers) -> operand
+    if (w < NS) {
+        const int t = 32 * w + L.n;
+        const bool tv = t < T_;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            P6 ph, po;
+            p6_load(S + (size_t)(4 + t) * TB_RS + q * TS_CG + 4 * L.h, ph);
+            float dh[12], d1[12];
+            p6_unpack(ph, dh);
+            p6_unpack(d1keep[q], d1);
+#pragma unroll
+            for (int r = 0; r < 12; ++r) dh[r] *= d1[r];
+            p6_pack(dh, lane_mask(tv), po);
+            p6_gstore(ops.da1 + ((size_t)(4 * gh + q) * ntok + n0 + t) * TS_CG + 4 * L.h, po, tv, true);
+        }
+    }
+#undef TB_BLOCKS
+    // GroupNorm affine partial sums of this workgroup's 96 channels -> its `part` row (entries [0, 2 FFN); the tail kernel writes the rest)
+    for (int i = tid; i < 2 * 96; i += blockDim.x) {
+        const int kind = i / 96, ch = i % 96;
+        part[(size_t)row * (2 * TS_FFN + 2 * TS_H) + kind * TS_FFN + gh * 96 + ch] = gnp[(0 * 2 + kind) * 96 + ch] + gnp[(1 * 2 + kind) * 96 + ch];
+    }
+    PHASE_END();
+}
+PHASE_READER(nbss_phase_read_tconvffn_bwd_s)
+
+int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* x, const void* dy,
+                          void* const* opsv, hipStream_t st) {
+    if (c.dtype != NBSS_BF16 || c.T > 256) return NBSS_EUNSUPPORTED;
+    const size_t NT = (size_t)((c.T + 31) / 32) * 32;
+    const size_t a_el = NT * TB_RS > (size_t)52 * 512 ? NT * TB_RS : (size_t)52 * 512;
+    const size_t lds = ((NT + TB_PAD) * TB_RS + a_el + NT * TB_RS) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + PHASE_LDS_BYTES;
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    const bf16_t* pk = (const bf16_t*)packed;
+    TsBwdW W = {pk + pack_off(c, layer, K_TS_W1),  pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1),  pk + pack_off(c, layer, K_TS_C2),
+                pk + pack_off(c, layer, K_TS_C3),  pk + pack_off(c, layer, K_TS_C1_T), pk + pack_off(c, layer, K_TS_C2_T), pk + pack_off(c, layer, K_TS_C3_T)};
+    TsOps ops = {(bf16_t*)opsv[0], (bf16_t*)opsv[1], (bf16_t*)opsv[2], (bf16_t*)opsv[3], (bf16_t*)opsv[4], (bf16_t*)opsv[5], (bf16_t*)opsv[6], (bf16_t*)opsv[7]};
+    int e = NBSS_SET_MAX_LDS(tconvffn_bwd_s_kernel, lds);
+    if (e) return e;
+    ProfScope ps(PK_TCF_B, st);
+    NBSS_LAUNCH(tconvffn_bwd_s_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, (const bf16_t*)x, (const bf16_t*)dy, part, ops);
+    return NBSS_CHECK_LAUNCH();
+}

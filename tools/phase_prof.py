@@ -16,13 +16,14 @@ from nbss_amd._lib import NBSS_BF16, hip, make_cfg  # noqa: E402
 def main():
     name = sys.argv[1]
     B, iters = (int(sys.argv[2]) if len(sys.argv) > 2 else 8), 3
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 251  # (kernels whose LDS is full at T = 251 need a shorter T for the timer slots)
     dev = torch.device("cuda:0")
     lib = hip()
-    cfg = make_cfg(B, 129, 251, 12, 4, L=1, dtype=NBSS_BF16)
+    cfg = make_cfg(B, 129, T, 12, 4, L=1, dtype=NBSS_BF16)
     flat = ops.random_params(lib, cfg, dev)
     packed = ops.pack_params(lib, cfg, flat)
-    x = torch.randn(B, 129, 251, 96, device=dev).bfloat16()
-    dy = torch.randn(B, 129, 251, 96, device=dev).bfloat16()
+    x = torch.randn(B, 129, T, 96, device=dev).bfloat16()
+    dy = torch.randn(B, 129, T, 96, device=dev).bfloat16()
     G = torch.zeros_like(flat)
     ws = ops.workspace(lib, cfg, dev)
     o = ops.mhsa_save(lib, cfg, dev)
@@ -37,7 +38,7 @@ def main():
     }
     if name == "mhsa_bwd":
         fns["mhsa_fwd"]()
-    reader = getattr(lib, "nbss_phase_read_" + name)  # (the single-pass bf16 attention backward shares mhsa_bwd's accumulators)
+    reader = getattr(lib, "nbss_phase_read_" + (sys.argv[4] if len(sys.argv) > 4 else name))  # (the single-pass bf16 attention backward shares mhsa_bwd's accumulators)
     reader.restype = C.c_int
     buf = (C.c_ulonglong * 32)()
     fns[name]()
