@@ -110,9 +110,10 @@ _HIP = None
 
 
 def hip_lib_path() -> Path:
-    # NBSS_HIP_FLAVOUR=phase selects the diagnostic build with in-kernel phase timers (tools/phase_prof.py); same kernels
+    # NBSS_HIP_FLAVOUR=phase selects the diagnostic build with in-kernel phase timers (tools/phase_prof.py); any other value
+    # names a side-by-side build lib/libnbss_hip_<flavour>.so for A/B timing by the tools (never set by the product)
     flavour = os.environ.get("NBSS_HIP_FLAVOUR", "")
-    return Path(__file__).resolve().parent / "lib" / ("libnbss_hip_phase.so" if flavour == "phase" else "libnbss_hip.so")
+    return Path(__file__).resolve().parent / "lib" / (f"libnbss_hip_{flavour}.so" if flavour else "libnbss_hip.so")
 
 
 def hip() -> Lib:

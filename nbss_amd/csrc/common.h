@@ -68,6 +68,16 @@ NBSS_DEV uint32_t pack2bf(float a, float b) {
 // evaluated unconditionally, so keep_if(cond, f(x)) is a v_cndmask.
 NBSS_DEV float keep_if(bool c, float v) { return c ? v : 0.f; }
 
+// 2^x as ONE v_exp_f32.  exp2f() expands to a denormal-safe sequence (v_cmp, 2 x v_cndmask, v_add, v_exp, v_ldexp: six VALU
+// instructions per softmax element); the attention kernels only exponentiate differences <= 0 whose results may flush to zero.
+NBSS_DEV float fast_exp2(float x) {
+#ifdef NBSS_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+
 NBSS_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
 NBSS_DEV float dsilu_f(float x) {

@@ -24,8 +24,11 @@
 #define MH_DH 24
 #define MH_TP 256
 #define MH_NT 16       // key/query tiles of 16 frames
-#define MH_NSW 2       // strips per wave (8 waves x 2 strips = 16 strips; two waves per SIMD share one K/V image)
+// strips per wave: template parameter NSW (2 = 8 waves x 2 strips; 1 = 16 waves x 1 strip)
 #define MH_KS (MH_H / 32)
+#ifndef MH_BF16_NSW
+#define MH_BF16_NSW 2
+#endif
 
 // LN of a 16-frame strip held as natural-order B fragments (lane: frame l&15, channels 32ks+8g+j)
 template <class T>
@@ -66,8 +69,8 @@ NBSS_DEV void v_frag_tr(Frag<bf16_t>& f, const bf16_t* __restrict__ vr, int half
 NBSS_DEV void v_frag_tr(Frag<float>&, const float*, int, int) {}
 
 // FULL: T in (240, 256]: every key tile exists, the tile tests fold at compile time (see mhsa_bwd.hip)
-template <class T, int HPP, bool FULL>
-__global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+template <class T, int HPP, bool FULL, int NSW>
+__global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
                                                        const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave, float* __restrict__ lse) {
@@ -92,17 +95,18 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
         load8(lnw + ks * 32 + 8 * g4, gam[ks]);
         load8(lnb + ks * 32 + 8 * g4, bet[ks]);
     }
-    u32x4 wr[6];  // this thread's share of a 48-fragment weight window
+    constexpr int NTHR = 64 * 16 / NSW, WPT = 3072 / NTHR;
+    u32x4 wr[WPT];  // this thread's share of a 48-fragment weight window
     auto wwin_load = [&](const T* s0, const T* s1) {  // two runs of 24 fragments (1536 16-byte vectors) each
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int v = tid + i * 512;
+        for (int i = 0; i < WPT; ++i) {
+            const int v = tid + i * NTHR;
             wr[i] = *reinterpret_cast<const u32x4*>((v < 1536 ? s0 : s1 - 1536 * 8) + (size_t)v * 8);
         }
     };
     auto wwin_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) reinterpret_cast<u32x4*>(wl)[tid + i * 512] = wr[i];
+        for (int i = 0; i < WPT; ++i) reinterpret_cast<u32x4*>(wl)[tid + i * NTHR] = wr[i];
     };
     if (WLDS) {
         wwin_load(Win, Win + 24 * 512);  // Q rows | K rows (24 fragments each: 4 heads x 2 halves x 3 k-steps)
@@ -115,12 +119,12 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
         if (pass > 0) lds_barrier();
 
         // ---- stage A: LN, then Q (registers), K and V^T (LDS) for this pass's heads --------
-        Frag<T> qf[MH_NSW][HPP];
+        Frag<T> qf[NSW][HPP];
         {
-            Frag<T> u[MH_NSW][MH_KS];
+            Frag<T> u[NSW][MH_KS];
 #pragma unroll
-            for (int si = 0; si < MH_NSW; ++si) {
-                const int t = (w * MH_NSW + si) * 16 + l15;
+            for (int si = 0; si < NSW; ++si) {
+                const int t = (w * NSW + si) * 16 + l15;
                 ln_strip<T>(xb + (size_t)t * MH_H, t < T_, gam, bet, u[si]);
             }
             if (WLDS) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
 #pragma unroll
                 for (int hh = 0; hh < HPP; ++hh) {
                     const int head = pass * HPP + hh;
-                    f32x4 ct[MH_NSW][2];
+                    f32x4 ct[NSW][2];
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         Frag<T> a[MH_KS];
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                             else wfrag_load(a[ks], Win, (which * MH_HEADS + head) * 2 + half, MH_KS, ks);
                         }
 #pragma unroll
-                        for (int si = 0; si < MH_NSW; ++si) {
+                        for (int si = 0; si < NSW; ++si) {
                             f32x4 acc = F32X4_ZERO;
 #pragma unroll
                             for (int ks = 0; ks < MH_KS; ++ks) acc = mma(a[ks], u[si][ks], acc);
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                         b1[r] = (16 + 4 * g4 + r < MH_DH) ? bsrc[which * MH_H + head * MH_DH + 16 + 4 * g4 + r] : 0.f;
                     }
 #pragma unroll
-                    for (int si = 0; si < MH_NSW; ++si) {
-                        const int t = (w * MH_NSW + si) * 16 + l15;
+                    for (int si = 0; si < NSW; ++si) {
+                        const int t = (w * NSW + si) * 16 + l15;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             ct[si][0][r] += b0[r];
@@ -201,9 +205,9 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
         lds_barrier();
 
         // ---- stage B: attention per (strip, head); outputs stay in registers as B fragments ---
-        Frag<T> of[MH_NSW][HPP];
+        Frag<T> of[NSW][HPP];
 #pragma unroll
-        for (int si = 0; si < MH_NSW; ++si) {
+        for (int si = 0; si < NSW; ++si) {
 #pragma unroll
             for (int hh = 0; hh < HPP; ++hh) {
                 const T* kh = Ks + (size_t)hh * MH_TP * MH_DH;
@@ -219,11 +223,13 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                         if (g4 < 2) frag_load_hi(a, kr + 16 + 4 * g4);
                         else frag_zero_hi(a);
                         sc[j] = mma(a, qf[si][hh], F32X4_ZERO);
+                        if (j == nst - 1) {  // only the last key tile can hold padded keys
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
-                            mx = fmaxf(mx, sc[j][r]);
+                            for (int r = 0; r < 4; ++r)
+                                if (j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
                         }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[j][r]);
                     } else {
                         sc[j] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
                     }
@@ -234,14 +240,14 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                 for (int j = 0; j < MH_NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = (j < nst) ? exp2f(sc[j][r] - mx) : 0.f;
+                        const float p = (j < nst) ? fast_exp2(sc[j][r] - mx) : 0.f;
                         sc[j][r] = p;
                         sum += p;
                     }
                 sum = wave_sum16(sum);
                 const float inv = 1.0f / sum;
                 if (lse && g4 == 0) {  // log2-sum-exp of the scaled score row: backward rebuilds P = exp2(S' - lse) from it
-                    const int t = (w * MH_NSW + si) * 16 + l15;
+                    const int t = (w * NSW + si) * 16 + l15;
                     if (t < T_) lse[((size_t)bf * T_ + t) * MH_HEADS + pass * HPP + hh] = mx + log2f(sum);
                 }
                 f32x4 o0 = F32X4_ZERO, o1 = F32X4_ZERO;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                 }
                 frag_from_c2(of[si][hh], o0, o1);
                 if (osave) {  // attention output before out_proj: the only extra activation backward needs
-                    const int t = (w * MH_NSW + si) * 16 + l15;
+                    const int t = (w * NSW + si) * 16 + l15;
                     if (t < T_) {
                         T* orow = osave + ((size_t)bf * T_ + t) * MH_H + (pass * HPP + hh) * MH_DH;
                         // (plain stores: the four heads' 48-byte pieces of a row merge in L2; non-temporal ones were 2x slower on some boxes)
@@ -290,10 +296,10 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
 
         // ---- stage C: output projection (+bias, +residual) --------------------------------------
         // the residual rows are requested up front (one wait instead of one per output tile)
-        float rv[MH_NSW][MH_H / 16][4];
+        float rv[NSW][MH_H / 16][4];
 #pragma unroll
-        for (int si = 0; si < MH_NSW; ++si) {
-            const int t = (w * MH_NSW + si) * 16 + l15;
+        for (int si = 0; si < NSW; ++si) {
+            const int t = (w * NSW + si) * 16 + l15;
 #pragma unroll
             for (int mt = 0; mt < MH_H / 16; ++mt) {
                 if (t < T_) load4((pass == 0 ? xb : yb) + (size_t)t * MH_H + 16 * mt + 4 * g4, rv[si][mt]);
@@ -315,8 +321,8 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
                 for (int r = 0; r < 4; ++r) bo[r] = WLDS ? prm[3 * MH_H + ch + r] : bout[ch + r];
             }
 #pragma unroll
-            for (int si = 0; si < MH_NSW; ++si) {
-                const int t = (w * MH_NSW + si) * 16 + l15;
+            for (int si = 0; si < NSW; ++si) {
+                const int t = (w * NSW + si) * 16 + l15;
                 f32x4 acc = F32X4_ZERO;
 #pragma unroll
                 for (int hh = 0; hh < HPP; ++hh) acc = mma(a[hh], of[si][hh], acc);
@@ -328,23 +334,23 @@ __global__ __launch_bounds__(512) void mhsa_fwd_kernel(nbss_cfg c, const float* 
     }
 }
 
-template <class T, int HPP, bool FULL>
+template <class T, int HPP, bool FULL, int NSW>
 static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
     if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
     // +64: the last transposing read overreaches its row by 16 B; bf16: 48-fragment weight window + biases
     const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T) + 64 + (sizeof(T) == 2 && HPP == MH_HEADS ? (size_t)48 * 512 * sizeof(T) + 4 * MH_H * sizeof(float) : 0);
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP, FULL>), lds);
+    int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP, FULL, NSW>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.F), block(512);
+    dim3 grid(c.B * c.F), block(64 * 16 / NSW);
     ProfScope ps(PK_MHSA_F, st);
-    NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
+    NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL, NSW>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
                 pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, osave ? (float*)((char*)osave + mhsa_lse_offset(c)) : nullptr);
     return NBSS_CHECK_LAUNCH();
 }
 
 int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
-    if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false>(c, P, packed, layer, x, y, osave, st);
-    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<bf16_t, 4, false>(c, P, packed, layer, x, y, osave, st);
+    if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false, 2>(c, P, packed, layer, x, y, osave, st);
+    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<bf16_t, 4, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st);
 }

@@ -365,8 +365,8 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                         const f32x4 dp = mma(av[e], dof[si], F32X4_ZERO);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const bool kv = jj * 16 + 4 * g4 + r < T_;  // (padding keys hold finite values: select, do not multiply)
-                            const float p = exp2f(st[r] - lsev[si]);
+                            const bool kv = jj != nst - 1 || jj * 16 + 4 * g4 + r < T_;  // (only the last key tile has padding keys; they hold finite values: select, do not multiply)
+                            const float p = fast_exp2(st[r] - lsev[si]);
                             ds[e][r] = kv ? p * (dp[r] - Dv[si]) : 0.f;
                         }
                     }
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                         const f32x4 dp = mma(doa[e], vf[si], F32X4_ZERO);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float p = exp2f(sq[r] - mls[e][r]);
+                            const float p = fast_exp2(sq[r] - mls[e][r]);
                             pt[e][r] = p;
                             dst[e][r] = p * (dp[r] - ddv[e][r]);
                         }
