@@ -59,7 +59,41 @@ def main():
     np.savez_compressed(HERE / "stft_norm_n1500.npz", sig=sig.numpy(), X_re=X.real.numpy(), X_im=X.imag.numpy(), Xl=Xl.numpy(),
                         XrMM=XrMM.numpy(), back=back.numpy())
     nb_models()
+    online_models()
     print("written:", [p.name for p in HERE.glob("*.npz")])
+
+
+def online_models():
+    """tiny seeded OnlineSpatialNet instances of the reference (OnlineSpatialNet.py, base/retention.py): banded causal MHSA and
+    retention (parallel form), eval mode: input, state_dict, output, gradients of sum(y * r).
+    The attention window (31) covers the whole fixture sequence (21 frames): with the torch of this image the reference's call
+    `mhsa(x, x, x, attn_mask=band, is_causal=True, need_weights=False)` takes nn.MultiheadAttention's causal fast path, which DROPS the
+    band mask — the reference attends to all past frames whatever N is; the two only agree (and the fixture is only meaningful) for T <= N."""
+    from models.arch.OnlineSpatialNet import OnlineSpatialNet  # noqa: E402  (reference)
+    assert "/root/reference" in sys.modules["models.arch.OnlineSpatialNet"].__file__
+    # mamba_ssm is not installed: the reference then sets Mamba = None and its `isinstance(self.mhsa, Mamba)` raises for EVERY attention
+    # type; a placeholder class lets the mhsa / retention variants run unmodified
+    sys.modules["models.arch.OnlineSpatialNet"].Mamba = type("Mamba", (), {})
+    torch.manual_seed(3)
+    out = {}
+    for name, kw in (("mhsa31", dict(attention="mhsa(31)")), ("ret2", dict(attention="ret(2)", decay=[4, 5, 9, 10], rope=False))):
+        net = OnlineSpatialNet(dim_input=4, dim_output=4, num_layers=2, dim_squeeze=8, num_freqs=9, encoder_kernel_size=5, dim_hidden=32, dim_ffn=64,
+                               num_heads=4, dropout=(0, 0, 0), kernel_size=(5, 3), conv_groups=(8, 8), norms=["LN", "LN", "GN", "LN", "LN", "LN"],
+                               full_share=0, **kw).eval()
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+        x = torch.randn(2, 9, 21, 4)
+        y = net(x)
+        r = torch.randn_like(y)
+        (y * r).sum().backward()
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/r"] = x.numpy(), y.detach().numpy(), r.numpy()
+        for k, v in net.state_dict().items():
+            out[f"{name}/param/{k}"] = v.numpy()
+        for k, p in net.named_parameters():
+            out[f"{name}/grad/{k}"] = p.grad.numpy()
+    np.savez_compressed(HERE / "online_tiny.npz", **out)
 
 
 def nb_models():
