@@ -41,6 +41,10 @@ int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal
         int _e = check_cfg(*(cfg));            \
         if (_e != NBSS_OK) return _e;          \
     }
+/* backward (and a forward that saves state for it) keeps a whole sequence per workgroup: T <= NBSS_T_TRAIN_MAX */
+#define CHECK_CFG_TRAIN(cfg) \
+    CHECK_CFG(cfg);          \
+    if ((cfg)->T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;
 #define CHECK_LAYER(cfg, layer) \
     if ((layer) < 0 || (layer) >= (cfg)->L) return NBSS_EINVAL;
 
@@ -121,7 +125,7 @@ int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, 
 
 int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
                   const void* o_save, void* dx, void* ws, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !o_save || !dx || !ws) return NBSS_EINVAL;
     return mhsa_bwd_impl(*cfg, params, grads, packed, layer, x, dy, o_save, dx, ws, (hipStream_t)stream);
@@ -141,7 +145,7 @@ int64_t nbss_workspace_bytes(const nbss_cfg* cfg) {
 
 int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
                       void* dx, void* ws, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
     return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
@@ -149,7 +153,7 @@ int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, co
 
 int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, int which, const void* x,
                    const void* dy, void* dx, void* ws, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws || (which != 0 && which != 1)) return NBSS_EINVAL;
     return fconv_bwd_impl(*cfg, params, grads, packed, layer, which, x, dy, dx, ws, (hipStream_t)stream);
@@ -157,7 +161,7 @@ int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const
 
 int nbss_full_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
                   void* dx, void* ws, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
     return full_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
@@ -165,13 +169,13 @@ int nbss_full_bwd(const nbss_cfg* cfg, const float* params, float* grads, const 
 
 int nbss_decoder_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* x, const float* dout, void* dx,
                      void* ws, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     if (!params || !grads || !packed || !x || !dout || !dx || !ws) return NBSS_EINVAL;
     return decoder_bwd_impl(*cfg, params, grads, packed, x, dout, dx, ws, (hipStream_t)stream);
 }
 
 int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const void* dy, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     if (!grads || !xin || !dy) return NBSS_EINVAL;
     return encoder_bwd_impl(*cfg, grads, xin, dy, (hipStream_t)stream);
 }
@@ -196,6 +200,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     CHECK_CFG(cfg);
     if (!params || !packed || !xin || !out || (!acts && !ws)) return NBSS_EINVAL;
     const nbss_cfg& c = *cfg;
+    if (acts && c.T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;  // long sequences: inference only
     hipStream_t st = (hipStream_t)stream;
     const size_t sb = stream_bytes(c);
     // training: every block input is kept (acts = [5L+1 stream copies | L attention save buffers]);
@@ -206,7 +211,8 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     int e = encoder_fwd_impl(c, params, packed, xin, buf(0), st);
     if (e) return e;
     for (int l = 0; l < c.L; ++l) {
-        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c)) : nullptr;
+        // (inference beyond 256 frames: the head of ws, idle without a backward pass, is the attention's K | V scratch)
+        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c)) : c.T > NBSS_T_TRAIN_MAX ? ws : nullptr;
         if ((e = fconv_fwd_impl(c, params, packed, l, 0, buf(k), buf(k + 1), st))) return e;
         if ((e = full_fwd_impl(c, params, packed, l, buf(k + 1), buf(k + 2), st))) return e;
         if ((e = fconv_fwd_impl(c, params, packed, l, 1, buf(k + 2), buf(k + 3), st))) return e;
@@ -219,7 +225,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
 
 int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
                               const float* dout, void* ws, int layer_hi, int layer_lo, void* stream) {
-    CHECK_CFG(cfg);
+    CHECK_CFG_TRAIN(cfg);
     if (!params || !grads || !packed || !xin || !acts || !ws) return NBSS_EINVAL;
     const nbss_cfg& c = *cfg;
     if (layer_lo < 0 || layer_hi > c.L || layer_lo >= layer_hi) return NBSS_EINVAL;

@@ -206,6 +206,9 @@ NBSS_HD int64_t pack_total(const nbss_cfg& c) {
 #define WGPART_BYTES ((size_t)512 * 112 * 272 * sizeof(float))
 // backward workspace (caller-provided): per-token LN statistics + the widest set of wgrad operands
 NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
+// sequence lengths: backward keeps a whole sequence per workgroup (LDS), forward has chunked variants beyond that
+#define NBSS_T_TRAIN_MAX 256
+#define NBSS_T_MAX 4096
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
@@ -215,7 +218,11 @@ NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
 NBSS_HD size_t mhsa_lse_offset(const nbss_cfg& c) {
     return ws_align((size_t)c.B * c.F * c.T * c.H * (c.dtype == NBSS_BF16 ? 2 : 4));
 }
-NBSS_HD size_t mhsa_save_bytes(const nbss_cfg& c) { return mhsa_lse_offset(c) + ws_align((size_t)c.B * c.F * c.T * c.heads * sizeof(float)); }
+// (T > 256, forward only: the same buffer is the K | V scratch of the long-sequence attention path, two stream tensors)
+NBSS_HD size_t mhsa_save_bytes(const nbss_cfg& c) {
+    const size_t s = mhsa_lse_offset(c) + ws_align((size_t)c.B * c.F * c.T * c.heads * sizeof(float));
+    return c.T > NBSS_T_TRAIN_MAX && s < 2 * mhsa_lse_offset(c) ? 2 * mhsa_lse_offset(c) : s;
+}
 // per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands
 NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
@@ -235,7 +242,7 @@ NBSS_HD int check_cfg(const nbss_cfg& c) {
     if (c.H != 96 || c.FFN != 192 || c.SQ != 8 || c.heads != 4) return NBSS_EUNSUPPORTED;
     if (c.f_groups != 8 || c.t_groups != 8 || c.f_ks != 5 || c.t_ks != 3 || c.enc_ks != 5) return NBSS_EUNSUPPORTED;
     if (c.C_in % 4 != 0 || c.C_in > 16 || c.C_out > 16 || c.C_out <= 0) return NBSS_EUNSUPPORTED;
-    if (c.F > 160 || c.T > 256) return NBSS_EUNSUPPORTED;
+    if (c.F > 160 || c.T > NBSS_T_MAX) return NBSS_EUNSUPPORTED;
     if (c.full_share < 0 || c.full_share >= c.L) return NBSS_EINVAL;
     // operand offsets inside the widest tensor ([N][3H] dqkv) are 32-bit in the weight-gradient kernels
     if ((size_t)c.B * c.F * c.T * 3 * c.H >= ((size_t)1 << 31)) return NBSS_EUNSUPPORTED;

@@ -350,7 +350,282 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     return NBSS_CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sequences beyond 256 frames (forward only: validate / test / predict on full-length utterances).  K and V of a whole
+// sequence no longer fit one workgroup's LDS, so the block is split in two launches:
+//   mhsa_kv_kernel    : LN + K / V projections of every frame -> scratch [N][H] each (stream dtype, heads side by side)
+//   mhsa_flash_kernel : one workgroup per 128 queries (8 waves x one 16-frame strip); K / V stream through LDS in blocks
+//                       of 128 keys (the next block's global loads are in flight during the current block's math),
+//                       online softmax per head, out_proj + bias + residual in the epilogue.
+// Any T; no state is saved for backward (training keeps the single-workgroup kernel and its T <= 256 limit).
+#define ML_KB 128
+template <class T>
+__global__ __launch_bounds__(512) void mhsa_kv_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ bin,
+                                                      const T* __restrict__ Win, const T* __restrict__ x, T* __restrict__ Kg, T* __restrict__ Vg) {
+    const int T_ = c.T, bf = blockIdx.x;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const int t = (int)blockIdx.y * ML_KB + w * 16 + l15;
+    const bool tv = t < T_;
+    const size_t n = (size_t)bf * T_ + (tv ? t : 0);
+    Frag<T> u[MH_KS];
+    {
+        float gam[MH_KS][8], bet[MH_KS][8];
+#pragma unroll
+        for (int ks = 0; ks < MH_KS; ++ks) {
+            load8(lnw + ks * 32 + 8 * g4, gam[ks]);
+            load8(lnb + ks * 32 + 8 * g4, bet[ks]);
+        }
+        ln_strip<T>(x + n * MH_H, tv, gam, bet, u);
+    }
+#pragma unroll
+    for (int which = 1; which < 3; ++which) {
+        T* dst = (which == 1 ? Kg : Vg) + n * MH_H;
+#pragma unroll
+        for (int head = 0; head < MH_HEADS; ++head) {
+            f32x4 ct[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < MH_KS; ++ks) {
+                    Frag<T> a;
+                    wfrag_load(a, Win, (which * MH_HEADS + head) * 2 + half, MH_KS, ks);
+                    acc = mma(a, u[ks], acc);
+                }
+                ct[half] = acc;
+            }
+            const float* bs = bin + which * MH_H + head * MH_DH;
+            if (tv) {
+                store4(dst + head * MH_DH + 4 * g4, ct[0][0] + bs[4 * g4], ct[0][1] + bs[4 * g4 + 1], ct[0][2] + bs[4 * g4 + 2], ct[0][3] + bs[4 * g4 + 3]);
+                if (g4 < 2)
+                    store4(dst + head * MH_DH + 16 + 4 * g4, ct[1][0] + bs[16 + 4 * g4], ct[1][1] + bs[17 + 4 * g4], ct[1][2] + bs[18 + 4 * g4],
+                           ct[1][3] + bs[19 + 4 * g4]);
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(512) void mhsa_flash_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ bin,
+                                                         const float* __restrict__ bout, const T* __restrict__ Win, const T* __restrict__ Wout,
+                                                         const T* __restrict__ x, const T* __restrict__ Kg, const T* __restrict__ Vg, T* __restrict__ y) {
+    NBSS_LDS(smem);
+    T* Ks = reinterpret_cast<T*>(smem);        // [heads][KB][DH]
+    T* Vs = Ks + MH_HEADS * ML_KB * MH_DH;     // bf16: [heads][KB][DH] (transposing reads); fp32: [heads][DH][KB]
+    const int T_ = c.T, bf = blockIdx.x;
+    const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const int t = (int)blockIdx.y * ML_KB + w * 16 + l15;
+    const bool tv = t < T_;
+    const size_t n = (size_t)bf * T_ + (tv ? t : 0);
+    const T* Kb = Kg + (size_t)bf * T_ * MH_H;
+    const T* Vb = Vg + (size_t)bf * T_ * MH_H;
+    const float qscale = 1.4426950408889634f * rsqrtf((float)MH_DH);
+
+    // ---- Q of this wave's strip, all heads, in registers -----------------------------------------
+    Frag<T> qf[MH_HEADS];
+    {
+        Frag<T> u[MH_KS];
+        {
+            float gam[MH_KS][8], bet[MH_KS][8];
+#pragma unroll
+            for (int ks = 0; ks < MH_KS; ++ks) {
+                load8(lnw + ks * 32 + 8 * g4, gam[ks]);
+                load8(lnb + ks * 32 + 8 * g4, bet[ks]);
+            }
+            ln_strip<T>(x + n * MH_H, tv, gam, bet, u);
+        }
+#pragma unroll
+        for (int head = 0; head < MH_HEADS; ++head) {
+            f32x4 ct[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < MH_KS; ++ks) {
+                    Frag<T> a;
+                    wfrag_load(a, Win, head * 2 + half, MH_KS, ks);
+                    acc = mma(a, u[ks], acc);
+                }
+                ct[half] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ct[0][r] = (ct[0][r] + bin[head * MH_DH + 4 * g4 + r]) * qscale;
+                ct[1][r] = g4 < 2 ? (ct[1][r] + bin[head * MH_DH + 16 + 4 * g4 + r]) * qscale : 0.f;
+            }
+            frag_from_c2(qf[head], ct[0], ct[1]);
+        }
+    }
+
+    // ---- key blocks ---------------------------------------------------------------------------------
+    constexpr int VN = 16 / sizeof(T), RV = MH_H / VN, NVB = ML_KB * RV / 512;  // 16-byte vectors: per row, per thread
+    u32x4 kreg[NVB], vreg[NVB];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + i * 512, row = v / RV, e = (v % RV) * VN;
+            const int tk = kb * ML_KB + row, tc = tk < T_ ? tk : T_ - 1;  // clamped address, zero rows past the sequence
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)tc * MH_H + e);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)tc * MH_H + e);
+            const uint32_t keep = tk < T_ ? 0xffffffffu : 0u;
+            kreg[i] = (u32x4){kv[0] & keep, kv[1] & keep, kv[2] & keep, kv[3] & keep};
+            vreg[i] = (u32x4){vv[0] & keep, vv[1] & keep, vv[2] & keep, vv[3] & keep};
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int v = tid + i * 512, row = v / RV, e = (v % RV) * VN, hh = e / MH_DH, d = e % MH_DH;
+            *reinterpret_cast<u32x4*>(Ks + ((size_t)hh * ML_KB + row) * MH_DH + d) = kreg[i];
+            if (sizeof(T) == 2) {
+                *reinterpret_cast<u32x4*>(Vs + ((size_t)hh * ML_KB + row) * MH_DH + d) = vreg[i];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) reinterpret_cast<uint32_t*>(Vs)[((size_t)hh * MH_DH + d + q) * ML_KB + row] = vreg[i][q];
+            }
+        }
+    };
+
+    float mrun[MH_HEADS], lrun[MH_HEADS];
+    f32x4 o0[MH_HEADS], o1[MH_HEADS];
+#pragma unroll
+    for (int hh = 0; hh < MH_HEADS; ++hh) {
+        mrun[hh] = -1e30f;
+        lrun[hh] = 0.f;
+        o0[hh] = o1[hh] = F32X4_ZERO;
+    }
+    const int nkb = cdiv(T_, ML_KB);
+    gload(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        lds_barrier();  // the previous block's readers are done
+        sstore();
+        lds_barrier();
+        if (kb + 1 < nkb) gload(kb + 1);
+        const bool lastb = kb == nkb - 1;
+#pragma unroll
+        for (int hh = 0; hh < MH_HEADS; ++hh) {
+            const T* kh = Ks + (size_t)hh * ML_KB * MH_DH;
+            f32x4 sc[ML_KB / 16];
+            float mx = -1e30f;
+#pragma unroll
+            for (int j = 0; j < ML_KB / 16; ++j) {
+                Frag<T> a;
+                const T* kr = kh + (size_t)(j * 16 + l15) * MH_DH;
+                frag_load_lo(a, kr + 4 * g4);
+                if (g4 < 2) frag_load_hi(a, kr + 16 + 4 * g4);
+                else frag_zero_hi(a);
+                sc[j] = mma(a, qf[hh], F32X4_ZERO);
+                if (lastb) {  // only the last block can hold keys past the sequence
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * ML_KB + j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[j][r]);
+            }
+            mx = fmaxf(wave_max16(mx), mrun[hh]);
+            const float alpha = fast_exp2(mrun[hh] - mx);
+            mrun[hh] = mx;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < ML_KB / 16; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(sc[j][r] - mx);
+                    sc[j][r] = p;
+                    sum += p;
+                }
+            lrun[hh] = lrun[hh] * alpha + wave_sum16(sum);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o0[hh][r] *= alpha;
+                o1[hh][r] *= alpha;
+            }
+#pragma unroll
+            for (int ks = 0; ks < ML_KB / 32; ++ks) {
+                Frag<T> pf, a0, a1;
+                frag_from_c2(pf, sc[2 * ks], sc[2 * ks + 1]);
+                if (sizeof(T) == 2) {
+                    const T* vh = Vs + (size_t)hh * ML_KB * MH_DH;
+                    v_frag_tr(a0, vh, 0, ks);
+                    v_frag_tr(a1, vh, 1, ks);  // rows d >= 24 pick up neighbouring data; those output rows are dropped below
+                } else {
+                    const T* vh = Vs + (size_t)hh * MH_DH * ML_KB;
+                    const T* v0 = vh + (size_t)l15 * ML_KB + ks * 32 + 4 * g4;
+                    frag_load_lo(a0, v0);
+                    frag_load_hi(a0, v0 + 16);
+                    if (l15 < MH_DH - 16) {
+                        const T* v1 = vh + (size_t)(16 + l15) * ML_KB + ks * 32 + 4 * g4;
+                        frag_load_lo(a1, v1);
+                        frag_load_hi(a1, v1 + 16);
+                    } else {
+                        frag_zero(a1);
+                    }
+                }
+                o0[hh] = mma(a0, pf, o0[hh]);
+                o1[hh] = mma(a1, pf, o1[hh]);
+            }
+        }
+    }
+
+    // ---- normalise, out_proj + bias + residual -------------------------------------------------------
+    Frag<T> of[MH_HEADS];
+#pragma unroll
+    for (int hh = 0; hh < MH_HEADS; ++hh) {
+        const float inv = 1.0f / lrun[hh];
+        f32x4 a = o0[hh], b = o1[hh];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] *= inv;
+            b[r] = g4 < 2 ? b[r] * inv : 0.f;  // output rows d = 16 + 4 g4 + r >= dh are padding
+        }
+        frag_from_c2(of[hh], a, b);
+    }
+    const T* xr = x + n * MH_H;
+    T* yr = y + n * MH_H;
+#pragma unroll
+    for (int mt = 0; mt < MH_H / 16; ++mt) {
+        const int ch = 16 * mt + 4 * g4;
+        f32x4 acc = F32X4_ZERO;
+#pragma unroll
+        for (int hh = 0; hh < MH_HEADS; ++hh) {
+            Frag<T> a;
+            wfrag_load(a, Wout, mt, MH_HEADS, hh);
+            acc = mma(a, of[hh], acc);
+        }
+        if (tv) {
+            float rv[4];
+            load4(xr + ch, rv);
+            store4(yr + ch, rv[0] + bout[ch] + acc[0], rv[1] + bout[ch + 1] + acc[1], rv[2] + bout[ch + 2] + acc[2], rv[3] + bout[ch + 3] + acc[3]);
+        }
+    }
+}
+
+template <class T>
+static int mhsa_fwd_long_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* scratch, hipStream_t st) {
+    if (!scratch) return NBSS_EINVAL;  // K | V, nbss_mhsa_save_bytes() bytes
+    const size_t N = (size_t)c.B * c.F * c.T;
+    T* Kg = (T*)scratch;
+    T* Vg = (T*)((char*)scratch + ws_align(N * MH_H * sizeof(T)));
+    const size_t lds = (size_t)2 * MH_HEADS * ML_KB * MH_DH * sizeof(T) + 64;
+    const T* pk = (const T*)packed;
+    int e = NBSS_SET_MAX_LDS((mhsa_flash_kernel<T>), lds);
+    if (e) return e;
+    dim3 grid(c.B * c.F, cdiv(c.T, ML_KB)), block(512);
+    ProfScope ps(PK_MHSA_F, st);
+    const float* lnw = P + param_off(c, layer, P_MH_LN_W);
+    const float* lnb = P + param_off(c, layer, P_MH_LN_B);
+    const float* bin = P + param_off(c, layer, P_INP_B);
+    NBSS_LAUNCH((mhsa_kv_kernel<T>), grid, block, 0, st, c, lnw, lnb, bin, pk + pack_off(c, layer, K_INP), (const T*)x, Kg, Vg);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH((mhsa_flash_kernel<T>), grid, block, lds, st, c, lnw, lnb, bin, P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
+                pk + pack_off(c, layer, K_OUTP), (const T*)x, (const T*)Kg, (const T*)Vg, (T*)y);
+    return NBSS_CHECK_LAUNCH();
+}
+
 int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
+    // T > 256: `osave` is the K | V scratch of the two-launch long-sequence path (nothing is saved for backward)
+    if (c.T > MH_TP) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float>(c, P, packed, layer, x, y, osave, st);
     if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false, 2>(c, P, packed, layer, x, y, osave, st);
     return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<bf16_t, 4, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st);
 }

@@ -173,7 +173,12 @@ NBSS_DEV void store_rows(T* __restrict__ h, int t, bool valid, const f32x4& lo, 
 }
 
 // NSW = 16-frame strips per wave: 2 with 8 waves (fp32), 1 with 16 waves (bf16: 4 waves per SIMD to hide the LDS / MFMA chains)
-template <class T, int NSW>
+//
+// LONG (sequences beyond TP frames, forward only): the sequence is walked in chunks of TP - 6 frames with a 3-frame halo on
+// either side (three k=3 convolutions), twice: pass 0 runs every chunk up to conv2 and accumulates the GroupNorm sums of
+// the 8 groups in LDS, pass 1 recomputes the chain with the sequence-wide statistics and writes y.  Exact (no windowing
+// approximation), any T, at twice the W1/conv1/conv2 work.
+template <class T, int NSW, bool LONG>
 __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tconvffn_fwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, int layer, const T* __restrict__ W1,
                                                            const T* __restrict__ Wc1, const T* __restrict__ Wc2, const T* __restrict__ Wc3,
                                                            const T* __restrict__ W2, const T* __restrict__ x, T* __restrict__ y) {
@@ -205,6 +210,10 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
     const float* gnb = prm + 5 * TF_FFN;
     const float* b2_g = lp.p[P_TF_B2];
     const float* b2 = prm + 6 * TF_FFN;
+    float* gstat = prm + 7 * TF_FFN;  // LONG: [G][2] sequence-wide GroupNorm sums
+    constexpr int HALO = LONG ? 3 : 0, CH = TF_TP - 2 * HALO;
+    const int nck = LONG ? cdiv(T_, CH) : 1;
+    if (LONG && tid < 2 * TF_G) gstat[tid] = 0.f;
 
     for (int i = tid; i < TF_FFN; i += blockDim.x) {
         prm[i] = b1_g[i]; prm[TF_FFN + i] = cb1_g[i]; prm[2 * TF_FFN + i] = cb2_g[i]; prm[3 * TF_FFN + i] = cb3_g[i];
@@ -219,6 +228,21 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
         store1(hb + (size_t)(TF_TP + 1) * TF_CG + tid, 0.f);
     }
 
+    const int d0 = 4 * g4, d1 = 16 + 4 * g4;
+    const bool v1 = g4 < 2;  // second tile holds channels 16..23 only
+    for (int pass = LONG ? 0 : 1; pass < 2; ++pass)
+    for (int ck = 0; ck < nck; ++ck) {
+    const int t0 = ck * CH - HALO;  // sequence frame of buffer row 0
+    int tt[NSW];   // buffer row of the strip's frame
+    bool tv[NSW];  // the frame exists (rows outside the sequence hold zeros: the convolutions' zero padding)
+    bool tin[NSW]; // the frame is this chunk's to reduce / write (LONG: the halo rows belong to the neighbours)
+#pragma unroll
+    for (int si = 0; si < NSW; ++si) {
+        tt[si] = (w * NSW + si) * 16 + l15;
+        const int tg = t0 + tt[si];
+        tv[si] = tg >= 0 && tg < T_;
+        tin[si] = tv[si] && (!LONG || (tt[si] >= HALO && tt[si] < HALO + CH));
+    }
     Frag<T> u[NSW][TF_KS];
     {
         float gam[TF_KS][8], bet[TF_KS][8];
@@ -231,8 +255,7 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
             }
 #pragma unroll
         for (int si = 0; si < NSW; ++si) {
-            const int t = (w * NSW + si) * 16 + l15;
-            ln_strip_tf<T>(xb + (size_t)t * TF_H, t < T_, gam, bet, u[si]);
+            ln_strip_tf<T>(xb + (ptrdiff_t)(t0 + tt[si]) * TF_H, tv[si], gam, bet, u[si]);
         }
     }
     f32x4 yacc[NSW][TF_H / 16];
@@ -240,16 +263,6 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
     for (int si = 0; si < NSW; ++si)
 #pragma unroll
         for (int mt = 0; mt < TF_H / 16; ++mt) yacc[si][mt] = F32X4_ZERO;
-
-    int tt[NSW];
-    bool tv[NSW];
-#pragma unroll
-    for (int si = 0; si < NSW; ++si) {
-        tt[si] = (w * NSW + si) * 16 + l15;
-        tv[si] = tt[si] < T_;
-    }
-    const int d0 = 4 * g4, d1 = 16 + 4 * g4;
-    const bool v1 = g4 < 2;  // second tile holds channels 16..23 only
 
     constexpr int FVN = 16 / sizeof(T), FVPF = 512 / FVN, FNV2 = (6 * FVPF + NTHR - 1) / NTHR;  // W2: 6 strided fragments
     StageRegs<T, 4, NTHR> fw;
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
             for (int r = 0; r < 4; ++r) {
                 ct[si][0][r] = round_to(ct[si][0][r] + cb2[cbase + d0 + r], x);
                 ct[si][1][r] = v1 ? round_to(ct[si][1][r] + cb2[cbase + d1 + r], x) : 0.f;
-                if (tv[si]) {
+                if (tin[si]) {
                     s1 += ct[si][0][r] + ct[si][1][r];
                     s2 += ct[si][0][r] * ct[si][0][r] + ct[si][1][r] * ct[si][1][r];
                 }
@@ -350,6 +363,18 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
             ts1 += red[2 * i];
             ts2 += red[2 * i + 1];
         }
+        if (LONG) {
+            if (pass == 0) {
+                if (tid == 0) {
+                    gstat[2 * gr] += ts1;
+                    gstat[2 * gr + 1] += ts2;
+                }
+            } else {
+                ts1 = gstat[2 * gr];
+                ts2 = gstat[2 * gr + 1];
+            }
+        }
+        if (pass == 1) {
         const float cnt = (float)(TF_CG * T_);
         const float mean = ts1 / cnt;
         const float var = fmaxf(ts2 / cnt - mean * mean, 0.f);
@@ -383,23 +408,27 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 1 ? 4 : TF_FWD_WPS) void tcon
 #pragma unroll
             for (int si = 0; si < NSW; ++si) yacc[si][mt] = mma(a, h5[si], yacc[si][mt]);
         }
+        }  // pass 1
         if (DB && gr + 1 < TF_G) fwd_wstore(wl0 + (size_t)((gr + 1) & 1) * 30 * 512);  // last read two barriers ago
         lds_barrier();  // ha / hb / red are rewritten by the next group; the other weight buffer is complete
     }
 
+    if (pass == 1)
 #pragma unroll
     for (int si = 0; si < NSW; ++si) {
-        if (tv[si]) {
+        if (tin[si]) {
+            const size_t tg = (size_t)(t0 + tt[si]);
 #pragma unroll
             for (int mt = 0; mt < TF_H / 16; ++mt) {
                 const int ch = 16 * mt + 4 * g4;
                 float xv[4];
-                load4(xb + (size_t)tt[si] * TF_H + ch, xv);
-                store4(yb + (size_t)tt[si] * TF_H + ch, xv[0] + round_to(yacc[si][mt][0] + b2[ch], x), xv[1] + round_to(yacc[si][mt][1] + b2[ch + 1], x),
+                load4(xb + tg * TF_H + ch, xv);
+                store4(yb + tg * TF_H + ch, xv[0] + round_to(yacc[si][mt][0] + b2[ch], x), xv[1] + round_to(yacc[si][mt][1] + b2[ch + 1], x),
                        xv[2] + round_to(yacc[si][mt][2] + b2[ch + 2], x), xv[3] + round_to(yacc[si][mt][3] + b2[ch + 3], x));
             }
         }
     }
+    }  // chunks x passes
 }
 
 
@@ -1111,15 +1140,15 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T, int NSW>
+template <class T, int NSW, bool LONG>
 static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
-    if (c.T > TF_TP) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (32 + 7 * TF_FFN) * sizeof(float) + (size_t)(sizeof(T) == 2 ? 2 : 1) * 30 * 512 * sizeof(T);
+    if (!LONG && c.T > TF_TP) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)2 * (TF_TP + 2) * TF_CG * sizeof(T) + (32 + 7 * TF_FFN + 2 * TF_G) * sizeof(float) + (size_t)(sizeof(T) == 2 ? 2 : 1) * 30 * 512 * sizeof(T);
     const T* pk = (const T*)packed;
     dim3 grid(c.B * c.F), block(64 * 16 / NSW);
     ProfScope ps(PK_TCF_F, st);
-    NBSS_LAUNCH((tconvffn_fwd_kernel<T, NSW>), grid, block, lds, st, c, lp, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
+    NBSS_LAUNCH((tconvffn_fwd_kernel<T, NSW, LONG>), grid, block, lds, st, c, lp, P, layer, pk + pack_off(c, layer, K_TF_W1), pk + pack_off(c, layer, K_TF_C1),
                 pk + pack_off(c, layer, K_TF_C2), pk + pack_off(c, layer, K_TF_C3), pk + pack_off(c, layer, K_TF_W2), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
@@ -1128,5 +1157,7 @@ int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, i
 
 int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     // bf16 stream: the streaming wave-per-group kernel (tconvffn_s.hip); fp32 stream: the group-serial kernel above
-    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, nullptr, st) : tconvffn_fwd_t<float, 2>(c, P, packed, layer, x, y, st);
+    // sequences beyond 256 frames (forward only): the chunked two-pass variant of the group-serial kernel
+    if (c.T > TF_TP) return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t, 1, true>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float, 2, true>(c, P, packed, layer, x, y, st);
+    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, nullptr, st) : tconvffn_fwd_t<float, 2, false>(c, P, packed, layer, x, y, st);
 }

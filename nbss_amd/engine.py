@@ -68,6 +68,9 @@ class SpatialNetEngine:
 
     def ensure_geometry(self, B: int, T: int, train: bool, dtype: int) -> Cfg:
         cfg = self.cfg_for(B, T, dtype)
+        if train and T > 256:
+            raise NbssError(f"T={T}: sequences beyond 256 frames are forward-only (validate / test / predict); training keeps one whole "
+                            "sequence per workgroup in LDS — cut training segments to <= 256 frames (the reference trains on 4 s = 251)")
         key = (B, T, dtype, train)
         if self._geom != key:
             self.ws = ops.scratch(self.lib.nbss_train_ws_bytes(C.byref(cfg)), self.device)

@@ -101,3 +101,60 @@ def test_tconvffn(backend, dtype):
         want = ref.tconvffn(x64, cs.p64, "layers.0")
         assert rel_l2(y, want) < cs.tol
         assert rel_l2(y.double().cpu() - x64, want - x64) < 3 * cs.tol
+
+
+# ---- sequences beyond 256 frames (forward only: validate / test / predict on full-length utterances) ------------------------
+# emulator: one ragged chunk boundary each (tconvffn: 250-frame chunks; attention: 128-key blocks); gpu: T = 600 and 1001
+def long_shapes(backend):
+    return [(1, 1, 300), (1, 2, 257)] + ([(2, 129, 600), (1, 33, 1001)] if backend.name == "hip" else [])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mhsa_long(backend, dtype):
+    for (B, F, T) in long_shapes(backend):
+        cs = Case(backend, B, F, T, dtype)
+        x, x64 = cs.stream(seed=19)
+        scratch = ops.mhsa_save(cs.lib, cs.cfg, x.device)  # beyond 256 frames this buffer is the K | V scratch
+        y = ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=scratch)
+        want = ref.mhsa(x64, cs.p64, "layers.0")
+        assert rel_l2(y, want) < cs.tol
+        assert rel_l2(y.double().cpu() - x64, want - x64) < 3 * cs.tol
+        with pytest.raises(RuntimeError):  # no scratch: refused, not silently wrong
+            ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_tconvffn_long(backend, dtype):
+    for (B, F, T) in long_shapes(backend):
+        cs = Case(backend, B, F, T, dtype)
+        x, x64 = cs.stream(seed=20)
+        y = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
+        want = ref.tconvffn(x64, cs.p64, "layers.0")
+        assert rel_l2(y, want) < cs.tol
+        assert rel_l2(y.double().cpu() - x64, want - x64) < 3 * cs.tol
+
+
+def test_long_sequences_are_forward_only(backend):
+    cs = Case(backend, 1, 2, 300, NBSS_BF16)
+    x, _ = cs.stream(seed=21)
+    grads = torch.zeros_like(cs.flat)
+    with pytest.raises(RuntimeError):
+        ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, grads, cs.packed, 0, x, x, ops.workspace(cs.lib, cs.cfg, x.device))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_network_long(backend, dtype):
+    """whole network, inference, T beyond 256 through nbss_spatialnet_fwd (ping-pong buffers, attention scratch at the head of ws)"""
+    from nbss_amd.engine import SpatialNetEngine
+    from nbss_amd._lib import NbssError
+    B, F, T, L = (1, 129, 600, 8) if backend.name == "hip" else (1, 2, 270, 2)
+    p = ref.init_params(num_layers=L, num_freqs=F, dim_input=12, dim_output=4, seed=4)
+    eng = SpatialNetEngine(backend.lib, backend.device, dim_input=12, dim_output=4, num_freqs=F, num_layers=L, dtype=dtype)
+    eng.load_params(p)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, F, T, 12, generator=g).to(eng.stream_dtype())
+    y = eng.forward(x.to(backend.device), train=False)
+    want = ref.spatialnet(x.double(), {k: v.double() for k, v in p.items()}, L)
+    assert rel_l2(y, want) < (1e-4 if dtype == NBSS_F32 else 3e-2)
+    with pytest.raises(NbssError):
+        eng.forward(x.to(backend.device), train=True)
