@@ -108,7 +108,7 @@ class SpatialNetLayer(nn.Module):
             u = self.mhsa(u, rel_pos=attn_mask, incremental_state=state, chunkwise_recurrent=chunkwise_recurrent, rope=rope)
         else:  # frame-by-frame recurrence (what a streaming deployment computes)
             st: Dict[str, Any] = {}
-            u = torch.cat([self.mhsa(u[:, [i]], rel_pos=attn_mask[i], incremental_state=st, rope=rope) for i in range(T)], dim=1)
+            u = torch.cat([self.mhsa(u[:, i:i + 1], rel_pos=attn_mask[i], incremental_state=st, rope=rope) for i in range(T)], dim=1)
         return self.dropout_mhsa(u.reshape(B, Fq, T, H)), attn
 
     def _tconvffn(self, x: Tensor, state: Dict[int, Any] = None) -> Tensor:
@@ -243,7 +243,7 @@ class OnlineSpatialNet(nn.Module):
             if isinstance(layer.mhsa, MultiheadAttention):
                 u = self._mhsa_stream(layer.mhsa, u, ast)
             else:
-                u = torch.cat([layer.mhsa(u[:, [i]], rel_pos=self.pos(slen=t0 + i + 1, activate_recurrent=True), incremental_state=ast, rope=self.rope)
+                u = torch.cat([layer.mhsa(u[:, i:i + 1], rel_pos=self.pos(slen=t0 + i + 1, activate_recurrent=True), incremental_state=ast, rope=self.rope)
                                for i in range(C)], dim=1)
             h = h + u.reshape(B, Fq, C, -1)
             h = h + layer._tconvffn(h, state=conv)

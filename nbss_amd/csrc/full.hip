@@ -194,7 +194,9 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
 
     for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
     for (int i = tid; i < 2 * FL_H; i += nthr) aff[i] = 0.f;
+    PHASE_BEGIN(aff + 2 * FL_H);
     lds_barrier();
+    PHASE(0);
 
     // ---- p1: LN + squeeze ----
     {
@@ -225,7 +227,9 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
             }
         }
     }
+    PHASE(1);
     lds_barrier();
+    PHASE(2);
 
     // ---- p2: z = Wf s + bf ----
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -252,7 +256,9 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
             }
         }
     }
+    PHASE(3);
     lds_barrier();
+    PHASE(4);
 
     // ---- p3: recompute y_pre, dy_pre, dz = Wu^T dy_pre (dz overwrites s) ----
     {
@@ -305,7 +311,9 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
             }
         }
     }
+    PHASE(5);
     lds_barrier();
+    PHASE(6);
 
     // ---- p4: ds = Wf^T dz ; ds_pre = ds * SiLU'(s_pre)  (ds_pre overwrites z) ----
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -335,7 +343,9 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
             }
         }
     }
+    PHASE(7);
     lds_barrier();
+    PHASE(8);
 
     // ---- p5: du = Ws^T ds_pre, LayerNorm backward + residual ----
     {
@@ -368,16 +378,20 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
         }
         ln_affine_flush(dlw, dlb, aff, aff + FL_H);
     }
+    PHASE(9);
     lds_barrier();
+    PHASE(10);
     for (int i = tid; i < 2 * FL_H; i += nthr) part[(size_t)blockIdx.x * 2 * FL_H + i] = aff[i];
+    PHASE_END();
 }
+PHASE_READER(nbss_phase_read_full_bwd)
 
 template <class T>
 static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                       float* stats, void* const* o, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + 2 * FL_H * sizeof(float);
+    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + 2 * FL_H * sizeof(float) + PHASE_LDS_BYTES;
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T>), lds);
     if (e) return e;

@@ -537,8 +537,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     bf16_t* Bi = A + a_el;                                  // [NT][TB_RS]  a3hat   (first: dh5 = W2^T dy of the strip phase)
     float* red = reinterpret_cast<float*>(Bi + (size_t)NT * TB_RS);  // [4 groups][2 halves][2]
     float* gnp = red + 16;                                   // [2 halves][2 kinds][96] GroupNorm affine partial sums
+    bf16_t* mbox = reinterpret_cast<bf16_t*>(gnp + 4 * 96);  // [8 waves][24]: the frame across the middle, private copy (backward convs)
     bf16_t* wl = A;
-    PHASE_BEGIN(gnp + 4 * 96);
+    PHASE_BEGIN(mbox + 8 * TS_CG);
     const TsLane L;
     const int w = wave_id_u(), tid = threadIdx.x;
     const int row = blockIdx.x >> 1, gh = blockIdx.x & 1;
@@ -666,6 +667,20 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     const size_t gbase = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;
     auto rowp = [&](int tt, int bl, int bu) -> const bf16_t* { return Sc + (size_t)((tt < TS ? bl : bu) + tt) * TB_RS; };
     auto orow = [&](int tt, int bl, int bu) -> bf16_t* { return Sc + (size_t)((th ? bu : bl) + tt) * TB_RS + 4 * L.h; };
+    // Backward convs: the halves shift TOWARDS each other, so the one row a wave reads across the middle (frame TS for the lower half,
+    // TS - 1 for the upper) is overwritten by the other wave's second output row of the same stage.  Each wave therefore copies that
+    // row into its private mailbox right after the stage barrier; a second barrier separates the copies from the stage's writes.
+    bf16_t* mb = mbox + w * TS_CG;
+    auto fetch_cross = [&](int bl, int bu) {
+        const bf16_t* src = Sc + (size_t)(th ? bl + TS - 1 : bu + TS) * TB_RS;
+        if (L.lane < 6) *reinterpret_cast<u32x2*>(mb + 4 * L.lane) = *reinterpret_cast<const u32x2*>(src + 4 * L.lane);
+        lds_barrier();
+    };
+    auto rowx = [&](int tt, int bl, int bu) -> const bf16_t* {
+        const bool lower = tt < TS;
+        const bf16_t* r = Sc + (size_t)((lower ? bl : bu) + tt) * TB_RS;
+        return lower != (th == 0) ? mb : r;
+    };
     float gw[12], gb[12];
     chan_vec12(lp.p[P_TF_GN_W] + g * TS_CG, L.h, gw);
     chan_vec12(lp.p[P_TF_GN_B] + g * TS_CG, L.h, gb);
@@ -829,6 +844,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     lds_barrier();
     PHASE(11);
     // B3: conv3^T: da5 (1,7) -> dh4; dn3 = dh4 * dSiLU(n3) -> S (2,6); GroupNorm backward sums and affine gradients
+    fetch_cross(1, 7);
     {
         float sa = 0.f, sb = 0.f, dgw[12], dgb[12];
 #pragma unroll
@@ -840,7 +856,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
             for (int k = 0; k < TB_SB; ++k)
                 if (s0 + k < s_end) {
                     const int t = 32 * (s0 + k) + L.n;
-                    conv_bfrags3(L, rowp(t - 1, 1, 7), rowp(t, 1, 7), rowp(t + 1, 1, 7), b[k]);
+                    conv_bfrags3(L, rowx(t - 1, 1, 7), rowp(t, 1, 7), rowx(t + 1, 1, 7), b[k]);
                 }
 #pragma unroll
             for (int k = 0; k < TB_SB; ++k)
@@ -913,6 +929,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     lds_barrier();
     PHASE(15);
     // B2: conv2^T: da3 (2,6) -> dh2; da2 = dh2 * dSiLU(a2) (image A) -> S (3,5)
+    fetch_cross(2, 6);
 #pragma unroll 1
     TB_BLOCKS(false) {
         FragH b[TB_SB][5];
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
         for (int k = 0; k < TB_SB; ++k)
             if (s0 + k < s_end) {
                 const int t = 32 * (s0 + k) + L.n;
-                conv_bfrags3(L, rowp(t - 1, 2, 6), rowp(t, 2, 6), rowp(t + 1, 2, 6), b[k]);
+                conv_bfrags3(L, rowx(t - 1, 2, 6), rowp(t, 2, 6), rowx(t + 1, 2, 6), b[k]);
             }
 #pragma unroll
         for (int k = 0; k < TB_SB; ++k)
@@ -945,6 +962,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     lds_barrier();
     PHASE(17);
     // B1: conv1^T: da2 (3,5) -> dh1 -> S (4,4): the halves meet again, strip-contiguous
+    fetch_cross(3, 5);
 #pragma unroll 1
     TB_BLOCKS(false) {
         FragH b[TB_SB][5];
@@ -952,7 +970,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
         for (int k = 0; k < TB_SB; ++k)
             if (s0 + k < s_end) {
                 const int t = 32 * (s0 + k) + L.n;
-                conv_bfrags3(L, rowp(t - 1, 3, 5), rowp(t, 3, 5), rowp(t + 1, 3, 5), b[k]);
+                conv_bfrags3(L, rowx(t - 1, 3, 5), rowp(t, 3, 5), rowx(t + 1, 3, 5), b[k]);
             }
 #pragma unroll
         for (int k = 0; k < TB_SB; ++k)
@@ -1001,7 +1019,7 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     if (c.dtype != NBSS_BF16 || c.T > 256) return NBSS_EUNSUPPORTED;
     const size_t NT = (size_t)((c.T + 31) / 32) * 32;
     const size_t a_el = NT * TB_RS > (size_t)52 * 512 ? NT * TB_RS : (size_t)52 * 512;
-    const size_t lds = ((NT + TB_PAD) * TB_RS + a_el + NT * TB_RS) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + PHASE_LDS_BYTES;
+    const size_t lds = ((NT + TB_PAD) * TB_RS + a_el + NT * TB_RS) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + 8 * TS_CG * sizeof(bf16_t) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const bf16_t* pk = (const bf16_t*)packed;
     TsBwdW W = {pk + pack_off(c, layer, K_TS_W1),  pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1),  pk + pack_off(c, layer, K_TS_C2),

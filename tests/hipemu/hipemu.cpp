@@ -107,6 +107,9 @@ static int order_mode() {
         if (!e) return 0;
         if (!strcmp(e, "rev")) return 1;
         if (!strcmp(e, "rand")) return 2;
+        if (!strcmp(e, "wave")) return 3;      // greedy waves: a wave runs until every one of its fibers sits at a block barrier
+        if (!strcmp(e, "waverev")) return 4;   // (or has finished) before the next wave gets a turn: one wave is a whole barrier
+        if (!strcmp(e, "waverand")) return 5;  // interval ahead of the others, which exposes cross-wave LDS races between barriers
         return 0;
     }();
     return mode;
@@ -155,6 +158,41 @@ static void run_block(Worker& wk, dim3 bid, dim3 grid, dim3 bdim, size_t lds_byt
     if (mode == 1) std::reverse(order.begin(), order.end());
     std::mt19937 rng(1234 + bid.x * 7919 + bid.y * 104729);
     int remaining = nthreads;
+    if (mode >= 3) {
+        std::vector<int> worder(nwaves);
+        for (int i = 0; i < nwaves; ++i) worder[i] = i;
+        if (mode == 4) std::reverse(worder.begin(), worder.end());
+        while (remaining > 0) {
+            if (mode == 5) std::shuffle(worder.begin(), worder.end(), rng);
+            bool any = false;
+            for (int wv : worder) {
+                bool progress = true;
+                while (progress) {
+                    progress = false;
+                    const int hi = std::min(nthreads, (wv + 1) * 64);
+                    for (int idx = wv * 64; idx < hi; ++idx) {
+                        Fiber& f = blk.fibers[idx];
+                        if (f.done) continue;
+                        if (f.wait == 1 && blk.bar_gen == f.wait_gen) continue;
+                        if (f.wait == 2 && blk.waves[f.wave].gen == f.wait_gen) continue;
+                        f.wait = 0;
+                        progress = any = true;
+                        g_fiber = &f;
+                        hipemu_switch(&blk.sched_sp, f.sp);
+                        if (f.done) remaining--;
+                    }
+                }
+            }
+            if (!any) {
+                fprintf(stderr, "hipemu: DEADLOCK in block (%u,%u,%u): %d threads stuck (divergent barrier / collective?)\n", bid.x, bid.y,
+                        bid.z, remaining);
+                abort();
+            }
+        }
+        g_block = nullptr;
+        g_fiber = nullptr;
+        return;
+    }
     while (remaining > 0) {
         if (mode == 2) std::shuffle(order.begin(), order.end(), rng);
         bool progress = false;
