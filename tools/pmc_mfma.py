@@ -7,13 +7,16 @@ import csv, glob, json, os, sys
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 out = {"batch": B, "commit": os.environ.get("NBSS_COMMIT"), "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "kernels": {}}
+MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
 for k in ["fconv_fwd", "full_fwd", "mhsa_fwd", "tconvffn_fwd", "fconv_bwd", "full_bwd", "mhsa_bwd", "tconvffn_bwd"]:
-    vals = {}
+    vals, per = {}, {}
     for tag in ("SQ", "GRBM"):
         for f in glob.glob(f"gpurun_out/mfma/{k}_{tag}/**/*_counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if k in r["Kernel_Name"] and "wgrad" not in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
-                    vals[r["Counter_Name"]] = float(r["Counter_Value"])  # last launch wins
+                if any(m in r["Kernel_Name"] for m in MEMBERS.get(k, [k])) and "wgrad" not in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
+                    per[(r["Counter_Name"], r["Kernel_Name"])] = float(r["Counter_Value"])  # last launch of each member kernel wins
+    for (cn, _), v in per.items():
+        vals[cn] = vals.get(cn, 0.0) + v
     if "SQ_VALU_MFMA_BUSY_CYCLES" not in vals or "GRBM_GUI_ACTIVE" not in vals:
         continue
     simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8 * 1024

@@ -6,15 +6,17 @@ import csv, glob, json, os, sys
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = 129 * 251 * 96 * 2 * B
 out = {"batch": B, "commit": os.environ.get("NBSS_COMMIT"), "units": "bytes per launch", "correction": "2 * FETCH_SIZE KiB (gfx950 half-count) + WRITE_SIZE KiB", "kernels": {}}
+MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
+KERNELS = os.environ.get("NBSS_PMC_KERNELS", "fconv_fwd full_fwd mhsa_fwd tconvffn_fwd fconv_bwd full_bwd mhsa_bwd tconvffn_bwd").split()
 for k in ["fconv_fwd", "full_fwd", "mhsa_fwd", "tconvffn_fwd", "fconv_bwd", "full_bwd", "mhsa_bwd", "tconvffn_bwd"]:
     vals = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        v = []
+        v = {}  # kernel name -> counter of its last dispatch; a sub-block that is several kernels (tconvffn_bwd: K1 + du) is their sum
         for f in glob.glob(f"gpurun_out/traffic/{k}_{c}/**/*_counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] == c and k in r["Kernel_Name"] and "wgrad" not in r["Kernel_Name"]:
-                    v.append(float(r["Counter_Value"]))
-        vals[c] = v[-1] if v else None
+                if r["Counter_Name"] == c and any(m in r["Kernel_Name"] for m in MEMBERS.get(k, [k])) and "wgrad" not in r["Kernel_Name"]:
+                    v[r["Kernel_Name"]] = float(r["Counter_Value"])
+        vals[c] = sum(v.values()) if v else None
     if vals["FETCH_SIZE"] is None or vals["WRITE_SIZE"] is None:
         continue
     hbm = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024

@@ -3,7 +3,7 @@
 # domains other than --kernel-trace.  Output: gpurun_out/pmc_traffic.json   (see tools/pmc_traffic.py for the gfx950 corrections)
 B=${1:-8}
 cd /tmp && export TMPDIR=/tmp
-for K in fconv_fwd full_fwd mhsa_fwd tconvffn_fwd fconv_bwd full_bwd mhsa_bwd tconvffn_bwd; do
+for K in ${NBSS_PMC_KERNELS:-fconv_fwd full_fwd mhsa_fwd tconvffn_fwd fconv_bwd full_bwd mhsa_bwd tconvffn_bwd}; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/traffic/${K}_$C -- python $GRAFT_REPO_ROOT/tools/run_one.py $K $B 2 > /dev/null 2>&1
   done
