@@ -947,6 +947,7 @@ __global__ __launch_bounds__(1024) void tconvffn_du_kernel(nbss_cfg c, LayerPtrs
     NBSS_LDS(smem);
     T* wl = reinterpret_cast<T*>(smem);  // the 36 W1^T fragments, once per workgroup
     float* aff = reinterpret_cast<float*>(wl + 36 * 512);  // [2H] LN weight | bias gradient sums of this workgroup
+    float* lnl = aff + 2 * TF_H;                            // [H] LN weight (24 per-lane values: through LDS, the kernel sits at its 128-VGPR budget)
     const int T_ = c.T;
     const int bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(1024) void tconvffn_du_kernel(nbss_cfg c, LayerPtrs
         constexpr int NV = 36 * 512 * (int)sizeof(T) / 16;
         for (int v = tid; v < NV; v += 1024) reinterpret_cast<u32x4*>(wl)[v] = reinterpret_cast<const u32x4*>(W1tn)[v];
     }
-    for (int i = tid; i < 2 * TF_H; i += blockDim.x) aff[i] = 0.f;
+    for (int i = tid; i < 3 * TF_H; i += blockDim.x) aff[i] = i < 2 * TF_H ? 0.f : lnw[i - 2 * TF_H];
     // this wave's first strip: every global read issued before the barrier
     for (int s16 = w; s16 * 16 < T_ || s16 == w; s16 += 16) {
         const int tt = s16 * 16 + l15;
@@ -1014,15 +1015,18 @@ __global__ __launch_bounds__(1024) void tconvffn_du_kernel(nbss_cfg c, LayerPtrs
         }
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < TF_H / 16; ++mt)
+        for (int mt = 0; mt < TF_H / 16; ++mt) {
+            float gq4[4];
+            load4(lnl + 16 * mt + 4 * g4, gq4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xv[mt][r] *= rstd;  // \hat x
                 du[mt][r] = keep_if(tv, du[mt][r]);
-                const float gq = du[mt][r] * lnw[16 * mt + 4 * g4 + r];
+                const float gq = du[mt][r] * gq4[r];
                 m1 += gq;
                 m2 += gq * xv[mt][r];
             }
+        }
         m1 = wave_sum16(m1) * (1.0f / TF_H);
         m2 = wave_sum16(m2) * (1.0f / TF_H);
         if (tv) {
@@ -1030,9 +1034,10 @@ __global__ __launch_bounds__(1024) void tconvffn_du_kernel(nbss_cfg c, LayerPtrs
             for (int mt = 0; mt < TF_H / 16; ++mt) {
                 const float dd[4] = {bf2f((bf16_t)(dr[mt][0] & 0xFFFF)), bf2f((bf16_t)(dr[mt][0] >> 16)), bf2f((bf16_t)(dr[mt][1] & 0xFFFF)),
                                      bf2f((bf16_t)(dr[mt][1] >> 16))};
-                float o[4];
+                float o[4], gq4[4];
+                load4(lnl + 16 * mt + 4 * g4, gq4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = dd[r] + rstd * (du[mt][r] * lnw[16 * mt + 4 * g4 + r] - m1 - xv[mt][r] * m2);
+                for (int r = 0; r < 4; ++r) o[r] = dd[r] + rstd * (du[mt][r] * gq4[r] - m1 - xv[mt][r] * m2);
                 store4(dxb + (size_t)tt * TF_H + 16 * mt + 4 * g4, o[0], o[1], o[2], o[3]);
             }
         }
@@ -1063,7 +1068,7 @@ static int tconvffn_bwd_bf16(const nbss_cfg& c, const float* P, float* part, con
     if (e) return e;
     const bf16_t* pk = (const bf16_t*)packed;
     ProfScope ps(PK_TCF_B, st);
-    NBSS_LAUNCH((tconvffn_du_kernel<bf16_t>), dim3(c.B * c.F), dim3(1024), 36 * 512 * sizeof(bf16_t) + 2 * TF_H * sizeof(float), st, c, lp, part, pk + pack_off(c, layer, K_TF_W1_TN),
+    NBSS_LAUNCH((tconvffn_du_kernel<bf16_t>), dim3(c.B * c.F), dim3(1024), 36 * 512 * sizeof(bf16_t) + 3 * TF_H * sizeof(float), st, c, lp, part, pk + pack_off(c, layer, K_TF_W1_TN),
                 (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, stats, (const bf16_t*)opsv[4]);
     return NBSS_CHECK_LAUNCH();
 }

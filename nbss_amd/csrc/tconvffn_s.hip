@@ -693,12 +693,19 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     // dh5 of the wave's strips: out of image B into registers now (the image becomes a3hat in F2b), consumed in F3.  (Parking such rows in
     // the operand buffers instead costs a vmcnt(0) drain of the strip phase's stores: 16 % of the wave time when measured.)
     constexpr int TB_MAXS = 4;  // strips per wave (T <= 256)
-    P6 park[TB_MAXS];
-#pragma unroll
-    for (int k = 0; k < TB_MAXS; ++k) {
-        const int t = 32 * (s_beg + k) + L.n;
-        if (s_beg + k < s_end) p6_load(Bc + (size_t)t * TB_RS, park[k]);
-    }
+    // (named variables + per-dword selects in F3: `cond ? park[i] : park[j]` on the struct becomes a select of ADDRESSES, which put the
+    //  array into scratch memory — and scratch loads queue behind the operand stores like any other vector-memory access)
+    P6 park0, park1, park2, park3;
+    static_assert(TB_MAXS == 4, "park0..3");
+#define TB_PARK_LOAD(k, dst)                                                   \
+    if (s_beg + (k) < s_end) p6_load(Bc + (size_t)(32 * (s_beg + (k)) + L.n) * TB_RS, dst); \
+    else                                                                       \
+        for (int i_ = 0; i_ < 6; ++i_) dst.d[i_] = 0u;
+    TB_PARK_LOAD(0, park0)
+    TB_PARK_LOAD(1, park1)
+    TB_PARK_LOAD(2, park2)
+    TB_PARK_LOAD(3, park3)
+#undef TB_PARK_LOAD
 
 #define TB_BLOCKS(fwd_dir)                                                   \
     for (int bi_ = 0; bi_ < nblk; ++bi_)                                     \
@@ -812,7 +819,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
             if (s0 + k < s_end) {
                 const int t = 32 * (s0 + k) + L.n;
                 conv_bfrags3(L, rowp(t - 1, 2, 6), rowp(t, 2, 6), rowp(t + 1, 2, 6), b[k]);
-                p5[k] = (s0 + k - s_beg) == 0 ? park[0] : (s0 + k - s_beg) == 1 ? park[1] : (s0 + k - s_beg) == 2 ? park[2] : park[3];
+                const int pi = s0 + k - s_beg;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const uint32_t lo = pi == 0 ? park0.d[i] : park1.d[i], hi = pi == 2 ? park2.d[i] : park3.d[i];
+                    p5[k].d[i] = pi < 2 ? lo : hi;
+                }
             }
 #pragma unroll
         for (int k = 0; k < TB_SB; ++k)
