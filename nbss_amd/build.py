@@ -52,21 +52,22 @@ def hipcc_path() -> str:
     return p
 
 
-def build_hip(force: bool = False, verbose: bool = False, phase_prof: bool = False) -> Path:
+def build_hip(force: bool = False, verbose: bool = False, phase_prof: bool = False, flavour: str = "", defines=()) -> Path:
     """Compile every .hip for gfx950 and link libnbss_hip.so (no-op when up to date).
 
     phase_prof=True builds the diagnostic flavour lib/libnbss_hip_phase.so (-DNBSS_PHASE_PROF: in-kernel phase
     timers, csrc/prof.h) that only tools/phase_prof.py loads."""
     LIBDIR.mkdir(parents=True, exist_ok=True)
-    objdir = LIBDIR / ("obj_phase" if phase_prof else "obj")
+    if phase_prof:
+        flavour, defines = "phase", ["-DNBSS_PHASE_PROF", *defines]
+    objdir = LIBDIR / (f"obj_{flavour}" if flavour else "obj")
     objdir.mkdir(exist_ok=True)
     hipcc = hipcc_path()
     hdrs = _headers()
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
              "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-pass-failed"]
-    HIP_LIB = LIBDIR / ("libnbss_hip_phase.so" if phase_prof else "libnbss_hip.so")
-    if phase_prof:
-        flags.append("-DNBSS_PHASE_PROF")
+    HIP_LIB = LIBDIR / (f"libnbss_hip_{flavour}.so" if flavour else "libnbss_hip.so")
+    flags += list(defines)  # side-by-side experiment builds (NBSS_HIP_FLAVOUR=<name> selects one; tools only)
     jobs = []
     objs = []
     for s in _sources():
@@ -118,5 +119,7 @@ if __name__ == "__main__":
         print(build_hip(verbose=True))
     if which == "phase":
         print(build_hip(verbose=True, phase_prof=True))
+    if which == "flavour":  # python -m nbss_amd.build flavour <name> [-DFOO ...]
+        print(build_hip(verbose=True, force=True, flavour=sys.argv[2], defines=sys.argv[3:]))
     if which in ("emu", "all"):
         print(build_emu(verbose=True))

@@ -21,6 +21,7 @@
 #define FC_CG 12   // channels per group
 #define FC_KS 2    // 15 pieces of 4 channels -> 2 k-steps of 8 pieces
 #define FC_MTF_MAX 10
+#define FC_MTF_BIG 17  // F <= 272
 
 template <class T> struct VecOf;
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
@@ -55,8 +56,9 @@ NBSS_DEV void ln_row_inplace(T* row, const float* __restrict__ gamma, const floa
 }
 
 // GPW = conv groups per wave: 2 with 4 waves (fp32), 1 with 8 waves (bf16: two 8-wave workgroups per CU)
-template <class T, int TT, int GPW>
-__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? 4 : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+// MTF = frequency tiles the accumulators are sized for: 10 (F <= 160, the 8-kHz geometry) or 17 (F <= 272: 16 kHz, n_fft 512 -> 257 bins)
+template <class T, int TT, int GPW, int MTF>
+__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 ? 4 : 2) : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ cb, const float* __restrict__ slope,
                                                         const T* __restrict__ Wp, const T* __restrict__ x, T* __restrict__ y) {
     NBSS_LDS(smem);
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? 4 : 1) void fconv_fwd_k
     lds_barrier();
 
     // ---- phase 2: grouped conv on the matrix cores -----------------------------------------
-    f32x4 acc[GPW][TT][FC_MTF_MAX];
+    f32x4 acc[GPW][TT][MTF];
     Frag<T> a[GPW][FC_KS];
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? 4 : 1) void fconv_fwd_k
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-            for (int ft = 0; ft < FC_MTF_MAX; ++ft) acc[gi][tt][ft] = F32X4_ZERO;
+            for (int ft = 0; ft < MTF; ++ft) acc[gi][tt][ft] = F32X4_ZERO;
 #pragma unroll
-    for (int ft = 0; ft < FC_MTF_MAX; ++ft) {
+    for (int ft = 0; ft < MTF; ++ft) {
         if (ft < mtf) {
             const int f = ft * 16 + l15;
 #pragma unroll
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? 4 : 1) void fconv_fwd_k
 #pragma unroll
             for (int r = 0; r < 4; ++r) { bb[r] = cb[ch + r]; sl[r] = slope[ch + r]; }
 #pragma unroll
-            for (int ft = 0; ft < FC_MTF_MAX; ++ft) {
+            for (int ft = 0; ft < MTF; ++ft) {
                 const int f = ft * 16 + l15;
                 if (ft < mtf && f < F) {
 #pragma unroll
@@ -186,7 +188,6 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? 4 : 1) void fconv_fwd_k
 // dv (for the conv weight gradient, wgrad.hip) is copied out of LDS as full rows.  The first version (one frame per 4-wave
 // workgroup, weights through LDS, per-group 8-byte global accesses, a per-thread serial LayerNorm) ran at 0.38 TB/s.
 #define FC_LD 104  // LDS row length: 208-byte rows put 16 consecutive rows on distinct 16-byte bank slots
-#define FC_BW 8    // waves per workgroup = conv groups
 
 template <class T>
 NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int rstride, int f, int ch0, int ks) {
@@ -197,8 +198,10 @@ NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int rstride, int
     else frag_zero_hi(bq);
 }
 
-template <class T, int TT>
-__global__ __launch_bounds__(512, (sizeof(T) == 2 && TT == 1) ? 4 : 2)
+// NW = waves per workgroup: 8 (= the conv groups), or 9 when the row phases have a multiple of 9 units (F = 129: 9 frequency tiles x 2
+// frames = 18 units, which 8 waves take in 3 rounds with 6 of them idle in the last); the ninth wave sits out the group phases.
+template <class T, int TT, int NW>
+__global__ __launch_bounds__(64 * NW, 2)
 void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ cb,
                       const float* __restrict__ slope, float* __restrict__ part, const T* __restrict__ Wp, const T* __restrict__ WpT,
                       const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout) {
@@ -217,9 +220,10 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     Frag<T> af[FC_KS], at[FC_KS];
 #pragma unroll
     for (int ks = 0; ks < FC_KS; ++ks) {
-        wfrag_load(af[ks], Wp, w, FC_KS, ks);
-        wfrag_load(at[ks], WpT, w, FC_KS, ks);
+        wfrag_load(af[ks], Wp, w < FC_G ? w : 0, FC_KS, ks);
+        wfrag_load(at[ks], WpT, w < FC_G ? w : 0, FC_KS, ks);
     }
+    const bool gwave = NW == FC_G || w < FC_G;  // this wave owns a conv group in the group phases
     for (int i = tid; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
     for (int i = tid; i < 2 * FC_H; i += blockDim.x) lnp[i] = i < FC_H ? lnw[i] : lnb[i - FC_H];
     for (int i = tid; i < 4 * ROW; i += blockDim.x) {  // halo rows (f = -2, -1, 16 mtf, 16 mtf + 1) of both images
@@ -296,7 +300,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
         row_stats(xr, rmean, rrstd);
         row_fwd(w, xr, dr, rmean, rrstd);
     }
-    for (int ti = w + FC_BW; ti < ntile; ti += FC_BW) {
+    for (int ti = w + NW; ti < ntile; ti += NW) {
         Frag<T> xq[BK_KS], dq[BK_KS];
         float mean, rstd;
         row_load(ti, xq, dq);
@@ -309,13 +313,13 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
 
     // ---- phase 1 (groups): conv forward recompute, PReLU', dv in place of dy ----
     const int ch = w * FC_CG + 4 * g4;  // this lane's 4 channels of group w (g4 == 3: padding rows)
-    const bool cvalid = g4 < 3;
+    const bool cvalid = g4 < 3 && gwave;
     float cbv[4] = {0.f, 0.f, 0.f, 0.f}, slv[4] = {0.f, 0.f, 0.f, 0.f}, dsl[4] = {0.f, 0.f, 0.f, 0.f};
     if (cvalid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { cbv[r] = cb[ch + r]; slv[r] = slope[ch + r]; }
     }
-    for (int ti = 0; ti < ntile; ++ti) {
+    for (int ti = 0; ti < (gwave ? ntile : 0); ++ti) {
         const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15;
         f32x4 acc = F32X4_ZERO;
 #pragma unroll
@@ -347,7 +351,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     PHASE(3);
 
     // ---- phase 2 (groups): transposed conv -> du into the u image; dv rows -> global ----
-    for (int ti = 0; ti < ntile; ++ti) {
+    for (int ti = 0; ti < (gwave ? ntile : 0); ++ti) {
         const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15;
         f32x4 acc = F32X4_ZERO;
 #pragma unroll
@@ -417,7 +421,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
         }
     };
     if (w < ntile) row_bwd(w, xr, dr, rmean, rrstd);
-    for (int ti = w + FC_BW; ti < ntile; ti += FC_BW) {
+    for (int ti = w + NW; ti < ntile; ti += NW) {
         Frag<T> xq[BK_KS], dq[BK_KS];
         float mean, rstd;
         row_load(ti, xq, dq);
@@ -432,20 +436,20 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
 }
 PHASE_READER(nbss_phase_read_fconv_bwd)
 
-template <class T, int TT>
+template <class T, int TT, int NW>
 static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                        float* stats, void* dv, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
-    if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
+    if (mtf > FC_MTF_BIG) return NBSS_EUNSUPPORTED;
     const size_t lds = (size_t)2 * (mtf * 16 + 4) * TT * FC_LD * sizeof(T) + 5 * FC_H * sizeof(float) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T, TT>), lds);
+    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T, TT, NW>), lds);
     if (e) return e;
-    dim3 grid(c.B * cdiv(c.T, TT)), block(512);
+    dim3 grid(c.B * cdiv(c.T, TT)), block(64 * NW);
     ProfScope ps(PK_FCONV_B, st);
-    NBSS_LAUNCH((fconv_bwd_kernel<T, TT>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
+    NBSS_LAUNCH((fconv_bwd_kernel<T, TT, NW>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
                 P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), part, pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
                 pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv);
     return NBSS_CHECK_LAUNCH();
@@ -459,10 +463,20 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     float* stats = (float*)ws;
     void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-                                 : fconv_bwd_t<bf16_t, FC_BWD_TT>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
+#ifdef NBSS_FC_NW8
+    const bool nine = false;
+#else
+    const bool nine = (cdiv(c.F, 16) * FC_BWD_TT) % 9 == 0;
+#endif
+    // (F > 160, the 16-kHz geometry: the two images of a 2-frame slab no longer fit the LDS -> one frame per workgroup; the fp32 stream
+    //  images of even one frame are 229 KB at F = 257: fconv_bwd_t returns NBSS_EUNSUPPORTED there, fp32 TRAINING stops at F = 160)
+    const bool big = c.F > 16 * FC_MTF_MAX;
+    int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1, 8>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : big                ? fconv_bwd_t<bf16_t, 1, 8>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : nine               ? fconv_bwd_t<bf16_t, FC_BWD_TT, 9>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+                                 : fconv_bwd_t<bf16_t, FC_BWD_TT, 8>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
     if (e) return e;
-    const int nwg = c.dtype == NBSS_BF16 ? c.B * cdiv(c.T, FC_BWD_TT) : c.B * c.T;
+    const int nwg = c.dtype == NBSS_BF16 && !big ? c.B * cdiv(c.T, FC_BWD_TT) : c.B * c.T;
     AffSegs sg;
     sg.n = 3;
     sg.off[0] = param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); sg.cnt[0] = FC_H;
@@ -480,25 +494,28 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T, int TT, int GPW>
+template <class T, int TT, int GPW, int MTF>
 static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
-    if (mtf > FC_MTF_MAX) return NBSS_EUNSUPPORTED;
+    if (mtf > MTF) return NBSS_EUNSUPPORTED;
     const size_t lds = (size_t)(mtf * 16 + 4) * TT * FC_H * sizeof(T);
     const float* lnw = P + param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W);
     const float* lnb = P + param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B);
     const float* cb = P + param_off(c, layer, which ? P_FC2_B : P_FC1_B);
     const float* sl = P + param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU);
     const T* Wp = (const T*)packed + pack_off(c, layer, which ? K_FC2 : K_FC1);
-    int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT, GPW>), lds);
+    int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT, GPW, MTF>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, TT)), block(64 * FC_G / GPW);
     ProfScope ps(PK_FCONV_F, st);
-    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
+    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW, MTF>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 int fconv_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
-    if (c.dtype == NBSS_BF16) return fconv_fwd_t<bf16_t, 2, 1>(c, P, packed, layer, which, x, y, st);
-    return fconv_fwd_t<float, 1, 2>(c, P, packed, layer, which, x, y, st);
+    if (c.F > 16 * FC_MTF_MAX)  // 16-kHz geometry: one frame per workgroup, 17 frequency tiles
+        return c.dtype == NBSS_BF16 ? fconv_fwd_t<bf16_t, 1, 1, FC_MTF_BIG>(c, P, packed, layer, which, x, y, st)
+                                    : fconv_fwd_t<float, 1, 2, FC_MTF_BIG>(c, P, packed, layer, which, x, y, st);
+    if (c.dtype == NBSS_BF16) return fconv_fwd_t<bf16_t, 2, 1, FC_MTF_MAX>(c, P, packed, layer, which, x, y, st);
+    return fconv_fwd_t<float, 1, 2, FC_MTF_MAX>(c, P, packed, layer, which, x, y, st);
 }

@@ -20,10 +20,11 @@
 #define FL_TT 8
 #define FL_KS (FL_H / 32)
 #define FL_MT (FL_H / 16)
-#define FL_KSF_MAX 5  // ceil(160 / 32): layout.h check_cfg caps F at 160
+#define FL_KSF_MAX 5  // ceil(160 / 32): the 8-kHz geometry (F <= 160)
+#define FL_KSF_BIG 9  // ceil(272 / 32): 16 kHz (n_fft 512 -> F = 257)
 #define FL_THREADS 512  // 8 waves: one workgroup per CU (256 slabs), so the waves of a workgroup are all the latency hiding there is
 
-template <class T>
+template <class T, int KSFM>  // KSFM: LinearGroup k-steps the fragment arrays are sized for
 __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bs, const float* __restrict__ bfull,
                                                        const float* __restrict__ bu, const T* __restrict__ Wsq,
@@ -104,12 +105,12 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
     for (int task = w; task < FL_SQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
-        Frag<T> a[FL_KSF_MAX];  // all k-step fragments of the tile requested together (F <= 160: at most 5)
+        Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
 #pragma unroll
-        for (int ks = 0; ks < FL_KSF_MAX; ++ks)
+        for (int ks = 0; ks < KSFM; ++ks)
             if (ks < ksf) wfrag_load(a[ks], Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
 #pragma unroll
-        for (int ks = 0; ks < FL_KSF_MAX; ++ks) {
+        for (int ks = 0; ks < KSFM; ++ks) {
             if (ks < ksf) {
                 Frag<T> bq;
                 if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
 // The three weight gradients (squeeze, LinearGroup, unsqueeze) are contracted by wgrad.hip.
 #define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
 
-template <class T>
+template <class T, int KSFM>
 __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
@@ -235,12 +236,12 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     for (int task = w; task < FL_SQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
-        Frag<T> a[FL_KSF_MAX];  // all k-step fragments of the tile requested together (F <= 160: at most 5)
+        Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
 #pragma unroll
-        for (int ks = 0; ks < FL_KSF_MAX; ++ks)
+        for (int ks = 0; ks < KSFM; ++ks)
             if (ks < ksf) wfrag_load(a[ks], Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
 #pragma unroll
-        for (int ks = 0; ks < FL_KSF_MAX; ++ks) {
+        for (int ks = 0; ks < KSFM; ++ks) {
             if (ks < ksf) {
                 Frag<T> bq;
                 if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
@@ -319,12 +320,12 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     for (int task = w; task < FL_SQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
-        Frag<T> a[FL_KSF_MAX];  // all k-step fragments of the tile requested together (F <= 160: at most 5)
+        Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
 #pragma unroll
-        for (int ks = 0; ks < FL_KSF_MAX; ++ks)
+        for (int ks = 0; ks < KSFM; ++ks)
             if (ks < ksf) wfrag_load(a[ks], WfullT + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
 #pragma unroll
-        for (int ks = 0; ks < FL_KSF_MAX; ++ks) {
+        for (int ks = 0; ks < KSFM; ++ks) {
             if (ks < ksf) {
                 Frag<T> bq;
                 if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
@@ -386,18 +387,19 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
 }
 PHASE_READER(nbss_phase_read_full_bwd)
 
-template <class T>
+template <class T, int KSFM>
 static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                       float* stats, void* const* o, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
     const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + 2 * FL_H * sizeof(float) + PHASE_LDS_BYTES;
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T>), lds);
+    if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (fp32 stream at F = 257: 213 KB of squeezed images)
+    int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T, KSFM>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
     ProfScope ps(PK_FULL_B, st);
-    NBSS_LAUNCH((full_bwd_kernel<T>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
+    NBSS_LAUNCH((full_bwd_kernel<T, KSFM>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
                 pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
                 (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4]);
     return NBSS_CHECK_LAUNCH();
@@ -423,8 +425,12 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     int e = memset_async_impl(o[0], 2 * ws_align(BT * FL_SQ * FKP * esz), st);
     if (e) return e;
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
-                             : full_bwd_t<float>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
+    if (c.F > 32 * FL_KSF_MAX)
+        e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
+                                 : full_bwd_t<float, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
+    else
+        e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
+                                 : full_bwd_t<float, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
     if (e) return e;
     AffSegs sg;
     sg.n = 2;
@@ -454,22 +460,25 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T>
+template <class T, int KSFM>
 static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
     const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)mtf * 16 * FL_TT * FL_SQ) * sizeof(T);
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T>), lds);
+    if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T, KSFM>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
     ProfScope ps(PK_FULL_F, st);
-    NBSS_LAUNCH((full_fwd_kernel<T>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+    NBSS_LAUNCH((full_fwd_kernel<T, KSFM>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
                 pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 int full_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t>(c, P, packed, layer, x, y, st) : full_fwd_t<float>(c, P, packed, layer, x, y, st);
+    if (c.F > 32 * FL_KSF_MAX)
+        return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t, FL_KSF_BIG>(c, P, packed, layer, x, y, st) : full_fwd_t<float, FL_KSF_BIG>(c, P, packed, layer, x, y, st);
+    return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t, FL_KSF_MAX>(c, P, packed, layer, x, y, st) : full_fwd_t<float, FL_KSF_MAX>(c, P, packed, layer, x, y, st);
 }

@@ -208,6 +208,8 @@ NBSS_HD int64_t pack_total(const nbss_cfg& c) {
 NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // sequence lengths: backward keeps a whole sequence per workgroup (LDS), forward has chunked variants beyond that
 #define NBSS_T_TRAIN_MAX 256
+// frequencies: the cross-band kernels keep the whole F axis of a slab on chip: 17 tiles of 16 (n_fft 512 -> F = 257; fp32 backward: F <= 160)
+#define NBSS_F_MAX 272
 #define NBSS_T_MAX 4096
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
@@ -242,7 +244,7 @@ NBSS_HD int check_cfg(const nbss_cfg& c) {
     if (c.H != 96 || c.FFN != 192 || c.SQ != 8 || c.heads != 4) return NBSS_EUNSUPPORTED;
     if (c.f_groups != 8 || c.t_groups != 8 || c.f_ks != 5 || c.t_ks != 3 || c.enc_ks != 5) return NBSS_EUNSUPPORTED;
     if (c.C_in % 4 != 0 || c.C_in > 16 || c.C_out > 16 || c.C_out <= 0) return NBSS_EUNSUPPORTED;
-    if (c.F > 160 || c.T > NBSS_T_MAX) return NBSS_EUNSUPPORTED;
+    if (c.F > NBSS_F_MAX || c.T > NBSS_T_MAX) return NBSS_EUNSUPPORTED;
     if (c.full_share < 0 || c.full_share >= c.L) return NBSS_EINVAL;
     // operand offsets inside the widest tensor ([N][3H] dqkv) are 32-bit in the weight-gradient kernels
     if ((size_t)c.B * c.F * c.T * 3 * c.H >= ((size_t)1 << 31)) return NBSS_EUNSUPPORTED;

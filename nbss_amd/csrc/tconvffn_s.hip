@@ -740,6 +740,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
                 p6_gstore(ops.h2 + gbase + (size_t)t * TS_CG, ph, tv, true);
             }
     }
+    load_wfrags<5>(wa, W.C1T, g, L.lane);  // conv1 is done: its transposed weights arrive long before B1 needs them
     PHASE(4);
     lds_barrier();
     PHASE(5);
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
             red[(gl * 2 + th) * 2 + 1] = s2;
         }
     }
+    load_wfrags<5>(wb, W.C2T, g, L.lane);
     PHASE(6);
     lds_barrier();
     PHASE(7);
@@ -848,10 +850,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
                 p6_gstore(ops.da5 + gbase + (size_t)t * TS_CG, pd, tv, true);
             }
     }
-    // transposed conv weights replace the forward ones
-    load_wfrags<5>(wa, W.C1T, g, L.lane);
-    load_wfrags<5>(wb, W.C2T, g, L.lane);
-    load_wfrags<5>(wc, W.C3T, g, L.lane);
+    load_wfrags<5>(wc, W.C3T, g, L.lane);  // (behind F3's operand stores; a separate register set requested before F3 measured the same)
     PHASE(10);
     lds_barrier();
     PHASE(11);

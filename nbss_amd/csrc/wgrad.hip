@@ -44,12 +44,17 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
-    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
-    const int tpg = mtiles * ntiles;
+    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles_all = cdiv(nexp, 16);
     // blockIdx.y selects a group when the groups are too large to share a workgroup (LinearGroup); else all groups
     const bool per_group = gridDim.y > 1;
+    // blockIdx.z selects a range of output-column tiles when even one group has more tiles than a workgroup holds (LinearGroup at
+    // F = 257: 17 x 17); only dense per-group problems are launched that way (wgrad_launch_t)
+    const int ntz = cdiv(ntiles_all, (int)gridDim.z), nt0 = (int)blockIdx.z * ntz;
+    const int ntiles = ntiles_all - nt0 < ntz ? ntiles_all - nt0 : ntz;
+    const int tpg = mtiles * ntiles;
     const int g_lo = per_group ? blockIdx.y : 0, ngrp = per_group ? 1 : a.groups;
-    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng, ncolsB = ngrp * ng;
+    const int acols0 = g_lo * mg, ncolsA = ngrp * mg, bcols0 = g_lo * ng + nt0 * 16;
+    const int ncolsB = gridDim.z > 1 ? (ng - nt0 * 16 < ntiles * 16 ? ng - nt0 * 16 : ntiles * 16) : ngrp * ng;
     const int mgp = mtiles * 16, ngp = ntiles * 16;
     const int rowsA = ngrp * mgp, rowsB = ngrp * ngp;
     T* At = reinterpret_cast<T*>(smem);            // [rowsA][WG_LD]   row = g*mgp + m
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
     float bsum = 0.f;
-    const bool do_bias = a.dbias != nullptr;
+    const bool do_bias = a.dbias != nullptr && blockIdx.z == 0;
     const T* Ag = reinterpret_cast<const T*>(a.A);
     const T* Bg = reinterpret_cast<const T*>(a.B);
     const int pcA = ncolsA / CW, pcB = ncolsB / CW, center = a.taps / 2;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
         const int tl = s * WG_WAVES + w;
         if (tl < ntot) {
             const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
-            const int q = nt * 16 + l15;
+            const int q = (nt0 + nt) * 16 + l15;
             if (q < nexp) {
                 const int tap = q / ng, i = q % ng;
 #pragma unroll
@@ -519,12 +524,19 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     const int mtiles = cdiv(mg, 16), ntiles = cdiv(a.taps * ng, 16), tpg = mtiles * ntiles;
     const int cap = WG_WAVES * WG_TPW;
-    if (tpg > cap) return NBSS_EUNSUPPORTED;
+    // one group with more tiles than a workgroup holds (LinearGroup at F = 257: 17 x 17 > 112): ranges of output-column tiles on blockIdx.z
+    int nz = 1;
+    if (tpg > cap) {
+        if (a.taps != 1 || mtiles > cap) return NBSS_EUNSUPPORTED;
+        nz = cdiv(ntiles, cap / mtiles);
+        nz = cdiv(ntiles, cdiv(ntiles, nz));  // no empty range
+    }
+    const int ntz = cdiv(ntiles, nz);
     // all groups in one workgroup when their tiles and LDS images fit, else one group per blockIdx.y
     size_t lds_all = (size_t)a.groups * (mtiles + ntiles) * 16 * WG_LD * sizeof(T);
-    const bool all = a.groups * tpg <= cap && lds_all <= 80 * 1024 && mtiles * 16 * a.groups <= WG_THREADS;
+    const bool all = nz == 1 && a.groups * tpg <= cap && lds_all <= 80 * 1024 && mtiles * 16 * a.groups <= WG_THREADS;
     const int ybl = all ? 1 : a.groups;
-    const size_t lds = all ? lds_all : (size_t)(mtiles + ntiles) * 16 * WG_LD * sizeof(T);
+    const size_t lds = all ? lds_all : (size_t)(mtiles + ntz) * 16 * WG_LD * sizeof(T);
     if (lds > 160 * 1024 || mtiles * 16 > WG_THREADS) return NBSS_EUNSUPPORTED;
     // a staging block must not straddle a group: the per-group widths have to be multiples of the block width
     const bool cw8 = mg % 8 == 0 && ng % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && sizeof(T) == 2;
@@ -532,7 +544,7 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     const int ncA = all ? a.MA : mg, ncB = all ? a.NB : ng;
     // transposing-read kernels: whole rows are copied in 16-byte pieces (staged widths % 8) and tiles are addressed in
     // 4-channel pieces (group widths % 4, checked by the caller)
-    if (sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
+    if (nz == 1 && sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
         // 64-token chunks, one X image for all taps: dense problems, T-convs and (96-row chunks of 48 frequencies x 2 frames) F-convs
         const bool fmode3 = a.taps > 1 && a.shift_dim == 1 && a.shift_stride == a.T && a.Ntok % (a.F * a.T) == 0;
         const bool tmode3 = a.taps > 1 && a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0;
@@ -574,10 +586,10 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
         }
     }
     if (a.a_gw || a.b_gw) return NBSS_EUNSUPPORTED;
-    int xbl = 384 / ybl;  // 1-2 resident workgroups (8-16 waves) per CU; every x-block ends with one atomicAdd per output element
+    int xbl = 384 / (ybl * nz);  // 1-2 resident workgroups (8-16 waves) per CU; every x-block ends with one atomicAdd per output element
     if (xbl < 16) xbl = 16;
     if (xbl > nchunks) xbl = nchunks;
-    dim3 grid(xbl, ybl), block(WG_THREADS);
+    dim3 grid(xbl, ybl, nz), block(WG_THREADS);
     ProfScope ps(PK_WGRAD, st);
     int e;
     if (cw8) {

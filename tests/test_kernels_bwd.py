@@ -15,7 +15,14 @@ DTYPES = [pytest.param(NBSS_F32, id="f32"), pytest.param(NBSS_BF16, id="bf16")]
 SHAPES = [(1, 5, 19), (2, 33, 40)]
 
 
-MAX_SHAPES = [(1, 160, 3), (1, 2, 256)]  # the largest F and T check_cfg accepts (10 frequency tiles / 16 full strips)
+MAX_SHAPES = [(1, 160, 3), (1, 2, 256), (1, 130, 4)]  # the largest F and T check_cfg accepts (10 frequency tiles / 16 full strips); 9 frequency tiles (the 9-wave fconv_bwd)
+
+
+BIG_F_SHAPES = [(1, 257, 3), (1, 272, 2)]  # 16 kHz (n_fft 512 -> 257 bins), 17 frequency tiles: the cross-band kernels, bf16 stream (fp32 backward stops at F = 160)
+
+
+def big_f_shapes(backend, dtype):
+    return (BIG_F_SHAPES + ([(2, 257, 126)] if backend.name == "hip" else [])) if dtype == NBSS_BF16 else []
 
 
 def shapes_for(backend):
@@ -96,7 +103,7 @@ def test_mhsa_bwd(backend, dtype):
 def test_fconv_bwd(backend, dtype, which):
     pre = f"layers.0.fconv{which + 1}"
     names = [f"{pre}.0.weight", f"{pre}.0.bias", f"{pre}.1.weight", f"{pre}.1.bias", f"{pre}.2.weight"]
-    for (B, F, T) in shapes_for(backend):
+    for (B, F, T) in shapes_for(backend) + big_f_shapes(backend, dtype):
         run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.fconv(x, p, pre),
                       lambda cs, G, x, dy, ws: ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, which, x, dy, ws), names, seed=40 + which,
                       bf16_tol=8e-2)  # PReLU kink: bf16 rounding flips the sign of ~1% of the pre-activations
@@ -108,7 +115,7 @@ FULL_NAMES = ["layers.0.norm_full.weight", "layers.0.norm_full.bias", "layers.0.
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_full_bwd(backend, dtype):
-    for (B, F, T) in shapes_for(backend):
+    for (B, F, T) in shapes_for(backend) + big_f_shapes(backend, dtype):
         run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.full(x, p, "layers.0"),
                       lambda cs, G, x, dy, ws: ops.full_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws), FULL_NAMES, seed=50)
 
@@ -135,3 +142,17 @@ def test_encoder_decoder_bwd(backend, dtype):
         ops.encoder_bwd(cs.lib, cs.cfg, G, xin, dy)
         _, want_g = oracle_grads(lambda xx, pp: ref.encoder(xx, pp), xin64, cs.p64, dy64, ["encoder.weight", "encoder.bias"])
         check_param_grads(cs, G, want_g, tol)
+
+
+def test_fp32_backward_stops_at_160_frequencies(backend):
+    """the fp32-stream images of the cross-band backward kernels do not fit the LDS beyond F = 160: refused loudly, not computed wrongly"""
+    from nbss_amd._lib import NbssError
+    cs = Case(backend, 1, 257, 2, NBSS_F32)
+    x, _ = cs.stream(seed=1)
+    dy, _ = cs.stream(seed=2)
+    G = torch.zeros_like(cs.flat)
+    ws = ops.workspace(cs.lib, cs.cfg, backend.device)
+    with pytest.raises(NbssError, match="UNSUPPORTED"):
+        ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, 0, x, dy, ws)
+    with pytest.raises(NbssError, match="UNSUPPORTED"):
+        ops.full_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws)

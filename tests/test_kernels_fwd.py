@@ -14,7 +14,8 @@ DTYPES = [pytest.param(NBSS_F32, id="f32"), pytest.param(NBSS_BF16, id="bf16")]
 SHAPES = [(1, 5, 19), (2, 33, 40)]
 
 
-MAX_SHAPES = [(1, 160, 3), (1, 2, 256)]  # the largest F and T check_cfg accepts (10 frequency tiles / 16 full strips)
+MAX_SHAPES = [(1, 160, 3), (1, 2, 256)]  # the largest 8-kHz F (10 frequency tiles) and the longest training sequence (16 full strips)
+BIG_F_SHAPES = [(1, 257, 3), (1, 272, 2)]  # 16 kHz (n_fft 512 -> 257 bins) and the largest F check_cfg accepts (17 frequency tiles): cross-band kernels
 
 
 def shapes_for(backend):
@@ -48,7 +49,7 @@ def test_encoder_decoder(backend, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("which", [0, 1])
 def test_fconv(backend, dtype, which):
-    for (B, F, T) in shapes_for(backend):
+    for (B, F, T) in shapes_for(backend) + BIG_F_SHAPES + ([(2, 257, 126)] if backend.name == "hip" else []):
         cs = Case(backend, B, F, T, dtype)
         x, x64 = cs.stream(seed=7)
         y = ops.fconv_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, which, x)
@@ -59,7 +60,7 @@ def test_fconv(backend, dtype, which):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_full(backend, dtype):
-    for (B, F, T) in shapes_for(backend):
+    for (B, F, T) in shapes_for(backend) + BIG_F_SHAPES + ([(2, 257, 126)] if backend.name == "hip" else []):
         cs = Case(backend, B, F, T, dtype)
         x, x64 = cs.stream(seed=8)
         y = ops.full_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)

@@ -10,9 +10,9 @@ from oracle import spatialnet_ref as ref
 from util import rel_l2
 
 
-def make(backend, dtype, B, C, S, N, L, seed=0):
-    eng = SpatialNetEngine(backend.lib, backend.device, dim_input=2 * C, dim_output=2 * S, num_freqs=129, num_layers=L, dtype=dtype)
-    p = ref.init_params(num_layers=L, num_freqs=129, dim_input=2 * C, dim_output=2 * S, seed=seed)
+def make(backend, dtype, B, C, S, N, L, seed=0, num_freqs=129):
+    eng = SpatialNetEngine(backend.lib, backend.device, dim_input=2 * C, dim_output=2 * S, num_freqs=num_freqs, num_layers=L, dtype=dtype)
+    p = ref.init_params(num_layers=L, num_freqs=num_freqs, dim_input=2 * C, dim_output=2 * S, seed=seed)
     eng.load_params(p)
     g = torch.Generator().manual_seed(seed + 1)
     src = torch.randn(B, S, N, generator=g)
@@ -20,14 +20,14 @@ def make(backend, dtype, B, C, S, N, L, seed=0):
     return eng, p, mix, src
 
 
-def oracle_step(p, mix, src, L):
+def oracle_step(p, mix, src, L, n_fft=256):
     p64 = {}
     seen = {}
     for k, v in p.items():
         if id(v) not in seen:
             seen[id(v)] = v.double().clone().requires_grad_(True)
         p64[k] = seen[id(v)]
-    loss, yr_hat, out = io_ref.train_forward(mix.double(), src.double(), p64, L)
+    loss, yr_hat, out = io_ref.train_forward(mix.double(), src.double(), p64, L, n_fft=n_fft, hop=n_fft // 2)
     loss.backward()
     return loss.detach(), yr_hat.detach(), {k: v.grad for k, v in p64.items()}
 
@@ -76,3 +76,24 @@ def test_train_step_bf16_runs_and_learns(backend):
     losses = [l0] + [float(ts.step(x, yr)) for _ in range(3 if backend.name == "emu" else 10)]
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0]  # same batch repeatedly: the loss must go down
+
+
+def test_16khz_geometry(backend):
+    """n_fft 512 / hop 256 -> 257 frequencies (the reference's 16-kHz setting, configs/SpatialNet.yaml:25 `num_freqs: 129 / 257`):
+    fp32-stream forward (loss, separated signals) and one bf16-stream training step with every parameter gradient vs the fp64 oracle."""
+    B, C, S, N, L = (1, 2, 2, 1536, 1) if backend.name == "emu" else (2, 6, 2, 16000, 2)
+    eng, p, mix, src = make(backend, NBSS_F32, B, C, S, N, L, num_freqs=257)
+    ts = TrainStep(eng, n_fft=512)
+    x, yr = mix.to(backend.device), src.to(backend.device)
+    wl, wy, wg = oracle_step(p, mix, src, L, n_fft=512)
+    loss, yr_hat, _, _, _ = ts.forward_loss(x, yr, need_grad=False)
+    assert abs(float(loss) - float(wl)) < 1e-3 * max(1.0, abs(float(wl)))
+    assert rel_l2(yr_hat, wy) < 1e-3
+    eng, p, mix, src = make(backend, NBSS_BF16, B, C, S, N, L, num_freqs=257)
+    ts = TrainStep(eng, n_fft=512)
+    loss, yr_hat, dout, xin, _ = ts.forward_loss(x, yr)
+    eng.backward(xin, dout)
+    assert abs(float(loss) - float(wl)) < 0.05 * max(1.0, abs(float(wl)))
+    views = eng.param_views(eng.grads)
+    bad = [(k, rel_l2(views[k], g)) for k, g in wg.items() if rel_l2(views[k], g) > 0.12]  # bf16 stream, whole network (tests/test_e2e_headline.py)
+    assert not bad, bad

@@ -4,7 +4,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -ffast-math -fno-finite-math-only -Wno-unused-variable -Wno-unused-but-set-variable -Wno-pass-failed -S --cuda-device-only".split()
-for stem in sys.argv[1:]:
+for stem in [a for a in sys.argv[1:] if not a.startswith("-D")]:
     out = Path(tempfile.gettempdir()) / f"{stem}.s"
     subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *[a for a in sys.argv if a.startswith("-D")], "-o", str(out), str(ROOT / "nbss_amd" / "csrc" / f"{stem}.hip")], check=True, stderr=subprocess.DEVNULL)
     s = out.read_text()
