@@ -41,10 +41,11 @@ int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal
         int _e = check_cfg(*(cfg));            \
         if (_e != NBSS_OK) return _e;          \
     }
-/* backward (and a forward that saves state for it) keeps a whole sequence per workgroup: T <= NBSS_T_TRAIN_MAX */
+/* backward (and a forward that saves state for it) keeps a whole sequence per workgroup: T <= NBSS_T_TRAIN_MAX; the training kernels
+   are specialised for the SpatialNet-small geometry (the large one is served forward-only) */
 #define CHECK_CFG_TRAIN(cfg) \
     CHECK_CFG(cfg);          \
-    if ((cfg)->T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;
+    if ((cfg)->T > NBSS_T_TRAIN_MAX || (cfg)->H != 96) return NBSS_EUNSUPPORTED;
 #define CHECK_LAYER(cfg, layer) \
     if ((layer) < 0 || (layer) >= (cfg)->L) return NBSS_EINVAL;
 
@@ -200,7 +201,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     CHECK_CFG(cfg);
     if (!params || !packed || !xin || !out || (!acts && !ws)) return NBSS_EINVAL;
     const nbss_cfg& c = *cfg;
-    if (acts && c.T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;  // long sequences: inference only
+    if (acts && (c.T > NBSS_T_TRAIN_MAX || c.H != 96)) return NBSS_EUNSUPPORTED;  // long sequences, SpatialNet-large: inference only
     hipStream_t st = (hipStream_t)stream;
     const size_t sb = stream_bytes(c);
     // training: every block input is kept (acts = [5L+1 stream copies | L attention save buffers]);
@@ -212,7 +213,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     if (e) return e;
     for (int l = 0; l < c.L; ++l) {
         // (inference beyond 256 frames: the head of ws, idle without a backward pass, is the attention's K | V scratch)
-        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c)) : c.T > NBSS_T_TRAIN_MAX ? ws : nullptr;
+        void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c)) : (c.T > NBSS_T_TRAIN_MAX || c.H != 96) ? ws : nullptr;
         if ((e = fconv_fwd_impl(c, params, packed, l, 0, buf(k), buf(k + 1), st))) return e;
         if ((e = full_fwd_impl(c, params, packed, l, buf(k + 1), buf(k + 2), st))) return e;
         if ((e = fconv_fwd_impl(c, params, packed, l, 1, buf(k + 2), buf(k + 3), st))) return e;

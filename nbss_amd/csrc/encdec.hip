@@ -8,17 +8,18 @@
 #include "layout.h"
 #include "wgrad.h"
 #include "prof.h"
+#include "geom.h"
 
-#define ENC_H 96
+#define ENC_H 96  // backward (training) kernels: SpatialNet-small
 
-template <class T>
+template <class T, int H>  // H = dim_hidden (geom.h)
 __global__ __launch_bounds__(256) void encoder_fwd_kernel(nbss_cfg c, const float* __restrict__ P, const T* __restrict__ Wp,
                                                           const T* __restrict__ xin, T* __restrict__ y) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
     const int T_ = c.T, Cin = c.C_in, pc = Cin / 4, np = c.enc_ks * pc, half = c.enc_ks / 2;
     const int nst = cdiv(T_, 16);
     const int nstrips = c.B * c.F * nst;
-    constexpr int MT = ENC_H / 16;
+    constexpr int MT = H / 16;
     const int KS = cdiv(np, 8);  // <= 3 for C_in <= 16 (checked by host)
     const float* bias = P + param_off_enc_b(c);
     const int wpb = blockDim.x >> 6;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(nbss_cfg c, const floa
         }
         const int t = t0 + l15;
         if (t < T_) {
-            T* yr = y + ((size_t)bf * T_ + t) * ENC_H;
+            T* yr = y + ((size_t)bf * T_ + t) * H;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int ch = 16 * i + 4 * g4;
@@ -59,14 +60,14 @@ __global__ __launch_bounds__(256) void encoder_fwd_kernel(nbss_cfg c, const floa
     }
 }
 
-template <class T>
+template <class T, int H>
 __global__ __launch_bounds__(256) void decoder_fwd_kernel(nbss_cfg c, const float* __restrict__ bias, const T* __restrict__ Wp,
                                                           const T* __restrict__ x, float* __restrict__ out) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
     const int T_ = c.T, Co = c.C_out;
     const int nst = cdiv(T_, 16);
     const int nstrips = c.B * c.F * nst;
-    constexpr int KS = ENC_H / 32;
+    constexpr int KS = H / 32;
     Frag<T> a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wfrag_load(a[ks], Wp, 0, KS, ks);
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(nbss_cfg c, const floa
     for (int s = blockIdx.x * wpb + wave_id(); s < nstrips; s += gridDim.x * wpb) {
         const int bf = s / nst, t = (s % nst) * 16 + l15;
         f32x4 acc = F32X4_ZERO;
-        const T* xr = x + ((size_t)bf * T_ + t) * ENC_H;
+        const T* xr = x + ((size_t)bf * T_ + t) * H;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             Frag<T> b;
@@ -93,28 +94,30 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(nbss_cfg c, const floa
     }
 }
 
-template <class T>
+template <class T, int H>
 static int encoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, const void* xin, void* y, hipStream_t st) {
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
     ProfScope ps(PK_ENC_F, st);
-    NBSS_LAUNCH((encoder_fwd_kernel<T>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_ENC), (const T*)xin, (T*)y);
+    NBSS_LAUNCH((encoder_fwd_kernel<T, H>), grid, block, 0, st, c, P, (const T*)packed + pack_off(c, 0, K_ENC), (const T*)xin, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
-template <class T>
+template <class T, int H>
 static int decoder_fwd_t(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st) {
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
     ProfScope ps(PK_DEC_F, st);
-    NBSS_LAUNCH((decoder_fwd_kernel<T>), grid, block, 0, st, c, P + param_off_dec_b(c), (const T*)packed + pack_off(c, 0, K_DEC), (const T*)x, out);
+    NBSS_LAUNCH((decoder_fwd_kernel<T, H>), grid, block, 0, st, c, P + param_off_dec_b(c), (const T*)packed + pack_off(c, 0, K_DEC), (const T*)x, out);
     return NBSS_CHECK_LAUNCH();
 }
 
 int encoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* xin, void* y, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? encoder_fwd_t<bf16_t>(c, P, packed, xin, y, st) : encoder_fwd_t<float>(c, P, packed, xin, y, st);
+    if (c.H == GeoL::H) return c.dtype == NBSS_BF16 ? encoder_fwd_t<bf16_t, GeoL::H>(c, P, packed, xin, y, st) : encoder_fwd_t<float, GeoL::H>(c, P, packed, xin, y, st);
+    return c.dtype == NBSS_BF16 ? encoder_fwd_t<bf16_t, GeoS::H>(c, P, packed, xin, y, st) : encoder_fwd_t<float, GeoS::H>(c, P, packed, xin, y, st);
 }
 int decoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st) {
-    return c.dtype == NBSS_BF16 ? decoder_fwd_t<bf16_t>(c, P, packed, x, out, st) : decoder_fwd_t<float>(c, P, packed, x, out, st);
+    if (c.H == GeoL::H) return c.dtype == NBSS_BF16 ? decoder_fwd_t<bf16_t, GeoL::H>(c, P, packed, x, out, st) : decoder_fwd_t<float, GeoL::H>(c, P, packed, x, out, st);
+    return c.dtype == NBSS_BF16 ? decoder_fwd_t<bf16_t, GeoS::H>(c, P, packed, x, out, st) : decoder_fwd_t<float, GeoS::H>(c, P, packed, x, out, st);
 }
 
 // ---- backward -------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "geom.h"
 #include <cstdlib>
 
 #define FC_H 96
@@ -33,41 +34,46 @@ NBSS_DEV void vec_zero(bf16_t* d) { *reinterpret_cast<u32x4*>(d) = (u32x4){0, 0,
 NBSS_DEV void vec_zero(float* d) { *reinterpret_cast<f32x4*>(d) = (f32x4){0, 0, 0, 0}; }
 
 // LayerNorm over H=96 of one LDS-resident row, in place (fp32 statistics, eps 1e-5).
-template <class T>
+template <class T, int HL>
 NBSS_DEV void ln_row_inplace(T* row, const float* __restrict__ gamma, const float* __restrict__ beta) {
     float s = 0.f;
-    float v[FC_H];
+    float v[HL];
 #pragma unroll
-    for (int i = 0; i < FC_H; i += 8) load8(row + i, v + i);
+    for (int i = 0; i < HL; i += 8) load8(row + i, v + i);
 #pragma unroll
-    for (int i = 0; i < FC_H; ++i) s += v[i];
-    const float mean = s * (1.0f / FC_H);
+    for (int i = 0; i < HL; ++i) s += v[i];
+    const float mean = s * (1.0f / HL);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < FC_H; ++i) {
+    for (int i = 0; i < HL; ++i) {
         const float d = v[i] - mean;
         q += d * d;
     }
-    const float rstd = rsqrtf(q * (1.0f / FC_H) + 1e-5f);
+    const float rstd = rsqrtf(q * (1.0f / HL) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < FC_H; i += 4)
+    for (int i = 0; i < HL; i += 4)
         store4(row + i, (v[i] - mean) * rstd * gamma[i] + beta[i], (v[i + 1] - mean) * rstd * gamma[i + 1] + beta[i + 1],
                (v[i + 2] - mean) * rstd * gamma[i + 2] + beta[i + 2], (v[i + 3] - mean) * rstd * gamma[i + 3] + beta[i + 3]);
 }
 
 // GPW = conv groups per wave: 2 with 4 waves (fp32), 1 with 8 waves (bf16: two 8-wave workgroups per CU)
 // MTF = frequency tiles the accumulators are sized for: 10 (F <= 160, the 8-kHz geometry) or 17 (F <= 272: 16 kHz, n_fft 512 -> 257 bins)
-template <class T, int TT, int GPW, int MTF>
-__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 ? 4 : 2) : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+// HH = dim_hidden (geom.h): 96 (12 channels per conv group, one 16-row output tile) or 192 (24 channels, two tiles)
+template <class T, int TT, int GPW, int MTF, int HH>
+__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 ? 4 : 2) : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ cb, const float* __restrict__ slope,
                                                         const T* __restrict__ Wp, const T* __restrict__ x, T* __restrict__ y) {
+    constexpr int FG = HH / FC_G;                 // channels per group
+    constexpr int MTG = (FG + 15) / 16;           // output tiles per group
+    constexpr int NP = 5 * (FG / 4);              // im2col pieces of 4 channels: (tap, channel quad)
+    constexpr int KSG = (NP + 7) / 8;             // k-steps
     NBSS_LDS(smem);
     T* u = reinterpret_cast<T*>(smem);
     const int F = c.F, T_ = c.T;
     const int ntt = cdiv(T_, TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
     const int mtf = cdiv(F, 16), FP = mtf * 16 + 4;
-    constexpr int ROW = TT * FC_H;           // elements per frequency row in LDS
+    constexpr int ROW = TT * HH;             // elements per frequency row in LDS
     constexpr int VN = VecOf<T>::N;
     constexpr int VPR = ROW / VN;            // vectors per frequency row
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -75,51 +81,57 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 ? 4 : 2) : 1
 
     // ---- phase 1: stage x (raw) into LDS rows f+2, zero halo / tail rows -------------------
     for (int i = tid; i < FP * VPR; i += nthr) {
-        const int rr = i / VPR, off = (i % VPR) * VN, f = rr - 2, tt = off / FC_H;
+        const int rr = i / VPR, off = (i % VPR) * VN, f = rr - 2, tt = off / HH;
         T* d = u + (size_t)rr * ROW + off;
         if (f >= 0 && f < F && t0 + tt < T_)
-            vec_copy(d, x + (((size_t)b * F + f) * T_ + t0) * FC_H + off);
+            vec_copy(d, x + (((size_t)b * F + f) * T_ + t0) * HH + off);
         else
             vec_zero(d);
     }
     lds_barrier();
     for (int r = tid; r < F * TT; r += nthr) {
         const int f = r / TT, tt = r % TT;
-        if (t0 + tt < T_) ln_row_inplace(u + (size_t)(f + 2) * ROW + tt * FC_H, lnw, lnb);
+        if (t0 + tt < T_) ln_row_inplace<T, HH>(u + (size_t)(f + 2) * ROW + tt * HH, lnw, lnb);
     }
     lds_barrier();
 
     // ---- phase 2: grouped conv on the matrix cores -----------------------------------------
-    f32x4 acc[GPW][TT][MTF];
-    Frag<T> a[GPW][FC_KS];
+    f32x4 acc[GPW][MTG][TT][MTF];
+    Frag<T> a[GPW][MTG][KSG];
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
-        for (int ks = 0; ks < FC_KS; ++ks) wfrag_load(a[gi][ks], Wp, GPW * w + gi, FC_KS, ks);
+        for (int mt = 0; mt < MTG; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KSG; ++ks) wfrag_load(a[gi][mt][ks], Wp, (GPW * w + gi) * MTG + mt, KSG, ks);
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
+        for (int mt = 0; mt < MTG; ++mt)
 #pragma unroll
-            for (int ft = 0; ft < MTF; ++ft) acc[gi][tt][ft] = F32X4_ZERO;
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int ft = 0; ft < MTF; ++ft) acc[gi][mt][tt][ft] = F32X4_ZERO;
 #pragma unroll
     for (int ft = 0; ft < MTF; ++ft) {
         if (ft < mtf) {
             const int f = ft * 16 + l15;
 #pragma unroll
             for (int gi = 0; gi < GPW; ++gi) {
-                const int ch0 = (GPW * w + gi) * FC_CG;
+                const int ch0 = (GPW * w + gi) * FG;
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
-                    for (int ks = 0; ks < FC_KS; ++ks) {
+                    for (int ks = 0; ks < KSG; ++ks) {
                         Frag<T> bq;
                         const int p0 = ks * 8 + 2 * g4, p1 = p0 + 1;
-                        // piece p -> tap p/3, channels (p%3)*4..+3 ; LDS row = f + tap
-                        frag_load_lo(bq, u + (size_t)(f + p0 / 3) * ROW + tt * FC_H + ch0 + (p0 % 3) * 4);
-                        if (p1 < 15) frag_load_hi(bq, u + (size_t)(f + p1 / 3) * ROW + tt * FC_H + ch0 + (p1 % 3) * 4);
+                        // piece p -> tap p / (FG/4), channels (p % (FG/4))*4..+3 ; LDS row = f + tap
+                        if (p0 < NP) frag_load_lo(bq, u + (size_t)(f + p0 / (FG / 4)) * ROW + tt * HH + ch0 + (p0 % (FG / 4)) * 4);
+                        else frag_zero_lo(bq);
+                        if (p1 < NP) frag_load_hi(bq, u + (size_t)(f + p1 / (FG / 4)) * ROW + tt * HH + ch0 + (p1 % (FG / 4)) * 4);
                         else frag_zero_hi(bq);
-                        acc[gi][tt][ft] = mma(a[gi][ks], bq, acc[gi][tt][ft]);
+#pragma unroll
+                        for (int mt = 0; mt < MTG; ++mt) acc[gi][mt][tt][ft] = mma(a[gi][mt][ks], bq, acc[gi][mt][tt][ft]);
                     }
                 }
             }
@@ -128,38 +140,40 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 ? 4 : 2) : 1
     lds_barrier();  // everyone is done reading u
 
     // ---- phase 3: bias + PReLU -> LDS [f][tt][H] ---------------------------------------------
-    if (g4 < 3) {
 #pragma unroll
-        for (int gi = 0; gi < GPW; ++gi) {
-            const int ch = (GPW * w + gi) * FC_CG + 4 * g4;
-            float bb[4], sl[4];
+    for (int gi = 0; gi < GPW; ++gi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { bb[r] = cb[ch + r]; sl[r] = slope[ch + r]; }
+        for (int mt = 0; mt < MTG; ++mt) {
+            if (16 * mt + 4 * g4 < FG) {
+                const int ch = (GPW * w + gi) * FG + 16 * mt + 4 * g4;
+                float bb[4], sl[4];
 #pragma unroll
-            for (int ft = 0; ft < MTF; ++ft) {
-                const int f = ft * 16 + l15;
-                if (ft < mtf && f < F) {
+                for (int r = 0; r < 4; ++r) { bb[r] = cb[ch + r]; sl[r] = slope[ch + r]; }
 #pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) {
-                        float o[4];
+                for (int ft = 0; ft < MTF; ++ft) {
+                    const int f = ft * 16 + l15;
+                    if (ft < mtf && f < F) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = acc[gi][tt][ft][r] + bb[r];
-                            o[r] = v > 0.f ? v : sl[r] * v;
+                        for (int tt = 0; tt < TT; ++tt) {
+                            float o[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[gi][mt][tt][ft][r] + bb[r];
+                                o[r] = v > 0.f ? v : sl[r] * v;
+                            }
+                            store4(u + (size_t)f * ROW + tt * HH + ch, o[0], o[1], o[2], o[3]);
                         }
-                        store4(u + (size_t)f * ROW + tt * FC_H + ch, o[0], o[1], o[2], o[3]);
                     }
                 }
             }
         }
-    }
     lds_barrier();
 
     // ---- phase 4: residual add + coalesced store -------------------------------------------------
     for (int i = tid; i < F * VPR; i += nthr) {
-        const int f = i / VPR, off = (i % VPR) * VN, tt = off / FC_H;
+        const int f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
         if (t0 + tt >= T_) continue;
-        const size_t go = (((size_t)b * F + f) * T_ + t0) * FC_H + off;
+        const size_t go = (((size_t)b * F + f) * T_ + t0) * HH + off;
         float xv[8], yv[8];
         if (VN == 8) {
             load8(x + go, xv);
@@ -494,28 +508,36 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T, int TT, int GPW, int MTF>
+template <class T, int TT, int GPW, int MTF, int HH>
 static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > MTF) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)(mtf * 16 + 4) * TT * FC_H * sizeof(T);
+    const size_t lds = (size_t)(mtf * 16 + 4) * TT * HH * sizeof(T);
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (fp32 stream, dim_hidden 192, F = 257: 212 KB)
     const float* lnw = P + param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W);
     const float* lnb = P + param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B);
     const float* cb = P + param_off(c, layer, which ? P_FC2_B : P_FC1_B);
     const float* sl = P + param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU);
     const T* Wp = (const T*)packed + pack_off(c, layer, which ? K_FC2 : K_FC1);
-    int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT, GPW, MTF>), lds);
+    int e = NBSS_SET_MAX_LDS((fconv_fwd_kernel<T, TT, GPW, MTF, HH>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, TT)), block(64 * FC_G / GPW);
     ProfScope ps(PK_FCONV_F, st);
-    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW, MTF>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
+    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW, MTF, HH>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 int fconv_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
-    if (c.F > 16 * FC_MTF_MAX)  // 16-kHz geometry: one frame per workgroup, 17 frequency tiles
-        return c.dtype == NBSS_BF16 ? fconv_fwd_t<bf16_t, 1, 1, FC_MTF_BIG>(c, P, packed, layer, which, x, y, st)
-                                    : fconv_fwd_t<float, 1, 2, FC_MTF_BIG>(c, P, packed, layer, which, x, y, st);
-    if (c.dtype == NBSS_BF16) return fconv_fwd_t<bf16_t, 2, 1, FC_MTF_MAX>(c, P, packed, layer, which, x, y, st);
-    return fconv_fwd_t<float, 1, 2, FC_MTF_MAX>(c, P, packed, layer, which, x, y, st);
+    const bool bigF = c.F > 16 * FC_MTF_MAX;  // 16-kHz geometry: one frame per workgroup, 17 frequency tiles
+    if (c.H == GeoL::H) {  // SpatialNet-large (forward only): 24 channels per group, one frame per workgroup
+        if (bigF) return c.dtype == NBSS_BF16 ? fconv_fwd_t<bf16_t, 1, 1, FC_MTF_BIG, GeoL::H>(c, P, packed, layer, which, x, y, st)
+                                              : fconv_fwd_t<float, 1, 2, FC_MTF_BIG, GeoL::H>(c, P, packed, layer, which, x, y, st);
+        return c.dtype == NBSS_BF16 ? fconv_fwd_t<bf16_t, 1, 1, FC_MTF_MAX, GeoL::H>(c, P, packed, layer, which, x, y, st)
+                                    : fconv_fwd_t<float, 1, 2, FC_MTF_MAX, GeoL::H>(c, P, packed, layer, which, x, y, st);
+    }
+    if (bigF)
+        return c.dtype == NBSS_BF16 ? fconv_fwd_t<bf16_t, 1, 1, FC_MTF_BIG, GeoS::H>(c, P, packed, layer, which, x, y, st)
+                                    : fconv_fwd_t<float, 1, 2, FC_MTF_BIG, GeoS::H>(c, P, packed, layer, which, x, y, st);
+    if (c.dtype == NBSS_BF16) return fconv_fwd_t<bf16_t, 2, 1, FC_MTF_MAX, GeoS::H>(c, P, packed, layer, which, x, y, st);
+    return fconv_fwd_t<float, 1, 2, FC_MTF_MAX, GeoS::H>(c, P, packed, layer, which, x, y, st);
 }

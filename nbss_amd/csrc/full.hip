@@ -14,6 +14,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "geom.h"
 
 #define FL_H 96
 #define FL_SQ 8
@@ -24,7 +25,8 @@
 #define FL_KSF_BIG 9  // ceil(272 / 32): 16 kHz (n_fft 512 -> F = 257)
 #define FL_THREADS 512  // 8 waves: one workgroup per CU (256 slabs), so the waves of a workgroup are all the latency hiding there is
 
-template <class T, int KSFM>  // KSFM: LinearGroup k-steps the fragment arrays are sized for
+// KSFM: LinearGroup k-steps the fragment arrays are sized for; HH / NSQ = dim_hidden / dim_squeeze (geom.h)
+template <class T, int KSFM, int HH, int NSQ>
 __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bs, const float* __restrict__ bfull,
                                                        const float* __restrict__ bu, const T* __restrict__ Wsq,
@@ -34,24 +36,24 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
     const int F = c.F, T_ = c.T;
     const int mtf = cdiv(F, 16), ksf = cdiv(F, 32), FK = ksf * 32, FM = mtf * 16;
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]
-    T* z = s + FL_SQ * FL_TT * FK;                 // [FM][TT][SQ]
+    T* z = s + NSQ * FL_TT * FK;                 // [FM][TT][SQ]
     const int ntt = cdiv(T_, FL_TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
     const int ntile = cdiv(F, 2);  // n-tiles of (2 freqs x 8 frames)
 
-    for (int i = tid; i < FL_SQ * FL_TT * FK + FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
+    for (int i = tid; i < NSQ * FL_TT * FK + FM * FL_TT * NSQ; i += nthr) store1(s + i, 0.f);
     lds_barrier();
 
     // ---- pass 1: LN + squeeze + SiLU ---------------------------------------------------------
     {
-        Frag<T> a[FL_KS];
+        Frag<T> a[(HH / 32)];
 #pragma unroll
-        for (int ks = 0; ks < FL_KS; ++ks) wfrag_load(a[ks], Wsq, 0, FL_KS, ks);
-        float gam[FL_KS][8], bet[FL_KS][8];
+        for (int ks = 0; ks < (HH / 32); ++ks) wfrag_load(a[ks], Wsq, 0, (HH / 32), ks);
+        float gam[(HH / 32)][8], bet[(HH / 32)][8];
 #pragma unroll
-        for (int ks = 0; ks < FL_KS; ++ks)
+        for (int ks = 0; ks < (HH / 32); ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 gam[ks][j] = lnw[ks * 32 + 8 * g4 + j];
@@ -60,11 +62,11 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
         for (int nt = w; nt < ntile; nt += nw) {
             const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
             const bool valid = f < F && t0 + tt < T_;
-            const T* xr = x + (((size_t)b * F + f) * T_ + t0 + tt) * FL_H;
-            float v[FL_KS][8];
+            const T* xr = x + (((size_t)b * F + f) * T_ + t0 + tt) * HH;
+            float v[(HH / 32)][8];
             float sum = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < FL_KS; ++ks) {
+            for (int ks = 0; ks < (HH / 32); ++ks) {
                 if (valid) load8(xr + ks * 32 + 8 * g4, v[ks]);
                 else
 #pragma unroll
@@ -72,25 +74,25 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += v[ks][j];
             }
-            const float mean = wave_sum16(sum) * (1.0f / FL_H);
+            const float mean = wave_sum16(sum) * (1.0f / HH);
             float q = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < FL_KS; ++ks)
+            for (int ks = 0; ks < (HH / 32); ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float d = v[ks][j] - mean;
                     q += d * d;
                 }
-            const float rstd = rsqrtf(wave_sum16(q) * (1.0f / FL_H) + 1e-5f);
+            const float rstd = rsqrtf(wave_sum16(q) * (1.0f / HH) + 1e-5f);
             f32x4 acc = F32X4_ZERO;
 #pragma unroll
-            for (int ks = 0; ks < FL_KS; ++ks) {
+            for (int ks = 0; ks < (HH / 32); ++ks) {
                 Frag<T> u;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) frag_set(u, j, (v[ks][j] - mean) * rstd * gam[ks][j] + bet[ks][j]);
                 acc = mma(a[ks], u, acc);
             }
-            if (valid && g4 < 2) {
+            if (valid && 4 * g4 < NSQ) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ch = 4 * g4 + r;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
     lds_barrier();
 
     // ---- pass 2: LinearGroup along F, one F x F matrix per squeeze channel -------------------
-    for (int task = w; task < FL_SQ * mtf; task += nw) {
+    for (int task = w; task < NSQ * mtf; task += nw) {
         const int ch = task / mtf, mt = task % mtf;
         f32x4 acc = F32X4_ZERO;
         Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = mt * 16 + 4 * g4 + r;
-                if (k < F) store1(z + ((size_t)k * FL_TT + l15) * FL_SQ + ch, acc[r] + bfull[ch * F + k]);
+                if (k < F) store1(z + ((size_t)k * FL_TT + l15) * NSQ + ch, acc[r] + bfull[ch * F + k]);
             }
         }
     }
@@ -130,18 +132,18 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
 
     // ---- pass 3: unsqueeze + SiLU + residual -----------------------------------------------------
     {
-        Frag<T> a[FL_MT];
+        Frag<T> a[(HH / 16)];
 #pragma unroll
-        for (int mt = 0; mt < FL_MT; ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
+        for (int mt = 0; mt < (HH / 16); ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
         for (int nt = w; nt < ntile; nt += nw) {
             const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
             const bool valid = f < F && t0 + tt < T_;
             Frag<T> bq;
-            if (g4 == 0 && f < F) frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
+            if (8 * g4 < NSQ && f < F) frag_load(bq, z + ((size_t)f * FL_TT + tt) * NSQ + 8 * g4);
             else frag_zero(bq);
-            const size_t go = (((size_t)b * F + f) * T_ + t0 + tt) * FL_H;
+            const size_t go = (((size_t)b * F + f) * T_ + t0 + tt) * HH;
 #pragma unroll
-            for (int mt = 0; mt < FL_MT; ++mt) {
+            for (int mt = 0; mt < (HH / 16); ++mt) {
                 f32x4 acc = mma(a[mt], bq, F32X4_ZERO);
                 if (valid) {
                     const int ch = 16 * mt + 4 * g4;
@@ -460,25 +462,30 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     return wgrad_launch(a, c.dtype, st);
 }
 
-template <class T, int KSFM>
+template <class T, int KSFM, class G>
 static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)mtf * 16 * FL_TT * FL_SQ) * sizeof(T);
+    const size_t lds = ((size_t)G::SQ * FL_TT * ksf * 32 + (size_t)mtf * 16 * FL_TT * G::SQ) * sizeof(T);
     const T* pk = (const T*)packed;
     if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
-    int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T, KSFM>), lds);
+    int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T, KSFM, G::H, G::SQ>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
     ProfScope ps(PK_FULL_F, st);
-    NBSS_LAUNCH((full_fwd_kernel<T, KSFM>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+    NBSS_LAUNCH((full_fwd_kernel<T, KSFM, G::H, G::SQ>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
                 pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
-int full_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+template <class G>
+static int full_fwd_g(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
     if (c.F > 32 * FL_KSF_MAX)
-        return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t, FL_KSF_BIG>(c, P, packed, layer, x, y, st) : full_fwd_t<float, FL_KSF_BIG>(c, P, packed, layer, x, y, st);
-    return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t, FL_KSF_MAX>(c, P, packed, layer, x, y, st) : full_fwd_t<float, FL_KSF_MAX>(c, P, packed, layer, x, y, st);
+        return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t, FL_KSF_BIG, G>(c, P, packed, layer, x, y, st) : full_fwd_t<float, FL_KSF_BIG, G>(c, P, packed, layer, x, y, st);
+    return c.dtype == NBSS_BF16 ? full_fwd_t<bf16_t, FL_KSF_MAX, G>(c, P, packed, layer, x, y, st) : full_fwd_t<float, FL_KSF_MAX, G>(c, P, packed, layer, x, y, st);
+}
+
+int full_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    return c.H == GeoL::H ? full_fwd_g<GeoL>(c, P, packed, layer, x, y, st) : full_fwd_g<GeoS>(c, P, packed, layer, x, y, st);
 }

@@ -223,7 +223,7 @@ NBSS_HD size_t mhsa_lse_offset(const nbss_cfg& c) {
 // (T > 256, forward only: the same buffer is the K | V scratch of the long-sequence attention path, two stream tensors)
 NBSS_HD size_t mhsa_save_bytes(const nbss_cfg& c) {
     const size_t s = mhsa_lse_offset(c) + ws_align((size_t)c.B * c.F * c.T * c.heads * sizeof(float));
-    return c.T > NBSS_T_TRAIN_MAX && s < 2 * mhsa_lse_offset(c) ? 2 * mhsa_lse_offset(c) : s;
+    return (c.T > NBSS_T_TRAIN_MAX || c.H != 96) && s < 2 * mhsa_lse_offset(c) ? 2 * mhsa_lse_offset(c) : s;
 }
 // per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands
 NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
@@ -240,8 +240,11 @@ NBSS_HD size_t ws_wgpart_offset(const nbss_cfg& c) {
 NBSS_HD int check_cfg(const nbss_cfg& c) {
     if (c.B <= 0 || c.F <= 0 || c.T <= 0 || c.L <= 0) return NBSS_EINVAL;
     if (c.dtype != NBSS_F32 && c.dtype != NBSS_BF16) return NBSS_EINVAL;
-    // this build ships kernels for the SpatialNet-small geometry (configs/SpatialNet.yaml)
-    if (c.H != 96 || c.FFN != 192 || c.SQ != 8 || c.heads != 4) return NBSS_EUNSUPPORTED;
+    // this build ships kernels for SpatialNet-small (configs/SpatialNet.yaml as shipped: training + inference) and for
+    // SpatialNet-large (its "for large" comments: dim_hidden 192, dim_ffn 384, dim_squeeze 16; forward only — check_cfg_train)
+    const bool small = c.H == 96 && c.FFN == 192 && c.SQ == 8 && c.heads == 4;
+    const bool large = c.H == 192 && c.FFN == 384 && c.SQ == 16 && c.heads == 4;
+    if (!small && !large) return NBSS_EUNSUPPORTED;
     if (c.f_groups != 8 || c.t_groups != 8 || c.f_ks != 5 || c.t_ks != 3 || c.enc_ks != 5) return NBSS_EUNSUPPORTED;
     if (c.C_in % 4 != 0 || c.C_in > 16 || c.C_out > 16 || c.C_out <= 0) return NBSS_EUNSUPPORTED;
     if (c.F > NBSS_F_MAX || c.T > NBSS_T_MAX) return NBSS_EUNSUPPORTED;

@@ -18,6 +18,7 @@
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"
+#include "geom.h"
 
 #define MH_H 96
 #define MH_HEADS 4
@@ -358,115 +359,146 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
 //                       of 128 keys (the next block's global loads are in flight during the current block's math),
 //                       online softmax per head, out_proj + bias + residual in the epilogue.
 // Any T; no state is saved for backward (training keeps the single-workgroup kernel and its T <= 256 limit).
-#define ML_KB 128
-template <class T>
+#define ML_QB 128  // queries per workgroup: 8 waves x one 16-frame strip
+// G = geometry (geom.h): small dh = 24 (two 16-row tiles per head, the second half empty; one k-step for q k^T), large dh = 48 (three
+// tiles, two k-steps).  in_proj fragments: K_INP tiles (which, head, i) with rows padded to multiples of 32 per head (layout.h).
+template <class T, class G>
+NBSS_DEV void ln_strip_g(const T* __restrict__ xr, bool valid, const float* __restrict__ lnw, const float* __restrict__ lnb, Frag<T> (&u)[G::KS]) {
+    const int g4 = lane_id() >> 4;
+    float v[G::KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        if (valid) load8(xr + ks * 32 + 8 * g4, v[ks]);
+        else
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[ks][j];
+    }
+    const float mean = wave_sum16(sum) * (1.0f / G::H);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[ks][j] - mean;
+            q += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum16(q) * (1.0f / G::H) + 1e-5f);
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+        float gam[8], bet[8];
+        load8(lnw + ks * 32 + 8 * g4, gam);
+        load8(lnb + ks * 32 + 8 * g4, bet);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frag_set(u[ks], j, (v[ks][j] - mean) * rstd * gam[j] + bet[j]);
+    }
+}
+
+template <class T, class G>
 __global__ __launch_bounds__(512) void mhsa_kv_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ bin,
                                                       const T* __restrict__ Win, const T* __restrict__ x, T* __restrict__ Kg, T* __restrict__ Vg) {
+    constexpr int H = G::H, DH = G::DH, HEADS = G::HEADS, KS = G::KS;
+    constexpr int TPH = (DH + 31) / 32 * 2, OT = (DH + 15) / 16;  // packed tiles per head / tiles that hold real rows
     const int T_ = c.T, bf = blockIdx.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
-    const int t = (int)blockIdx.y * ML_KB + w * 16 + l15;
+    const int t = (int)blockIdx.y * ML_QB + w * 16 + l15;
     const bool tv = t < T_;
     const size_t n = (size_t)bf * T_ + (tv ? t : 0);
-    Frag<T> u[MH_KS];
-    {
-        float gam[MH_KS][8], bet[MH_KS][8];
-#pragma unroll
-        for (int ks = 0; ks < MH_KS; ++ks) {
-            load8(lnw + ks * 32 + 8 * g4, gam[ks]);
-            load8(lnb + ks * 32 + 8 * g4, bet[ks]);
-        }
-        ln_strip<T>(x + n * MH_H, tv, gam, bet, u);
-    }
+    Frag<T> u[KS];
+    ln_strip_g<T, G>(x + n * H, tv, lnw, lnb, u);
 #pragma unroll
     for (int which = 1; which < 3; ++which) {
-        T* dst = (which == 1 ? Kg : Vg) + n * MH_H;
+        T* dst = (which == 1 ? Kg : Vg) + n * H;
 #pragma unroll
-        for (int head = 0; head < MH_HEADS; ++head) {
-            f32x4 ct[2];
+        for (int head = 0; head < HEADS; ++head) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int i = 0; i < OT; ++i) {
                 f32x4 acc = F32X4_ZERO;
 #pragma unroll
-                for (int ks = 0; ks < MH_KS; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     Frag<T> a;
-                    wfrag_load(a, Win, (which * MH_HEADS + head) * 2 + half, MH_KS, ks);
+                    wfrag_load(a, Win, (which * HEADS + head) * TPH + i, KS, ks);
                     acc = mma(a, u[ks], acc);
                 }
-                ct[half] = acc;
-            }
-            const float* bs = bin + which * MH_H + head * MH_DH;
-            if (tv) {
-                store4(dst + head * MH_DH + 4 * g4, ct[0][0] + bs[4 * g4], ct[0][1] + bs[4 * g4 + 1], ct[0][2] + bs[4 * g4 + 2], ct[0][3] + bs[4 * g4 + 3]);
-                if (g4 < 2)
-                    store4(dst + head * MH_DH + 16 + 4 * g4, ct[1][0] + bs[16 + 4 * g4], ct[1][1] + bs[17 + 4 * g4], ct[1][2] + bs[18 + 4 * g4],
-                           ct[1][3] + bs[19 + 4 * g4]);
+                const int d = 16 * i + 4 * g4;
+                if (tv && d < DH) {
+                    const float* bs = bin + which * H + head * DH + d;
+                    store4(dst + head * DH + d, acc[0] + bs[0], acc[1] + bs[1], acc[2] + bs[2], acc[3] + bs[3]);
+                }
             }
         }
     }
 }
 
-template <class T>
+// A operand of O^T = V^T P^T from a row-major bf16 V image [keys][DH]: rows d = tile*16 + l15, K = the 32 keys of k-step ks
+template <int DH>
+NBSS_DEV void v_frag_tr_g(Frag<bf16_t>& f, const bf16_t* __restrict__ vr, int tile, int ks) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    frag_load_tr(f, vr + (size_t)(ks * 32 + 4 * g4 + (l15 >> 2)) * DH + tile * 16 + 4 * (l15 & 3), DH);
+}
+template <int DH>
+NBSS_DEV void v_frag_tr_g(Frag<float>&, const float*, int, int) {}
+
+// KB = keys per LDS block (128; 64 for the fp32 stream at dh = 48 so that K and V^T fit)
+template <class T, class G, int KB>
 __global__ __launch_bounds__(512) void mhsa_flash_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ bin,
                                                          const float* __restrict__ bout, const T* __restrict__ Win, const T* __restrict__ Wout,
                                                          const T* __restrict__ x, const T* __restrict__ Kg, const T* __restrict__ Vg, T* __restrict__ y) {
+    constexpr int H = G::H, DH = G::DH, HEADS = G::HEADS, KS = G::KS;
+    constexpr int TPH = (DH + 31) / 32 * 2, OT = (DH + 15) / 16, KSD = (DH + 31) / 32;
     NBSS_LDS(smem);
     T* Ks = reinterpret_cast<T*>(smem);        // [heads][KB][DH]
-    T* Vs = Ks + MH_HEADS * ML_KB * MH_DH;     // bf16: [heads][KB][DH] (transposing reads); fp32: [heads][DH][KB]
+    T* Vs = Ks + HEADS * KB * DH;              // bf16: [heads][KB][DH] (transposing reads); fp32: [heads][DH][KB]
     const int T_ = c.T, bf = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
-    const int t = (int)blockIdx.y * ML_KB + w * 16 + l15;
+    const int t = (int)blockIdx.y * ML_QB + w * 16 + l15;
     const bool tv = t < T_;
     const size_t n = (size_t)bf * T_ + (tv ? t : 0);
-    const T* Kb = Kg + (size_t)bf * T_ * MH_H;
-    const T* Vb = Vg + (size_t)bf * T_ * MH_H;
-    const float qscale = 1.4426950408889634f * rsqrtf((float)MH_DH);
+    const T* Kb = Kg + (size_t)bf * T_ * H;
+    const T* Vb = Vg + (size_t)bf * T_ * H;
+    const float qscale = 1.4426950408889634f * rsqrtf((float)DH);
 
-    // ---- Q of this wave's strip, all heads, in registers -----------------------------------------
-    Frag<T> qf[MH_HEADS];
+    // ---- Q of this wave's strip, all heads, in registers (B fragments in the permuted K order of stacked C tiles) ----
+    Frag<T> qf[HEADS][KSD];
     {
-        Frag<T> u[MH_KS];
-        {
-            float gam[MH_KS][8], bet[MH_KS][8];
+        Frag<T> u[KS];
+        ln_strip_g<T, G>(x + n * H, tv, lnw, lnb, u);
 #pragma unroll
-            for (int ks = 0; ks < MH_KS; ++ks) {
-                load8(lnw + ks * 32 + 8 * g4, gam[ks]);
-                load8(lnb + ks * 32 + 8 * g4, bet[ks]);
-            }
-            ln_strip<T>(x + n * MH_H, tv, gam, bet, u);
-        }
+        for (int head = 0; head < HEADS; ++head) {
+            f32x4 ct[2 * KSD];
 #pragma unroll
-        for (int head = 0; head < MH_HEADS; ++head) {
-            f32x4 ct[2];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int i = 0; i < 2 * KSD; ++i) {
                 f32x4 acc = F32X4_ZERO;
+                if (i < OT) {
 #pragma unroll
-                for (int ks = 0; ks < MH_KS; ++ks) {
-                    Frag<T> a;
-                    wfrag_load(a, Win, head * 2 + half, MH_KS, ks);
-                    acc = mma(a, u[ks], acc);
+                    for (int ks = 0; ks < KS; ++ks) {
+                        Frag<T> a;
+                        wfrag_load(a, Win, head * TPH + i, KS, ks);
+                        acc = mma(a, u[ks], acc);
+                    }
                 }
-                ct[half] = acc;
+                const int d = 16 * i + 4 * g4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ct[i][r] = d < DH ? (acc[r] + bin[head * DH + (d < DH ? d : 0) + r]) * qscale : 0.f;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ct[0][r] = (ct[0][r] + bin[head * MH_DH + 4 * g4 + r]) * qscale;
-                ct[1][r] = g4 < 2 ? (ct[1][r] + bin[head * MH_DH + 16 + 4 * g4 + r]) * qscale : 0.f;
-            }
-            frag_from_c2(qf[head], ct[0], ct[1]);
+            for (int p = 0; p < KSD; ++p) frag_from_c2(qf[head][p], ct[2 * p], ct[2 * p + 1]);
         }
     }
 
     // ---- key blocks ---------------------------------------------------------------------------------
-    constexpr int VN = 16 / sizeof(T), RV = MH_H / VN, NVB = ML_KB * RV / 512;  // 16-byte vectors: per row, per thread
+    constexpr int VN = 16 / sizeof(T), RV = H / VN, NVB = KB * RV / 512;  // 16-byte vectors: per row, per thread
+    static_assert(KB * RV % 512 == 0, "whole vectors per thread");
     u32x4 kreg[NVB], vreg[NVB];
     auto gload = [&](int kb) {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
             const int v = tid + i * 512, row = v / RV, e = (v % RV) * VN;
-            const int tk = kb * ML_KB + row, tc = tk < T_ ? tk : T_ - 1;  // clamped address, zero rows past the sequence
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)tc * MH_H + e);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)tc * MH_H + e);
+            const int tk = kb * KB + row, tc = tk < T_ ? tk : T_ - 1;  // clamped address, zero rows past the sequence
+            const u32x4 kv = *reinterpret_cast<const u32x4*>(Kb + (size_t)tc * H + e);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(Vb + (size_t)tc * H + e);
             const uint32_t keep = tk < T_ ? 0xffffffffu : 0u;
             kreg[i] = (u32x4){kv[0] & keep, kv[1] & keep, kv[2] & keep, kv[3] & keep};
             vreg[i] = (u32x4){vv[0] & keep, vv[1] & keep, vv[2] & keep, vv[3] & keep};
@@ -475,26 +507,27 @@ __global__ __launch_bounds__(512) void mhsa_flash_kernel(nbss_cfg c, const float
     auto sstore = [&]() {
 #pragma unroll
         for (int i = 0; i < NVB; ++i) {
-            const int v = tid + i * 512, row = v / RV, e = (v % RV) * VN, hh = e / MH_DH, d = e % MH_DH;
-            *reinterpret_cast<u32x4*>(Ks + ((size_t)hh * ML_KB + row) * MH_DH + d) = kreg[i];
+            const int v = tid + i * 512, row = v / RV, e = (v % RV) * VN, hh = e / DH, d = e % DH;
+            *reinterpret_cast<u32x4*>(Ks + ((size_t)hh * KB + row) * DH + d) = kreg[i];
             if (sizeof(T) == 2) {
-                *reinterpret_cast<u32x4*>(Vs + ((size_t)hh * ML_KB + row) * MH_DH + d) = vreg[i];
+                *reinterpret_cast<u32x4*>(Vs + ((size_t)hh * KB + row) * DH + d) = vreg[i];
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) reinterpret_cast<uint32_t*>(Vs)[((size_t)hh * MH_DH + d + q) * ML_KB + row] = vreg[i][q];
+                for (int q = 0; q < 4; ++q) reinterpret_cast<uint32_t*>(Vs)[((size_t)hh * DH + d + q) * KB + row] = vreg[i][q];
             }
         }
     };
 
-    float mrun[MH_HEADS], lrun[MH_HEADS];
-    f32x4 o0[MH_HEADS], o1[MH_HEADS];
+    float mrun[HEADS], lrun[HEADS];
+    f32x4 o[HEADS][OT];
 #pragma unroll
-    for (int hh = 0; hh < MH_HEADS; ++hh) {
+    for (int hh = 0; hh < HEADS; ++hh) {
         mrun[hh] = -1e30f;
         lrun[hh] = 0.f;
-        o0[hh] = o1[hh] = F32X4_ZERO;
+#pragma unroll
+        for (int i = 0; i < OT; ++i) o[hh][i] = F32X4_ZERO;
     }
-    const int nkb = cdiv(T_, ML_KB);
+    const int nkb = cdiv(T_, KB);
     gload(0);
     for (int kb = 0; kb < nkb; ++kb) {
         lds_barrier();  // the previous block's readers are done
@@ -503,22 +536,28 @@ __global__ __launch_bounds__(512) void mhsa_flash_kernel(nbss_cfg c, const float
         if (kb + 1 < nkb) gload(kb + 1);
         const bool lastb = kb == nkb - 1;
 #pragma unroll
-        for (int hh = 0; hh < MH_HEADS; ++hh) {
-            const T* kh = Ks + (size_t)hh * ML_KB * MH_DH;
-            f32x4 sc[ML_KB / 16];
+        for (int hh = 0; hh < HEADS; ++hh) {
+            const T* kh = Ks + (size_t)hh * KB * DH;
+            f32x4 sc[KB / 16];
             float mx = -1e30f;
 #pragma unroll
-            for (int j = 0; j < ML_KB / 16; ++j) {
-                Frag<T> a;
-                const T* kr = kh + (size_t)(j * 16 + l15) * MH_DH;
-                frag_load_lo(a, kr + 4 * g4);
-                if (g4 < 2) frag_load_hi(a, kr + 16 + 4 * g4);
-                else frag_zero_hi(a);
-                sc[j] = mma(a, qf[hh], F32X4_ZERO);
+            for (int j = 0; j < KB / 16; ++j) {
+                const T* kr = kh + (size_t)(j * 16 + l15) * DH;
+                f32x4 sacc = F32X4_ZERO;
+#pragma unroll
+                for (int p = 0; p < KSD; ++p) {
+                    Frag<T> a;
+                    if (32 * p + 4 * g4 < DH) frag_load_lo(a, kr + 32 * p + 4 * g4);
+                    else frag_zero_lo(a);
+                    if (32 * p + 16 + 4 * g4 < DH) frag_load_hi(a, kr + 32 * p + 16 + 4 * g4);
+                    else frag_zero_hi(a);
+                    sacc = mma(a, qf[hh][p], sacc);
+                }
+                sc[j] = sacc;
                 if (lastb) {  // only the last block can hold keys past the sequence
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kb * ML_KB + j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
+                        if (kb * KB + j * 16 + 4 * g4 + r >= T_) sc[j][r] = -1e30f;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[j][r]);
@@ -528,71 +567,75 @@ __global__ __launch_bounds__(512) void mhsa_flash_kernel(nbss_cfg c, const float
             mrun[hh] = mx;
             float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < ML_KB / 16; ++j)
+            for (int j = 0; j < KB / 16; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(sc[j][r] - mx);
-                    sc[j][r] = p;
-                    sum += p;
+                    const float pv = fast_exp2(sc[j][r] - mx);
+                    sc[j][r] = pv;
+                    sum += pv;
                 }
             lrun[hh] = lrun[hh] * alpha + wave_sum16(sum);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o0[hh][r] *= alpha;
-                o1[hh][r] *= alpha;
-            }
+            for (int i = 0; i < OT; ++i)
 #pragma unroll
-            for (int ks = 0; ks < ML_KB / 32; ++ks) {
-                Frag<T> pf, a0, a1;
+                for (int r = 0; r < 4; ++r) o[hh][i][r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < KB / 32; ++ks) {
+                Frag<T> pf;
                 frag_from_c2(pf, sc[2 * ks], sc[2 * ks + 1]);
-                if (sizeof(T) == 2) {
-                    const T* vh = Vs + (size_t)hh * ML_KB * MH_DH;
-                    v_frag_tr(a0, vh, 0, ks);
-                    v_frag_tr(a1, vh, 1, ks);  // rows d >= 24 pick up neighbouring data; those output rows are dropped below
-                } else {
-                    const T* vh = Vs + (size_t)hh * MH_DH * ML_KB;
-                    const T* v0 = vh + (size_t)l15 * ML_KB + ks * 32 + 4 * g4;
-                    frag_load_lo(a0, v0);
-                    frag_load_hi(a0, v0 + 16);
-                    if (l15 < MH_DH - 16) {
-                        const T* v1 = vh + (size_t)(16 + l15) * ML_KB + ks * 32 + 4 * g4;
-                        frag_load_lo(a1, v1);
-                        frag_load_hi(a1, v1 + 16);
+#pragma unroll
+                for (int i = 0; i < OT; ++i) {
+                    Frag<T> a;
+                    if (sizeof(T) == 2) {
+                        // (dh = 24: rows d >= 24 of the second tile pick up neighbouring data; those output rows are dropped below)
+                        v_frag_tr_g<DH>(a, Vs + (size_t)hh * KB * DH, i, ks);
                     } else {
-                        frag_zero(a1);
+                        const T* vh = Vs + (size_t)hh * DH * KB;
+                        if (16 * i + l15 < DH) {
+                            const T* v0 = vh + (size_t)(16 * i + l15) * KB + ks * 32 + 4 * g4;
+                            frag_load_lo(a, v0);
+                            frag_load_hi(a, v0 + 16);
+                        } else {
+                            frag_zero(a);
+                        }
                     }
+                    o[hh][i] = mma(a, pf, o[hh][i]);
                 }
-                o0[hh] = mma(a0, pf, o0[hh]);
-                o1[hh] = mma(a1, pf, o1[hh]);
             }
         }
     }
 
     // ---- normalise, out_proj + bias + residual -------------------------------------------------------
-    Frag<T> of[MH_HEADS];
+    Frag<T> of[HEADS][KSD];
 #pragma unroll
-    for (int hh = 0; hh < MH_HEADS; ++hh) {
+    for (int hh = 0; hh < HEADS; ++hh) {
         const float inv = 1.0f / lrun[hh];
-        f32x4 a = o0[hh], b = o1[hh];
+        f32x4 ct[2 * KSD];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            a[r] *= inv;
-            b[r] = g4 < 2 ? b[r] * inv : 0.f;  // output rows d = 16 + 4 g4 + r >= dh are padding
-        }
-        frag_from_c2(of[hh], a, b);
+        for (int i = 0; i < 2 * KSD; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.f;
+                if (i < OT) v = o[hh][i < OT ? i : 0][r] * inv;
+                ct[i][r] = 16 * i + 4 * g4 < DH ? v : 0.f;  // rows d >= dh are padding
+            }
+#pragma unroll
+        for (int p = 0; p < KSD; ++p) frag_from_c2(of[hh][p], ct[2 * p], ct[2 * p + 1]);
     }
-    const T* xr = x + n * MH_H;
-    T* yr = y + n * MH_H;
+    const T* xr = x + n * H;
+    T* yr = y + n * H;
 #pragma unroll
-    for (int mt = 0; mt < MH_H / 16; ++mt) {
+    for (int mt = 0; mt < H / 16; ++mt) {
         const int ch = 16 * mt + 4 * g4;
         f32x4 acc = F32X4_ZERO;
 #pragma unroll
-        for (int hh = 0; hh < MH_HEADS; ++hh) {
-            Frag<T> a;
-            wfrag_load(a, Wout, mt, MH_HEADS, hh);
-            acc = mma(a, of[hh], acc);
-        }
+        for (int hh = 0; hh < HEADS; ++hh)
+#pragma unroll
+            for (int p = 0; p < KSD; ++p) {
+                Frag<T> a;
+                wfrag_load(a, Wout, mt, HEADS * KSD, hh * KSD + p);
+                acc = mma(a, of[hh][p], acc);
+            }
         if (tv) {
             float rv[4];
             load4(xr + ch, rv);
@@ -601,31 +644,34 @@ __global__ __launch_bounds__(512) void mhsa_flash_kernel(nbss_cfg c, const float
     }
 }
 
-template <class T>
+template <class T, class G, int KB>
 static int mhsa_fwd_long_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* scratch, hipStream_t st) {
     if (!scratch) return NBSS_EINVAL;  // K | V, nbss_mhsa_save_bytes() bytes
     const size_t N = (size_t)c.B * c.F * c.T;
     T* Kg = (T*)scratch;
-    T* Vg = (T*)((char*)scratch + ws_align(N * MH_H * sizeof(T)));
-    const size_t lds = (size_t)2 * MH_HEADS * ML_KB * MH_DH * sizeof(T) + 64;
+    T* Vg = (T*)((char*)scratch + ws_align(N * G::H * sizeof(T)));
+    const size_t lds = (size_t)2 * G::HEADS * KB * G::DH * sizeof(T) + 64;
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((mhsa_flash_kernel<T>), lds);
+    int e = NBSS_SET_MAX_LDS((mhsa_flash_kernel<T, G, KB>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.F, cdiv(c.T, ML_KB)), block(512);
+    dim3 grid(c.B * c.F, cdiv(c.T, ML_QB)), block(512);
     ProfScope ps(PK_MHSA_F, st);
     const float* lnw = P + param_off(c, layer, P_MH_LN_W);
     const float* lnb = P + param_off(c, layer, P_MH_LN_B);
     const float* bin = P + param_off(c, layer, P_INP_B);
-    NBSS_LAUNCH((mhsa_kv_kernel<T>), grid, block, 0, st, c, lnw, lnb, bin, pk + pack_off(c, layer, K_INP), (const T*)x, Kg, Vg);
+    NBSS_LAUNCH((mhsa_kv_kernel<T, G>), grid, block, 0, st, c, lnw, lnb, bin, pk + pack_off(c, layer, K_INP), (const T*)x, Kg, Vg);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
-    NBSS_LAUNCH((mhsa_flash_kernel<T>), grid, block, lds, st, c, lnw, lnb, bin, P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
+    NBSS_LAUNCH((mhsa_flash_kernel<T, G, KB>), grid, block, lds, st, c, lnw, lnb, bin, P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
                 pk + pack_off(c, layer, K_OUTP), (const T*)x, (const T*)Kg, (const T*)Vg, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
+    // SpatialNet-large (forward only): always the two-launch path; `osave` is its K | V scratch
+    if (c.H == GeoL::H) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t, GeoL, 128>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float, GeoL, 64>(c, P, packed, layer, x, y, osave, st);
     // T > 256: `osave` is the K | V scratch of the two-launch long-sequence path (nothing is saved for backward)
-    if (c.T > MH_TP) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float>(c, P, packed, layer, x, y, osave, st);
+    if (c.T > MH_TP) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t, GeoS, 128>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float, GeoS, 128>(c, P, packed, layer, x, y, osave, st);
     if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false, 2>(c, P, packed, layer, x, y, osave, st);
     return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<bf16_t, 4, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st);
 }

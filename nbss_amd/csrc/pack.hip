@@ -103,19 +103,19 @@ NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the 
             return (m < c.F && knat < c.F) ? P[((int64_t)nb * c.F + m) * c.F + knat] : 0.f;
         case K_USQ:
             return knat < c.SQ ? P[(int64_t)m * c.SQ + knat] : 0.f;
-        case K_INP: {
-            const int dh = H / c.heads;
-            const int which = mt / (c.heads * 2), rem = mt % (c.heads * 2), head = rem >> 1, d = (rem & 1) * 16 + l15;
+        case K_INP: {  // tiles per head: the head's dh rows padded to a multiple of 32 (dh = 24: 2 tiles, dh = 48: 4)
+            const int dh = H / c.heads, tph = cdiv(dh, 32) * 2;
+            const int which = mt / (c.heads * tph), rem = mt % (c.heads * tph), head = rem / tph, d = (rem % tph) * 16 + l15;
             if (d >= dh) return 0.f;
             return P[(int64_t)(which * H + head * dh + d) * H + knat];
         }
-        case K_OUTP: {
-            const int dh = H / c.heads, d = perm_k(g4, j);
+        case K_OUTP: {  // k-steps per head: cdiv(dh, 32), permuted order inside each
+            const int dh = H / c.heads, kph = cdiv(dh, 32), d = (ks % kph) * 32 + perm_k(g4, j);
             if (d >= dh) return 0.f;
-            return P[(int64_t)m * H + ks * dh + d];
+            return P[(int64_t)m * H + (ks / kph) * dh + d];
         }
         case K_TF_W1: {
-            const int cg = c.FFN / c.t_groups, grp = mt >> 1, ci = (mt & 1) * 16 + l15;
+            const int cg = c.FFN / c.t_groups, tpg = cdiv(cg, 32) * 2, grp = mt / tpg, ci = (mt % tpg) * 16 + l15;
             if (ci >= cg) return 0.f;
             return P[(int64_t)(grp * cg + ci) * H + knat];
         }
@@ -126,9 +126,9 @@ NBSS_DEV float pack_value(const nbss_cfg& c, const float* __restrict__ P /* the 
             return P[((int64_t)(nb * cg + m) * cg + i) * c.t_ks + tap];
         }
         case K_TF_W2: {
-            const int cg = c.FFN / c.t_groups, d = perm_k(g4, j);
+            const int cg = c.FFN / c.t_groups, kpg = cdiv(cg, 32), d = (ks % kpg) * 32 + perm_k(g4, j);
             if (d >= cg) return 0.f;
-            return P[(int64_t)m * c.FFN + ks * cg + d];
+            return P[(int64_t)m * c.FFN + (ks / kpg) * cg + d];
         }
         // ---- transposed (data-gradient) operands ----
         case K_DEC_T:
@@ -210,11 +210,13 @@ __global__ void pack_kernel(nbss_cfg c, PackTable tb, const float* __restrict__ 
 
 int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipStream_t stream) {
     dim3 grid(16, NUM_PACK_KINDS), block(256);
+    const bool small = c.H == 96 && c.FFN == 192 && c.SQ == 8 && c.heads == 4;
     ProfScope ps(PK_PACK, stream);
     for (int layer = 0; layer < c.L; ++layer) {
         PackTable tb;
         for (int k = 0; k < NUM_PACK_KINDS; ++k) {
-            tb.skip[k] = pack_is_global(k) && layer != 0;
+            // (geometries other than SpatialNet-small are forward only: their backward fragment kinds are never read)
+            tb.skip[k] = (pack_is_global(k) && layer != 0) || (!small && k >= K_DEC_T);
             tb.src[k] = pack_src_base(c, k, layer);
             tb.src2[k] = pack_src2_base(c, k, layer);
             tb.dst[k] = pack_off(c, layer, k);

@@ -1160,7 +1160,10 @@ static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed,
 
 int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, float* gn_save, hipStream_t st);
 
+int tconvffn_fwd_large_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
+
 int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    if (c.H != TF_H) return tconvffn_fwd_large_impl(c, P, packed, layer, x, y, st);  // SpatialNet-large, forward only (tconvffn_g.hip)
     // bf16 stream: the streaming wave-per-group kernel (tconvffn_s.hip); fp32 stream: the group-serial kernel above
     // sequences beyond 256 frames (forward only): the chunked two-pass variant of the group-serial kernel
     if (c.T > TF_TP) return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t, 1, true>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float, 2, true>(c, P, packed, layer, x, y, st);

@@ -38,8 +38,11 @@ NBSS_DEV void load_cw(const T* p, float (&v)[8]) {
     else load4(p, v);
 }
 
-template <class T, int CW>
-__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
+// TPW = output tiles per wave: WG_TPW (LinearGroup: 81 tiles per group), or 4 for the small problems (encoder / decoder: 24 / 6 tiles) so
+// that the kernel fits 128 VGPRs and several workgroups per CU overlap their load -> barrier -> MFMA -> barrier rounds (one 8-wave
+// workgroup per CU spent every chunk's HBM latency exposed: 560 us for 220 MB of operands)
+template <class T, int CW, int TPW>
+__global__ __launch_bounds__(WG_THREADS, TPW <= 4 ? 4 : 2) void wgrad_kernel(WgradArgs a) {
     NBSS_LDS(smem);
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
@@ -61,9 +64,9 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
     T* Bt = At + (size_t)rowsA * WG_LD;            // [rowsB][WG_LD]   row = g*ngp + tap*ng + i
     for (int i = tid; i < (rowsA + rowsB) * WG_LD; i += WG_THREADS) store1(At + i, 0.f);
 
-    f32x4 acc[WG_TPW];
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) acc[s] = F32X4_ZERO;
+    for (int s = 0; s < TPW; ++s) acc[s] = F32X4_ZERO;
     float bsum = 0.f;
     const bool do_bias = a.dbias != nullptr && blockIdx.z == 0;
     const T* Ag = reinterpret_cast<const T*>(a.A);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
         lds_barrier();
         // ---- MFMA: K = the 32 tokens of this chunk ----
 #pragma unroll
-        for (int s = 0; s < WG_TPW; ++s) {
+        for (int s = 0; s < TPW; ++s) {
             const int tl = s * WG_WAVES + w;
             if (tl < ntot) {
                 const int g = tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(WgradArgs a) {
 
     // ---- flush ----
 #pragma unroll
-    for (int s = 0; s < WG_TPW; ++s) {
+    for (int s = 0; s < TPW; ++s) {
         const int tl = s * WG_WAVES + w;
         if (tl < ntot) {
             const int g = g_lo + tl / tpg, rem = tl % tpg, mt = rem / ntiles, nt = rem % ntiles;
@@ -586,19 +589,27 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
         }
     }
     if (a.a_gw || a.b_gw) return NBSS_EUNSUPPORTED;
-    int xbl = 384 / (ybl * nz);  // 1-2 resident workgroups (8-16 waves) per CU; every x-block ends with one atomicAdd per output element
+#ifdef NBSS_WG_NOSMALL
+    const bool small = false;
+#else
+    const bool small = (all ? a.groups : 1) * mtiles * ntz <= WG_WAVES * 4 && sizeof(T) == 2;
+#endif
+    int xbl = (small ? 1024 : 384) / (ybl * nz);  // resident workgroups; every x-block ends with one atomicAdd per output element
     if (xbl < 16) xbl = 16;
     if (xbl > nchunks) xbl = nchunks;
     dim3 grid(xbl, ybl, nz), block(WG_THREADS);
     ProfScope ps(PK_WGRAD, st);
     int e;
-    if (cw8) {
-        if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, 8>), lds))) return e;
-        NBSS_LAUNCH((wgrad_kernel<T, 8>), grid, block, lds, st, a);
-    } else {
-        if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, 4>), lds))) return e;
-        NBSS_LAUNCH((wgrad_kernel<T, 4>), grid, block, lds, st, a);
-    }
+#define WK_GO(CW, TPW)                                                             \
+    do {                                                                           \
+        if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, CW, TPW>), lds))) return e;     \
+        NBSS_LAUNCH((wgrad_kernel<T, CW, TPW>), grid, block, lds, st, a);          \
+    } while (0)
+    if (cw8 && small) WK_GO(8, 4);
+    else if (cw8) WK_GO(8, WG_TPW);
+    else if (small) WK_GO(4, 4);
+    else WK_GO(4, WG_TPW);
+#undef WK_GO
     return NBSS_CHECK_LAUNCH();
 }
 
