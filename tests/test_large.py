@@ -106,3 +106,20 @@ def test_large_is_forward_only(backend):
         ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws)
     with pytest.raises(NbssError, match="UNSUPPORTED"):
         ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, 0, x, dy, ws)
+
+
+@pytest.mark.gpu
+def test_large_dropin_module_inference(hip_lib):
+    """models.arch.SpatialNet.SpatialNet with the large configuration: eval-mode forward (what validate / test / predict run) equals the
+    oracle on the module's own state_dict; a training-mode forward raises"""
+    from models.arch.SpatialNet import SpatialNet
+    torch.manual_seed(5)
+    net = SpatialNet(dim_input=12, dim_output=4, num_layers=3, dim_hidden=192, dim_ffn=384, num_heads=4, dim_squeeze=16, num_freqs=129).cuda().eval()
+    x = torch.randn(1, 129, 40, 12, device="cuda")
+    with torch.no_grad():
+        y = net(x)
+    p = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    assert rel_l2(y, ref.spatialnet(x.double().cpu(), p, 3)) < 1e-3
+    net.train()
+    with pytest.raises((NbssError, RuntimeError)):
+        net(x).sum().backward()

@@ -54,6 +54,19 @@ def test_spatialnet_small_forward_and_grads(reference_modules):
     assert rel_l2(ref.tconvffn(h, p, "layers.3"), h + lay._tconvffn(h)) < 1e-10
 
 
+def test_spatialnet_large_16khz_forward(reference_modules):
+    """SpatialNet-large as the "for large" comments of configs/SpatialNet.yaml build it (12 layers, 192 / 384 / squeeze 16), 257 frequencies
+    (16 kHz): the oracle the large-geometry HIP kernels are tested against (tests/test_large.py) IS the reference's forward"""
+    torch.manual_seed(1)
+    torch.set_num_threads(4)
+    SpatialNet = reference_modules["models.arch.SpatialNet"].SpatialNet
+    net = SpatialNet(dim_input=12, dim_output=4, num_layers=12, dim_hidden=192, dim_ffn=384, num_heads=4, kernel_size=(5, 3), conv_groups=(8, 8),
+                     norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=16, num_freqs=257, full_share=0).double()
+    x = torch.randn(1, 257, 12, 12, dtype=torch.float64)
+    p = {k: v.detach() for k, v in net.state_dict().items()}
+    assert rel_l2(ref.spatialnet(x, p, 12), net(x)) < 1e-10
+
+
 def test_state_dict_interchanges_with_the_reference(reference_modules, tmp_path):
     """checkpoint contract: the drop-in module's state_dict loads strictly into the reference's SpatialNet and
     back, through a file written by SharedTrainer.save_checkpoint"""
