@@ -112,6 +112,85 @@ NBSS_DEV void ln_bwd_row96(f32x4 (&du)[BK_MT], const T* __restrict__ xr, const T
     }
 }
 
+// ---- raw C-layout row pieces (lane = row, 4 channels per 16-channel tile) for software-pipelined row loops --------------------------
+// The cross-band row loops (full.hip) are bound by exposed HBM latency at one workgroup per CU: the next iteration's x / dy pieces are
+// requested before the current iteration's math.  Addresses are clamped by the caller (always readable), validity is applied on use.
+template <class T> struct RawC4;
+template <> struct RawC4<bf16_t> { u32x2 v; };
+template <> struct RawC4<float> { f32x4 v; };
+NBSS_DEV void rawc_load(RawC4<bf16_t>& r, const bf16_t* p) { r.v = *reinterpret_cast<const u32x2*>(p); }
+NBSS_DEV void rawc_load(RawC4<float>& r, const float* p) { r.v = *reinterpret_cast<const f32x4*>(p); }
+NBSS_DEV void rawc_get(const RawC4<bf16_t>& r, float (&o)[4]) {
+    o[0] = bf2f((bf16_t)(r.v[0] & 0xFFFF)); o[1] = bf2f((bf16_t)(r.v[0] >> 16));
+    o[2] = bf2f((bf16_t)(r.v[1] & 0xFFFF)); o[3] = bf2f((bf16_t)(r.v[1] >> 16));
+}
+NBSS_DEV void rawc_get(const RawC4<float>& r, float (&o)[4]) { o[0] = r.v[0]; o[1] = r.v[1]; o[2] = r.v[2]; o[3] = r.v[3]; }
+template <class T>
+NBSS_DEV void rawc_load_row(RawC4<T> (&r)[BK_MT], const T* __restrict__ row) {
+    const int g4 = lane_id() >> 4;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt) rawc_load(r[mt], row + 16 * mt + 4 * g4);
+}
+
+// ln_bwd_row96 with the x and dy pieces of the row already in registers (rawc_load_row)
+template <class T>
+NBSS_DEV void ln_bwd_row96_raw(f32x4 (&du)[BK_MT], const RawC4<T> (&xr)[BK_MT], const RawC4<T> (&dyr)[BK_MT], T* __restrict__ dxr, float* __restrict__ stat,
+                               bool valid, const float* __restrict__ lnw, float (&dlw)[BK_MT][4], float (&dlb)[BK_MT][4]) {
+    const int g4 = lane_id() >> 4;
+    float xv[BK_MT][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt) {
+        rawc_get(xr[mt], xv[mt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xv[mt][r] = keep_if(valid, xv[mt][r]);
+            sum += xv[mt][r];
+        }
+    }
+    const float mean = wave_sum16(sum) * (1.0f / BK_H);
+    float q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xv[mt][r] -= mean;
+            q += xv[mt][r] * xv[mt][r];
+        }
+    const float rstd = rsqrtf(wave_sum16(q) * (1.0f / BK_H) + 1e-5f);
+    if (valid && g4 == 0 && stat) {
+        stat[0] = mean;
+        stat[1] = rstd;
+    }
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = 16 * mt + 4 * g4 + r;
+            xv[mt][r] *= rstd;  // xhat
+            const float dv = valid ? du[mt][r] : 0.f;
+            dlw[mt][r] += dv * xv[mt][r];
+            dlb[mt][r] += dv;
+            du[mt][r] = dv * lnw[ch];
+            m1 += du[mt][r];
+            m2 += du[mt][r] * xv[mt][r];
+        }
+    m1 = wave_sum16(m1) * (1.0f / BK_H);
+    m2 = wave_sum16(m2) * (1.0f / BK_H);
+    if (valid) {
+#pragma unroll
+        for (int mt = 0; mt < BK_MT; ++mt) {
+            const int ch = 16 * mt + 4 * g4;
+            float dv[4], o[4];
+            rawc_get(dyr[mt], dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = dv[r] + rstd * (du[mt][r] - m1 - xv[mt][r] * m2);
+            store4(dxr + ch, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // Small per-channel parameter gradients (LN / GN affine, PReLU slope) are summed per workgroup in LDS
 // (ds_add_f32) and written as ONE partial row per workgroup; util.hip's affine_reduce folds the rows
 // into the gradient buffer.  (Same-address global atomics from every wave serialise in the memory

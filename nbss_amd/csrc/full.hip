@@ -201,6 +201,21 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     lds_barrier();
     PHASE(0);
 
+    // the squeezed image s[c][tt][f] (s, later dz) is copied to its [B*T][SQ][FKP] wgrad operand as whole frequency rows (8-byte pieces of
+    // a contiguous 2 FKP-byte run) after the barrier that completes it: the first version stored every element from the MFMA epilogue,
+    // 2-byte stores scattered over 64 rows per instruction
+    auto copy_sq_image = [&](T* __restrict__ dst) {
+        constexpr int VE = 8 / sizeof(T);  // elements per 8-byte piece
+        const int vpr = FKP / VE;          // FKP is a multiple of 4
+        for (int i = tid; i < FL_SQ * FL_TT * vpr; i += nthr) {
+            const int rowi = i / vpr, v = i % vpr, ch = rowi / FL_TT, tt = rowi % FL_TT;
+            if (t0 + tt >= T_) continue;
+            // (image columns F..FK are never written and hold the zero fill: the operand's padding columns F..FKP come out zero)
+            const u32x2 val = *reinterpret_cast<const u32x2*>(s + ((size_t)ch * FL_TT + tt) * FK + v * VE);
+            *reinterpret_cast<u32x2*>(dst + (((size_t)b * T_ + t0 + tt) * FL_SQ + ch) * FKP + v * VE) = val;
+        }
+    };
+
     // ---- p1: LN + squeeze ----
     {
         Frag<T> a[FL_KS];
@@ -223,8 +238,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
                     const int ch = 4 * g4 + r;
                     pre[r] = acc[r] + bs[ch];
                     const float sv = silu_f(pre[r]);
-                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, sv);
-                    store1(s_out + (((size_t)b * T_ + t0 + tt) * FL_SQ + ch) * FKP + f, sv);
+                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, sv);  // (the global copy for wgrad leaves from this image: copy_sq_image)
                 }
                 store4(sp + ((size_t)f * FL_TT + tt) * FL_SQ + 4 * g4, pre[0], pre[1], pre[2], pre[3]);
             }
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     PHASE(1);
     lds_barrier();
     PHASE(2);
+    copy_sq_image(s_out);
 
     // ---- p2: z = Wf s + bf ----
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -270,10 +285,27 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
         for (int mt = 0; mt < FL_MT; ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
 #pragma unroll
         for (int ks = 0; ks < FL_KS; ++ks) wfrag_load(at[ks], WusqT, 0, FL_KS, ks);
+        // software pipeline: the dy pieces of the wave's NEXT row tile are requested before this tile's math (clamped addresses)
+        const int tcl = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        auto row_of = [&](int nt) -> size_t {
+            const int f = 2 * nt + (l15 >> 3);
+            return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
+        };
+        constexpr bool PF = sizeof(T) == 2;  // (fp32 stream: the extra 24-48 registers spill; it keeps the plain loop)
+        RawC4<T> dnext[BK_MT];
+        if (PF && w < ntile) rawc_load_row<T>(dnext, dy + row_of(w) * FL_H);
         for (int nt = w; nt < ntile; nt += nw) {
             const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
             const bool valid = f < F && t0 + tt < T_;
             const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
+            RawC4<T> dcur[BK_MT];
+            if (PF) {
+#pragma unroll
+                for (int mt = 0; mt < BK_MT; ++mt) dcur[mt] = dnext[mt];
+                rawc_load_row<T>(dnext, dy + row_of(nt + nw < ntile ? nt + nw : nt) * FL_H);
+            } else {
+                rawc_load_row<T>(dcur, dy + row_of(nt) * FL_H);
+            }
             Frag<T> bq;
             if (g4 == 0 && f < F) {
                 frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
@@ -291,8 +323,8 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
             for (int mt = 0; mt < FL_MT; ++mt) {
                 const f32x4 acc = mma(a[mt], bq, F32X4_ZERO);
                 const int ch = 16 * mt + 4 * g4;
-                float dv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (valid) load4(dy + n * FL_H + ch, dv);
+                float dv[4];
+                rawc_get(dcur[mt], dv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dyp[mt][r] = valid ? dv[r] * dsilu_f(acc[r] + bu[ch + r]) : 0.f;
                 if (valid) store4(dyp_out + n * FL_H + ch, dyp[mt][0], dyp[mt][1], dyp[mt][2], dyp[mt][3]);
@@ -309,7 +341,6 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
                 for (int r = 0; r < 4; ++r) {
                     const int ch = 4 * g4 + r;
                     store1(s + ((size_t)ch * FL_TT + tt) * FK + f, dzt[r]);
-                    store1(dz_out + (((size_t)b * T_ + t0 + tt) * FL_SQ + ch) * FKP + f, dzt[r]);
                 }
             }
         }
@@ -317,6 +348,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     PHASE(5);
     lds_barrier();
     PHASE(6);
+    copy_sq_image(dz_out);
 
     // ---- p4: ds = Wf^T dz ; ds_pre = ds * SiLU'(s_pre)  (ds_pre overwrites z) ----
     for (int task = w; task < FL_SQ * mtf; task += nw) {
@@ -360,10 +392,32 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
         for (int mt = 0; mt < BK_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dlw[mt][r] = dlb[mt][r] = 0.f;
+        const int tcl = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        auto row_of = [&](int nt) -> size_t {
+            const int f = 2 * nt + (l15 >> 3);
+            return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
+        };
+        constexpr bool PF = sizeof(T) == 2;
+        RawC4<T> xnext[BK_MT], dnext[BK_MT];
+        if (PF && w < ntile) {
+            rawc_load_row<T>(xnext, x + row_of(w) * FL_H);
+            rawc_load_row<T>(dnext, dy + row_of(w) * FL_H);
+        }
         for (int nt = w; nt < ntile; nt += nw) {
             const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
             const bool valid = f < F && t0 + tt < T_;
             const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
+            RawC4<T> xcur[BK_MT], dcur[BK_MT];
+            if (PF) {
+#pragma unroll
+                for (int mt = 0; mt < BK_MT; ++mt) { xcur[mt] = xnext[mt]; dcur[mt] = dnext[mt]; }
+                const size_t nn = row_of(nt + nw < ntile ? nt + nw : nt);
+                rawc_load_row<T>(xnext, x + nn * FL_H);
+                rawc_load_row<T>(dnext, dy + nn * FL_H);
+            } else {
+                rawc_load_row<T>(xcur, x + row_of(nt) * FL_H);
+                rawc_load_row<T>(dcur, dy + row_of(nt) * FL_H);
+            }
             Frag<T> bq;
             if (g4 == 0 && valid) {
                 frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
@@ -377,7 +431,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
             f32x4 du[BK_MT];
 #pragma unroll
             for (int mt = 0; mt < FL_MT; ++mt) du[mt] = mma(a[mt], bq, F32X4_ZERO);
-            ln_bwd_row96<T>(du, x + n * FL_H, dy + n * FL_H, dx + n * FL_H, stats + n * 2, valid, lnw, dlw, dlb);
+            ln_bwd_row96_raw<T>(du, xcur, dcur, dx + n * FL_H, stats + n * 2, valid, lnw, dlw, dlb);
         }
         ln_affine_flush(dlw, dlb, aff, aff + FL_H);
     }
@@ -423,9 +477,8 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     o[2] = p; p += ws_align(N * FL_SQ * esz);
     o[3] = p; p += ws_align(N * FL_H * esz);
     o[4] = p;
-    // the F..FKP padding columns of s / dz are read by the wgrad staging: keep them zero
-    int e = memset_async_impl(o[0], 2 * ws_align(BT * FL_SQ * FKP * esz), st);
-    if (e) return e;
+    // (the F..FKP padding columns of s / dz, read by the wgrad staging, are written as zeros by the kernel's row copies)
+    int e;
     float* part = (float*)((char*)ws + ws_part_offset(c));
     if (c.F > 32 * FL_KSF_MAX)
         e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
