@@ -57,6 +57,25 @@ def test_validate_test_predict_on_gpu(tmp_path):
     assert (tmp_path / "predict_00000.pt").exists()
 
 
+@pytest.mark.gpu
+def test_large_and_16khz_through_the_cli(tmp_path):
+    """SpatialNet-large ("for large" comments of configs/SpatialNet.yaml) at 16 kHz (n_fft 512 -> 257 bins) through
+    validate / predict; `fit` on the large geometry is refused loudly; the small model trains at 16 kHz"""
+    from nbss_amd._lib import NbssError
+    base = ["--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml"),
+            "--model.arch.dim_input=12", "--model.arch.dim_output=4", "--model.arch.num_freqs=257", "--model.stft.n_fft=512", "--model.stft.n_hop=256",
+            "--data.sample_rate=16000", "--trainer.precision=bf16-mixed", "--data.num_samples=[4,2,2]", "--data.audio_time_len=[1.0,1.0,1.0]"]
+    large = ["--model.arch.num_layers=3", "--model.arch.dim_hidden=192", "--model.arch.dim_ffn=384", "--model.arch.dim_squeeze=16"]
+    rec = TrainCLI(argv=["validate"] + base + large).result
+    assert rec["batches"] >= 1 and all(torch.isfinite(torch.tensor(v)) for v in rec.values())
+    out = TrainCLI(argv=["predict"] + base + large + [f"--trainer.default_root_dir={tmp_path}"]).result["yr_hat"]
+    assert out[0].shape[1:] == (2, 16000) and torch.isfinite(out[0]).all()
+    with pytest.raises((NbssError, NotImplementedError, RuntimeError)):
+        TrainCLI(argv=["fit"] + base + large + ["--trainer.max_epochs=1"])
+    log = TrainCLI(argv=["fit"] + base + ["--model.arch.num_layers=2", "--trainer.max_epochs=2"]).result["log"]
+    assert len(log) == 2 and log[1]["train/neg_si_sdr"] < log[0]["train/neg_si_sdr"]
+
+
 def test_checkpoint_roundtrip_reference_format(tmp_path, emu_lib):
     """save_checkpoint writes what the reference's Lightning trainer reads: `state_dict` with `arch.` keys + `stft.window`
     (general_steps.py:189-199), `optimizer_states[0]` as a torch.optim.Adam state_dict sliced out of the fused optimizer's flat
