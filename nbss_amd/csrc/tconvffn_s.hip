@@ -487,6 +487,9 @@ NBSS_DEV void p6_pack(const float (&v)[12], uint32_t vm, P6& p) {
     for (int i = 0; i < 6; ++i) p.d[i] = pack2bf(v[2 * i], v[2 * i + 1]) & vm;
 }
 NBSS_DEV void p6_gstore(bf16_t* __restrict__ g, const P6& p, bool ok, bool nt) {  // g = &op[group][token][4 h]
+#ifdef NBSS_K1_NOSTORE  // knock-out probe (flavour build): how much of the kernel is the operand stores?
+    return;
+#endif
     if (!ok) return;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -506,6 +509,27 @@ NBSS_DEV void p6_gload(const bf16_t* __restrict__ g, P6& p) {
         p.d[2 * q + 1] = v[1];
     }
 }
+// A run of consecutive frames x the 24 channels of one group leaves an LDS image for its group-major operand tensor as 16-byte pieces of
+// ONE contiguous run (48 bytes per frame), read back by the wave that has just written the rows (same wave: LDS executes in order).
+// The lane-wise form (p6_gstore: three 8-byte stores per lane, each instruction covering 16 of every 48 bytes of a 1.5 KB span) cost a
+// quarter of the kernel: knocked out, tconvffn_bwd went from 12.8 to 10.3 ms per step.
+template <int NPMAX>
+NBSS_DEV void rows_gstore(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < (NPMAX + 63) / 64; ++k) {
+        const int i = lane + 64 * k, tok = i / 3, part = i - 3 * tok;
+        if (i < 3 * nrows && tok < nvalid) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + (size_t)tok * TB_RS + 8 * part);
+#ifndef NBSS_EMU
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part));
+#else
+            *reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part) = v;
+#endif
+        }
+    }
+}
+
 // sum over the 32 lanes of each wave half (lanes sharing lane >> 5)
 NBSS_DEV float half_sum32(float v) {
     v = row_sum16(v);
@@ -652,8 +676,11 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
             p6_store(srow + gl * TS_CG, ph);
             p6_store(brow + gl * TS_CG, p5);  // dh5: picked up by the group waves right after the barrier (image B is free until F2b)
             d1keep[gl] = pd;                  // dSiLU(a1) stays in this wave's registers until the last strip phase
-            p6_gstore(ops.h1 + ((size_t)(4 * gh + gl) * ntok + n0 + t) * TS_CG + 4 * L.h, ph, tv, true);
         }
+        wave_lds_sync();
+#pragma unroll
+        for (int gl = 0; gl < 4; ++gl)
+            rows_gstore<96>(ops.h1 + ((size_t)(4 * gh + gl) * ntok + n0 + 32 * w) * TS_CG, S + (size_t)(4 + 32 * w) * TB_RS + gl * TS_CG, 32, T_ - 32 * w);
     }
     PHASE(2);
     lds_barrier();  // S and the dh5 image are complete; the weight window is dead
@@ -665,6 +692,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     bf16_t* Ac = A + gl * TS_CG + 4 * L.h;
     bf16_t* Bc = Bi + gl * TS_CG + 4 * L.h;
     const size_t gbase = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;
+    // the wave's own run of frames [32 s_beg, 32 s_end) of an operand tensor / of the spatial image at stage bases (bl, bu)
+    const int run0 = 32 * s_beg, nrun = 32 * (s_end - s_beg);
+    auto run_gstore = [&](bf16_t* __restrict__ op, int bl, int bu) {
+        wave_lds_sync();
+        rows_gstore<128 * 3>(op + ((size_t)g * ntok + n0 + run0) * TS_CG, Sc + (size_t)((th ? bu : bl) + run0) * TB_RS, nrun, T_ - run0);
+    };
     auto rowp = [&](int tt, int bl, int bu) -> const bf16_t* { return Sc + (size_t)((tt < TS ? bl : bu) + tt) * TB_RS; };
     auto orow = [&](int tt, int bl, int bu) -> bf16_t* { return Sc + (size_t)((th ? bu : bl) + tt) * TB_RS + 4 * L.h; };
     // Backward convs: the halves shift TOWARDS each other, so the one row a wave reads across the middle (frame TS for the lower half,
@@ -737,9 +770,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
                 p6_pack(dv, vm, pd);
                 p6_store(orow(t, 3, 5), ph);
                 p6_store(Ac + (size_t)t * TB_RS, pd);
-                p6_gstore(ops.h2 + gbase + (size_t)t * TS_CG, ph, tv, true);
             }
     }
+    run_gstore(ops.h2, 3, 5);
     load_wfrags<5>(wa, W.C1T, g, L.lane);  // conv1 is done: its transposed weights arrive long before B1 needs them
     PHASE(4);
     lds_barrier();
@@ -806,8 +839,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
         p6_pack(hv, vm, ph);
         p6_store(Bc + (size_t)t * TB_RS, pn);
         p6_store(r, ph);
-        p6_gstore(ops.h4 + gbase + (size_t)t * TS_CG, ph, tv, true);
     }
+    run_gstore(ops.h4, 2, 6);
     PHASE(8);
     lds_barrier();
     PHASE(9);
@@ -846,10 +879,10 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
                 p6_pack(hv, vm, ph);
                 p6_pack(dv, vm, pd);
                 p6_store(orow(t, 1, 7), pd);
-                p6_gstore(ops.h5 + gbase + (size_t)t * TS_CG, ph, tv, true);
-                p6_gstore(ops.da5 + gbase + (size_t)t * TS_CG, pd, tv, true);
+                p6_gstore(ops.h5 + gbase + (size_t)t * TS_CG, ph, tv, true);  // (h5 never enters an image: lane-wise)
             }
     }
+    run_gstore(ops.da5, 1, 7);
     load_wfrags<5>(wc, W.C3T, g, L.lane);  // (behind F3's operand stores; a separate register set requested before F3 measured the same)
     PHASE(10);
     lds_barrier();
@@ -933,8 +966,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
             for (int q = 0; q < 12; ++q) dn[q] = grstd * (gw[q] * dn[q] - msa - ah[q] * msb);
             p6_pack(dn, vm, po);
             p6_store(r, po);
-            p6_gstore(ops.da3 + gbase + (size_t)t * TS_CG, po, tv, true);
         }
+        run_gstore(ops.da3, 2, 6);
     }
     PHASE(14);
     lds_barrier();
@@ -965,9 +998,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
                 for (int r = 0; r < 12; ++r) o[r] = dh2[r] * d2[r];
                 p6_pack(o, vm, po);
                 p6_store(orow(t, 3, 5), po);
-                p6_gstore(ops.da2 + gbase + (size_t)t * TS_CG, po, tv, true);
             }
     }
+    run_gstore(ops.da2, 3, 5);
     if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 5 : 2) * TB_RS + 4 * L.lane) = (u32x2){0u, 0u};
     PHASE(16);
     lds_barrier();
@@ -1012,8 +1045,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
 #pragma unroll
             for (int r = 0; r < 12; ++r) dh[r] *= d1[r];
             p6_pack(dh, lane_mask(tv), po);
-            p6_gstore(ops.da1 + ((size_t)(4 * gh + q) * ntok + n0 + t) * TS_CG + 4 * L.h, po, tv, true);
+            p6_store(S + (size_t)(4 + t) * TB_RS + q * TS_CG + 4 * L.h, po);  // in place (this lane's own piece), then out as whole rows
         }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rows_gstore<96>(ops.da1 + ((size_t)(4 * gh + q) * ntok + n0 + 32 * w) * TS_CG, S + (size_t)(4 + 32 * w) * TB_RS + q * TS_CG, 32, T_ - 32 * w);
     }
 #undef TB_BLOCKS
     // GroupNorm affine partial sums of this workgroup's 96 channels -> its `part` row (entries [0, 2 FFN); the tail kernel writes the rest)
