@@ -1064,10 +1064,10 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
 static int tconvffn_bwd_bf16(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                              float* stats, void* const* opsv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
+    ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
     int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, st);
     if (e) return e;
     const bf16_t* pk = (const bf16_t*)packed;
-    ProfScope ps(PK_TCF_B, st);
     NBSS_LAUNCH((tconvffn_du_kernel<bf16_t>), dim3(c.B * c.F), dim3(1024), 36 * 512 * sizeof(bf16_t) + 3 * TF_H * sizeof(float), st, c, lp, part, pk + pack_off(c, layer, K_TF_W1_TN),
                 (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, stats, (const bf16_t*)opsv[4]);
     return NBSS_CHECK_LAUNCH();
