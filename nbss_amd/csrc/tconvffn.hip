@@ -1058,14 +1058,29 @@ __global__ __launch_bounds__(1024) void tconvffn_du_kernel(nbss_cfg c, LayerPtrs
 }
 
 int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* x, const void* dy,
-                          void* const* opsv, hipStream_t st);
+                          void* const* opsv, float* stats, int pstride, hipStream_t st);
+struct TailArgs;
+int tailw_tconvffn(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
+                   const void* da1, float* wgpart, float* G, const float* P, hipStream_t st);
 
-// bf16 stream: data-gradient kernel of tconvffn_s.hip + the tail kernel above (same operand tensors, same `part` rows as the group-serial kernel)
-static int tconvffn_bwd_bf16(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
-                             float* stats, void* const* opsv, hipStream_t st) {
+// the tail (du, LayerNorm backward, dx) runs inside the W1 weight-gradient kernel (tailw.hip) unless built with -DNBSS_NO_TAILW (A/B flavour)
+#ifdef NBSS_NO_TAILW
+#define TF_FUSED_TAIL 0
+#else
+#define TF_FUSED_TAIL 1
+#endif
+
+// bf16 stream: data-gradient kernel of tconvffn_s.hip + the tail (same operand tensors, same `part` rows as the group-serial kernel)
+static int tconvffn_bwd_bf16(const nbss_cfg& c, const float* P, float* G, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                             float* stats, void* const* opsv, float* wgpart, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
-    int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, st);
+    if (TF_FUSED_TAIL) {
+        int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, stats, 2 * TF_FFN, st);
+        if (e) return e;
+        return tailw_tconvffn(c, lp, packed, layer, x, dy, dx, stats, opsv[4], wgpart, G, P, st);
+    }
+    int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, nullptr, TF_AFF, st);
     if (e) return e;
     const bf16_t* pk = (const bf16_t*)packed;
     NBSS_LAUNCH((tconvffn_du_kernel<bf16_t>), dim3(c.B * c.F), dim3(1024), 36 * 512 * sizeof(bf16_t) + 3 * TF_H * sizeof(float), st, c, lp, part, pk + pack_off(c, layer, K_TF_W1_TN),
@@ -1105,18 +1120,20 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     void* ops[8];
     for (int i = 0; i < 8; ++i) ops[i] = base + (size_t)i * ws_align(N * TF_FFN * esz);
     float* part = (float*)((char*)ws + ws_part_offset(c));
-    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_bf16(c, P, part, packed, layer, x, dy, dx, stats, ops, st)
+    float* wgpart = (float*)((char*)ws + ws_wgpart_offset(c));
+    const bool fused = c.dtype == NBSS_BF16 && TF_FUSED_TAIL;  // the tail kernel contracted dW1 / db1 and reduced the LayerNorm affine sums
+    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_bf16(c, P, G, part, packed, layer, x, dy, dx, stats, ops, wgpart, st)
                                  : tconvffn_bwd_t<float>(c, P, part, packed, layer, x, dy, dx, stats, ops, st);
     if (e) return e;
     AffSegs sg;
-    sg.n = 4;
+    sg.n = fused ? 2 : 4;
     sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
     sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
     sg.off[2] = param_off(c, layer, P_TF_LN_W); sg.cnt[2] = TF_H;
     sg.off[3] = param_off(c, layer, P_TF_LN_B); sg.cnt[3] = TF_H;
     if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
     WgradArgs a;
-    a.part = (float*)((char*)ws + ws_wgpart_offset(c));
+    a.part = wgpart;
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
@@ -1137,6 +1154,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
         a.dW = G + param_off(c, layer, convW[k]); a.dbias = G + param_off(c, layer, convBias[k]);
         if ((e = wgrad_launch(a, c.dtype, st))) return e;
     }
+    if (fused) return NBSS_OK;
     // W1: dW1[FFN][H] = da1^T LN(x) ; db1 = colsum(da1)
     a.A = ops[4]; a.lda = TF_FFN; a.MA = TF_FFN; a.B = x; a.ldb = TF_H; a.NB = TF_H; a.groups = 1; a.taps = 1;
     a.a_gw = ogw; a.a_gs = ogs; a.b_gw = 0; a.b_gs = 0;

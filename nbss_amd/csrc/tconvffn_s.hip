@@ -551,7 +551,7 @@ NBSS_DEV void conv_bfrags3(const TsLane& L, const bf16_t* r0, const bf16_t* r1, 
 }
 
 __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPtrs lp, TsBwdW W, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                             float* __restrict__ part, TsOps ops) {
+                                                             float* __restrict__ part, TsOps ops, float* __restrict__ stats, int pstride) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);             // [NT + TB_PAD][TB_RS]
@@ -633,6 +633,10 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
             }
         sq += __shfl_xor(sq, 32);
         const float rstd = rsqrtf(sq * (1.0f / TS_H) + 1e-5f);
+        if (stats && gh == 0 && tv && L.h == 0) {  // LayerNorm row statistics for the fused tail / weight-gradient kernel (tailw.hip)
+            stats[(n0 + t) * 2] = mean;
+            stats[(n0 + t) * 2 + 1] = rstd;
+        }
         FragH u[7], dq[6];
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
@@ -1056,14 +1060,15 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_s_kernel(nbss_cfg c, LayerPt
     // GroupNorm affine partial sums of this workgroup's 96 channels -> its `part` row (entries [0, 2 FFN); the tail kernel writes the rest)
     for (int i = tid; i < 2 * 96; i += blockDim.x) {
         const int kind = i / 96, ch = i % 96;
-        part[(size_t)row * (2 * TS_FFN + 2 * TS_H) + kind * TS_FFN + gh * 96 + ch] = gnp[(0 * 2 + kind) * 96 + ch] + gnp[(1 * 2 + kind) * 96 + ch];
+        part[(size_t)row * pstride + kind * TS_FFN + gh * 96 + ch] = gnp[(0 * 2 + kind) * 96 + ch] + gnp[(1 * 2 + kind) * 96 + ch];
     }
     PHASE_END();
 }
 PHASE_READER(nbss_phase_read_tconvffn_bwd_s)
 
+// stats != nullptr: the kernel also writes the LayerNorm (mean, rstd) rows; pstride = floats per `part` row (GroupNorm sums in [0, 2 FFN))
 int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* x, const void* dy,
-                          void* const* opsv, hipStream_t st) {
+                          void* const* opsv, float* stats, int pstride, hipStream_t st) {
     if (c.dtype != NBSS_BF16 || c.T > 256) return NBSS_EUNSUPPORTED;
     const size_t NT = (size_t)((c.T + 31) / 32) * 32;
     const size_t a_el = NT * TB_RS > (size_t)52 * 512 ? NT * TB_RS : (size_t)52 * 512;
@@ -1076,6 +1081,6 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     int e = NBSS_SET_MAX_LDS(tconvffn_bwd_s_kernel, lds);
     if (e) return e;
     // (timed by the caller's ProfScope together with the tail kernel: one "launch" of the sub-block in bench.py's roofline line)
-    NBSS_LAUNCH(tconvffn_bwd_s_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, (const bf16_t*)x, (const bf16_t*)dy, part, ops);
+    NBSS_LAUNCH(tconvffn_bwd_s_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, (const bf16_t*)x, (const bf16_t*)dy, part, ops, stats, pstride);
     return NBSS_CHECK_LAUNCH();
 }

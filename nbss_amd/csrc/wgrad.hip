@@ -522,6 +522,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb, 
     }
 }
 
+// second pass alone, for kernels that write partial tiles in wgrad_tr3_kernel's layout themselves (tailw.hip)
+int wgrad_reduce_launch(const WgradArgs& a, int ntot, int xb, hipStream_t st) {
+    NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot, xb < WG_RSL ? xb : WG_RSL, 1), dim3(256), 0, st, a, xb, 1);
+    return NBSS_CHECK_LAUNCH();
+}
+
 template <class T>
 static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
@@ -576,7 +582,8 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
             if (fmode3) {
                 if (need <= 5) W3_GO(96, 5);
                 else W3_GO(96, 14);
-            } else if (need <= 5) W3_GO(64, 5);
+            } else if (need <= 2) W3_GO(64, 2);  // squeeze / unsqueeze (6 tiles for 8 waves): no dummy slots
+            else if (need <= 5) W3_GO(64, 5);
             else if (need <= 10) W3_GO(64, 10);
             else W3_GO(64, 14);
 #undef W3_GO
