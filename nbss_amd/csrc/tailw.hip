@@ -236,7 +236,9 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
     if (need > wgpart_bytes) return NBSS_EUNSUPPORTED;
     t.part = wgpart;
     t.affpart = wgpart + (size_t)grid * ntot * 272;
-    int e = MA == 192 ? tailw_go<192, 2>(t, grid, st) : MA == 288 ? tailw_go<288, 1>(t, grid, st) : NBSS_EUNSUPPORTED;
+    // (MA = 288, the attention's in_proj, is the same template: its 108 tiles are 27 per accumulator wave and spill 78 registers; with 6
+    //  accumulator + 2 tail waves the tail path spills instead (9 k-steps of W^T fragments) — not instantiated until one of them fits)
+    int e = MA == 192 ? tailw_go<192, 2>(t, grid, st) : NBSS_EUNSUPPORTED;
     if (e) return e;
     WgradArgs a;
     a.A = nullptr; a.lda = MA; a.MA = MA; a.B = nullptr; a.ldb = TW_H; a.NB = TW_H; a.groups = 1; a.mvalid = 0; a.nvalid = 0; a.taps = 1;
