@@ -214,7 +214,12 @@ NBSS_DEV void fconv_bfrag(Frag<T>& bq, const T* __restrict__ u, int rstride, int
 
 // NW = waves per workgroup: 8 (= the conv groups), or 9 when the row phases have a multiple of 9 units (F = 129: 9 frequency tiles x 2
 // frames = 18 units, which 8 waves take in 3 rounds with 6 of them idle in the last); the ninth wave sits out the group phases.
-template <class T, int TT, int NW>
+// WGF: the conv weight gradient is contracted here too (bf16, TT = 2): between phase 1 and phase 2 both of its operands — dv and LN(x) — sit
+// in the two LDS images as row-major [frequency][channel] arrays, which is what a token-contraction needs: transposing reads give MFMA
+// fragments with K = 32 frequencies, wave g accumulates dW[g][12 x 12] per tap (5 tiles) + the bias column sums, and the workgroup's partial
+// goes out as one row (the whole [96][12][5] weight + [96] bias in dW's own memory order) behind its affine sums; affine_reduce folds the rows.
+// The separate path wrote dv (S) and had wgrad.hip read dv + x (2 S) again: 0.6 GB per f-conv at batch 32 against 2 x 94 MB of partial rows.
+template <class T, int TT, int NW, bool WGF>
 __global__ __launch_bounds__(64 * NW, NW > 8 ? 3 : 2)  // (9 waves: one SIMD hosts three of them -> at most 168 VGPRs)
 void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ cb,
                       const float* __restrict__ slope, float* __restrict__ part, const T* __restrict__ Wp, const T* __restrict__ WpT,
@@ -284,7 +289,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     auto row_fwd = [&](int ti, const Frag<T> (&xq)[BK_KS], const Frag<T> (&dq)[BK_KS], float mean, float rstd) {
         const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15, t = t0 + tt;
         const bool valid = f < F && t < T_;
-        if (valid && g4 == 0) {
+        if (!WGF && valid && g4 == 0) {  // (row statistics: only the separate weight-gradient kernel needs them)
             const size_t n = ((size_t)b * F + f) * T_ + t;
             stats[n * 2] = mean;
             stats[n * 2 + 1] = rstd;
@@ -374,6 +379,48 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     lds_barrier();
     PHASE(3);
 
+    constexpr int PROW = 3 * FC_H + FC_H * FC_CG * 5 + FC_H;  // floats per partial row (layout.h NBSS_FC_PROW)
+    if constexpr (WGF) {
+        // ---- weight gradient of group w: dW[o][i][tap] = sum_{f,tt} dv[f][o] LN(x)[f + tap - 2][i], db[o] = sum dv[f][o] ----
+        if (gwave) {
+            f32x4 wacc[5], bsum = F32X4_ZERO;
+#pragma unroll
+            for (int tap = 0; tap < 5; ++tap) wacc[tap] = F32X4_ZERO;
+            Frag<T> ones;
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) frag_set(ones, jq, 1.0f);
+            const int nk = cdiv(mtf * 16, 32);
+            const bool odd = (mtf & 1) != 0;  // the last k-step has 16 real rows: the upper halves of the fragments are cleared
+            const int roff = (4 * g4 + (l15 >> 2)) * ROW + w * FC_CG + 4 * (l15 & 3);
+            for (int tt = 0; tt < TT; ++tt)
+                for (int ks = 0; ks < nk; ++ks) {
+                    const bool half = odd && ks == nk - 1;
+                    Frag<T> fa;
+                    frag_load_tr(fa, dvb + (size_t)(2 + 32 * ks) * ROW + tt * FC_LD + roff, ROW);
+                    if (half) frag_zero_hi(fa);
+                    bsum = mma(fa, ones, bsum);
+#pragma unroll
+                    for (int tap = 0; tap < 5; ++tap) {
+                        Frag<T> fb;
+                        frag_load_tr(fb, u + (size_t)(32 * ks + tap) * ROW + tt * FC_LD + roff, ROW);
+                        if (half) frag_zero_hi(fb);
+                        wacc[tap] = mma(fa, fb, wacc[tap]);
+                    }
+                }
+            // C tile: lane = input channel i (l15), rows = output channels 4 g4 + r; valid 12 x 12
+            float* prow = part + (size_t)blockIdx.x * PROW + 3 * FC_H;
+            if (l15 < FC_CG && g4 < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = w * FC_CG + 4 * g4 + r;
+#pragma unroll
+                    for (int tap = 0; tap < 5; ++tap) prow[((size_t)o * FC_CG + l15) * 5 + tap] = wacc[tap][r];
+                    if (l15 == 0) prow[FC_H * FC_CG * 5 + o] = bsum[r];
+                }
+            }
+        }
+    }
+
     // ---- phase 2 (groups): transposed conv -> du into the u image; dv rows -> global ----
     for (int ti = 0; ti < (gwave ? ntile : 0); ++ti) {
         const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15;
@@ -386,7 +433,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
         }
         if (cvalid) store4(u + (size_t)(f + 2) * ROW + tt * FC_LD + ch, acc[0], acc[1], acc[2], acc[3]);
     }
-    {
+    if (!WGF) {
         constexpr int VN = VecOf<T>::N, VPR = FC_H / VN;
         for (int i = tid; i < F * TT * VPR; i += blockDim.x) {
             const int f = i / (TT * VPR), rem = i % (TT * VPR), tt = rem / VPR, off = (rem % VPR) * VN;
@@ -460,13 +507,13 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     }
     PHASE(6);
     lds_barrier();
-    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) part[(size_t)blockIdx.x * 3 * FC_H + i] = aff[i];
+    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) part[(size_t)blockIdx.x * (WGF ? PROW : 3 * FC_H) + i] = aff[i];
     PHASE(7);
     PHASE_END();
 }
 PHASE_READER(nbss_phase_read_fconv_bwd)
 
-template <class T, int TT, int NW>
+template <class T, int TT, int NW, bool WGF>
 static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                        float* stats, void* dv, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
@@ -475,11 +522,11 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T, TT, NW>), lds);
+    int e = NBSS_SET_MAX_LDS((fconv_bwd_kernel<T, TT, NW, WGF>), lds);
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, TT)), block(64 * NW);
     ProfScope ps(PK_FCONV_B, st);
-    NBSS_LAUNCH((fconv_bwd_kernel<T, TT, NW>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
+    NBSS_LAUNCH((fconv_bwd_kernel<T, TT, NW, WGF>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
                 P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), part, pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
                 pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv);
     return NBSS_CHECK_LAUNCH();
@@ -501,18 +548,28 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     // (F > 160, the 16-kHz geometry: the two images of a 2-frame slab no longer fit the LDS -> one frame per workgroup; the fp32 stream
     //  images of even one frame are 229 KB at F = 257: fconv_bwd_t returns NBSS_EUNSUPPORTED there, fp32 TRAINING stops at F = 160)
     const bool big = c.F > 16 * FC_MTF_MAX;
-    int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1, 8>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-            : big                ? fconv_bwd_t<bf16_t, 1, 8>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-            : nine               ? fconv_bwd_t<bf16_t, FC_BWD_TT, 9>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
-                                 : fconv_bwd_t<bf16_t, FC_BWD_TT, 8>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
+#ifdef NBSS_FC_NOWGF
+    const bool fused = false;
+#else
+    const bool fused = c.dtype == NBSS_BF16 && !big;  // the conv weight gradient is contracted inside the kernel (two-frame bf16 slabs)
+#endif
+    if (fused) part = (float*)((char*)ws + ws_fcpart_offset(c));
+    int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1, 8, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : big                ? fconv_bwd_t<bf16_t, 1, 8, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : fused              ? fconv_bwd_t<bf16_t, FC_BWD_TT, 8, true>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : nine               ? fconv_bwd_t<bf16_t, FC_BWD_TT, 9, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+                                 : fconv_bwd_t<bf16_t, FC_BWD_TT, 8, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
     if (e) return e;
     const int nwg = c.dtype == NBSS_BF16 && !big ? c.B * cdiv(c.T, FC_BWD_TT) : c.B * c.T;
     AffSegs sg;
-    sg.n = 3;
+    sg.n = fused ? 5 : 3;
     sg.off[0] = param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); sg.cnt[0] = FC_H;
     sg.off[1] = param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B); sg.cnt[1] = FC_H;
     sg.off[2] = param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU); sg.cnt[2] = FC_H;
+    sg.off[3] = param_off(c, layer, which ? P_FC2_W : P_FC1_W); sg.cnt[3] = FC_H * FC_CG * 5;  // partial rows carry dW / db in their own order
+    sg.off[4] = param_off(c, layer, which ? P_FC2_B : P_FC1_B); sg.cnt[4] = FC_H;
     if ((e = affine_reduce_launch(part, nwg, sg, G, st))) return e;
+    if (fused) return NBSS_OK;
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));

@@ -211,10 +211,15 @@ NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // frequencies: the cross-band kernels keep the whole F axis of a slab on chip: 17 tiles of 16 (n_fft 512 -> F = 257; fp32 backward: F <= 160)
 #define NBSS_F_MAX 272
 #define NBSS_T_MAX 4096
+// fconv_bwd with the fused weight gradient (bf16, two frames per workgroup): one partial row per workgroup = the affine sums (3 H) + the
+// whole conv weight gradient [H][H / groups][ks] + its bias [H] as this workgroup's two frames see it; affine_reduce folds the rows
+#define NBSS_FC_PROW(c) (3 * (c).H + (c).H * ((c).H / (c).f_groups) * (c).f_ks + (c).H)
+NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * ((c.T + 1) / 2) * NBSS_FC_PROW(c) * sizeof(float); }
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
-    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) + 256;
+    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) +
+           ws_align(fc_part_bytes(c)) + 256;
 }
 // attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32
 NBSS_HD size_t mhsa_lse_offset(const nbss_cfg& c) {
@@ -236,6 +241,9 @@ NBSS_HD size_t ws_wgpart_offset(const nbss_cfg& c) {
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
     return ws_part_offset(c) + ws_align(nwg * 576 * sizeof(float));
 }
+
+// the fused f-conv weight-gradient partial rows live behind the wgrad partial tiles
+NBSS_HD size_t ws_fcpart_offset(const nbss_cfg& c) { return ws_wgpart_offset(c) + ws_align(WGPART_BYTES); }
 
 NBSS_HD int check_cfg(const nbss_cfg& c) {
     if (c.B <= 0 || c.F <= 0 || c.T <= 0 || c.L <= 0) return NBSS_EINVAL;
