@@ -9,8 +9,11 @@
 //   * all 8 waves contract the chunk's dW tiles (A = da image, B = LN(x) image, K = the 64 tokens),
 //   * waves 0-3 then take one 16-token tile each: du = W^T da with the B operand straight from the da image rows (natural K order) and the
 //     W^T fragments resident in LDS, LayerNorm backward in registers (x, dy as 8-byte C-layout pieces, requested before the MFMA section),
-//     dx stored, LayerNorm affine gradients accumulated per lane and flushed once per workgroup.
-// Partial dW tiles go to wgrad_reduce_kernel (wgrad.hip), the affine partial rows to affine_reduce.
+//     dx stored.
+// The LayerNorm affine gradients need no per-token work at all: the B image holds xhat = (x - mean) rstd (not LN(x)), so the contraction
+// yields D = da^T xhat, and with db = colsum(da):   dW = D gamma + db (x) beta,   dgamma[i] = sum_o W[o][i] D[o][i],   dbeta[i] = sum_o W[o][i] db[o]
+// (du = W^T da summed against xhat / 1 over the tokens, reordered) — tailw_finalize_kernel applies them while it folds the partial tiles.
+// (48 per-lane accumulators for dgamma / dbeta were what kept the tail path above 256 registers.)
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"
@@ -31,21 +34,23 @@ struct TailArgs {
     const float* beta;
     const bf16_t* WT;     // packed W^T fragments [6][MA/32][64][8] (K_TF_W1_TN / K_INP_TN: rows = H, K = MA natural)
     float* part;          // [grid][ntot][256] partial dW tiles | [grid][ntot][16] bias sums (WGPART region)
-    float* affpart;       // [grid][2 * 96] LayerNorm affine partial sums
     int Ntok;
 };
 
 // Wave specialisation: waves 4-7 hold ALL dW accumulators (NTOT / 4 tiles each), waves 0-3 run the tail.  The two roles are two
 // separate chunk loops (same sequence of barriers) so that their register sets — 27 accumulator tiles for in_proj on one side, du / x / dy /
 // affine sums on the other — have disjoint live ranges; as one loop with `if (w < 4)` inside, both sets stayed live and 65-146 VGPRs spilled.
-template <int MA, int NBUF>
+// NTW = tail waves: 4 (one 16-token tile of the chunk each, 4 accumulator waves) or 2 (two tiles each, 6 accumulator waves: in_proj's
+// 108 tiles are 18 per wave then instead of 27, which did not fit the register file)
+template <int MA, int NBUF, int NTW>
 __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     constexpr int LDA = MA + 16;                    // image row strides == 16 (mod 32) elements: wgrad.hip tr_ld()
     constexpr int LDX = 112;                        // 96 + 16
     constexpr int IMGA = TW_KC * LDA, IMG = IMGA + TW_KC * LDX;
     constexpr int MTA = MA / 16, NTB = TW_H / 16, NTOT = MTA * NTB;  // tile tl = nt * MTA + mt
-    constexpr int NSW = (NTOT + 3) / 4;              // tile slots of a wgrad wave
-    constexpr int BSW = (MTA + 3) / 4;               // slots that can hold nt == 0 tiles (bias sums)
+    constexpr int NWW = 8 - NTW;                     // accumulator waves
+    constexpr int NSW = (NTOT + NWW - 1) / NWW;      // tile slots of an accumulator wave
+    constexpr int BSW = (MTA + NWW - 1) / NWW;       // slots that can hold nt == 0 tiles (bias sums)
     constexpr int KSW = MA / 32;                     // k-steps of du = W^T da
     constexpr int PA = MA / 8, NVA = TW_KC * PA, NVX = TW_KC * (TW_H / 8);
     constexpr int UA = (NVA + TW_THREADS - 1) / TW_THREADS, UX = (NVX + TW_THREADS - 1) / TW_THREADS;  // whole vector slots: da | x
@@ -53,12 +58,11 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     NBSS_LDS(smem);
     bf16_t* base = reinterpret_cast<bf16_t*>(smem);
     bf16_t* wl = base + (size_t)NBUF * IMG;                       // W^T fragments
-    float* lnp = reinterpret_cast<float*>(wl + 6 * KSW * 512);    // gamma | beta
-    float* affl = lnp + 2 * TW_H;                                 // LN weight | bias gradient sums of this workgroup
+    float* lnp = reinterpret_cast<float*>(wl + 6 * KSW * 512);    // LayerNorm gamma (du is scaled by it in the tail)
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id_u();
     for (int i = tid; i < NBUF * IMG / 2; i += TW_THREADS) reinterpret_cast<uint32_t*>(base)[i] = 0u;
     for (int i = tid; i < 6 * KSW * 64; i += TW_THREADS) reinterpret_cast<u32x4*>(wl)[i] = reinterpret_cast<const u32x4*>(a.WT)[i];
-    for (int i = tid; i < 4 * TW_H; i += TW_THREADS) lnp[i] = i < TW_H ? a.gamma[i] : i < 2 * TW_H ? a.beta[i - TW_H] : 0.f;
+    for (int i = tid; i < TW_H; i += TW_THREADS) lnp[i] = a.gamma[i];
 
     const int nchunks = cdiv(a.Ntok, TW_KC);
     // staging: slot u < UA is a da piece for every thread, the rest x pieces (a few lanes of the last slot of each kind idle)
@@ -93,15 +97,13 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
 #pragma unroll
         for (int u = 0; u < UX; ++u) {
             const int v = tid + u * TW_THREADS, r = v / (TW_H / 8), col = (v % (TW_H / 8)) * 8;
-            if (v < NVX) {  // LayerNorm on the fly (rows past Ntok: rstd = 0, they stay 0)
+            if (v < NVX) {  // xhat on the fly (rows past Ntok: rstd = 0, they stay 0)
                 u32x4 xq = preX[u];
-                float f[8], gm[8], bt[8];
+                float f[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(xq[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(xq[i] >> 16)); }
-                load8(lnp + col, gm);
-                load8(lnp + TW_H + col, bt);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = prs[u] != 0.f ? (f[e] - pmu[u]) * prs[u] * gm[e] + bt[e] : 0.f;
+                for (int e = 0; e < 8; ++e) f[e] = (f[e] - pmu[u]) * prs[u];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xq[i] = pack2bf(f[2 * i], f[2 * i + 1]);
                 *reinterpret_cast<u32x4*>(buf + IMGA + r * LDX + col) = xq;
@@ -113,9 +115,9 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     if (ch < nchunks) prefetch(ch);
     lds_barrier();  // zero fill, fragments, gamma / beta
     int b = 0;
-    if (w >= 4) {
-        // ================= weight-gradient waves: tile tl = 4 s + (w - 4) =================
-        const int w4 = w - 4;
+    if (w >= NTW) {
+        // ================= weight-gradient waves: tile tl = NWW s + (w - NTW) =================
+        const int w4 = w - NTW;
         f32x4 acc[NSW], bacc[BSW];
 #pragma unroll
         for (int s = 0; s < NSW; ++s) acc[s] = F32X4_ZERO;
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
         for (int jq = 0; jq < 8; ++jq) frag_set(ones, jq, 1.0f);
         const int toff = (4 * g4 + (l15 >> 2)), tcol = 4 * (l15 & 3);
         const int la = toff * LDA + tcol, lb = IMGA + toff * LDX + tcol;
-        auto off_a = [&](int s) { const int tl = 4 * s + w4; return la + (tl < NTOT ? tl % MTA : 0) * 16; };  // slots past the last tile
-        auto off_b = [&](int s) { const int tl = 4 * s + w4; return lb + (tl < NTOT ? tl / MTA : 0) * 16; };  // re-contract tile 0: never flushed
+        auto off_a = [&](int s) { const int tl = NWW * s + w4; return la + (tl < NTOT ? tl % MTA : 0) * 16; };  // slots past the last tile
+        auto off_b = [&](int s) { const int tl = NWW * s + w4; return lb + (tl < NTOT ? tl / MTA : 0) * 16; };  // re-contract tile 0: never flushed
         for (; ch < nchunks; ch += gridDim.x) {
             bf16_t* buf = base + (size_t)b * IMG;
             stash(buf);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
         float* pbias = a.part + (size_t)gridDim.x * NTOT * 256 + wg * NTOT * 16;
 #pragma unroll
         for (int s = 0; s < NSW; ++s) {
-            const int tl = 4 * s + w4;
+            const int tl = NWW * s + w4;
             if (tl < NTOT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[s][r];
@@ -169,17 +171,8 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
         }
     } else {
         // ================= tail waves: 16 tokens of the chunk each =================
-        float dlw[BK_MT][4], dlb[BK_MT][4];
-#pragma unroll
-        for (int mt = 0; mt < BK_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dlw[mt][r] = dlb[mt][r] = 0.f;
-        for (; ch < nchunks; ch += gridDim.x) {
-            bf16_t* buf = base + (size_t)b * IMG;
-            stash(buf);
-            lds_barrier();
-            if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
-            const long nt0 = (long)ch * TW_KC + 16 * w + l15;
+        auto tail_tile = [&](const bf16_t* buf, int ch, int tile) {
+            const long nt0 = (long)ch * TW_KC + 16 * tile + l15;
             const bool tv = nt0 < a.Ntok;
             const size_t nrow = (size_t)(tv ? nt0 : a.Ntok - 1);  // clamped address, validity applied on use
             RawC4<bf16_t> xr[BK_MT], dr[BK_MT];
@@ -188,8 +181,8 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
             f32x4 du[BK_MT];
 #pragma unroll
             for (int mt = 0; mt < BK_MT; ++mt) du[mt] = F32X4_ZERO;
-            const bf16_t* arow = buf + (size_t)(16 * w + l15) * LDA + 8 * g4;  // B operand: the token's da row, natural K order
-#pragma unroll
+            const bf16_t* arow = buf + (size_t)(16 * tile + l15) * LDA + 8 * g4;  // B operand: the token's da row, natural K order
+#pragma unroll(KSW > 6 ? 1 : KSW)  // (9 k-steps unrolled: the scheduler hoists all 54 W^T fragment reads, 216 registers)
             for (int ks = 0; ks < KSW; ++ks) {
                 Frag<bf16_t> df;
                 frag_load(df, arow + 32 * ks);
@@ -200,56 +193,89 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
                     du[mt] = mma(af, df, du[mt]);
                 }
             }
-            ln_bwd_row96_raw<bf16_t>(du, xr, dr, a.dx + nrow * TW_H, nullptr, tv, lnp, dlw, dlb);
+            ln_bwd_row96_raw_na<bf16_t>(du, xr, dr, a.dx + nrow * TW_H, tv, lnp);
+        };
+        for (; ch < nchunks; ch += gridDim.x) {
+            bf16_t* buf = base + (size_t)b * IMG;
+            stash(buf);
+            lds_barrier();
+            if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
+#pragma unroll 1  // (two tiles inlined side by side were scheduled together: twice the live registers)
+            for (int tile = w; tile < TW_KC / 16; tile += NTW) tail_tile(buf, ch, tile);
             if (NBUF == 1) lds_barrier();
             else b ^= 1;
         }
-        ln_affine_flush(dlw, dlb, affl, affl + TW_H);
     }
-    lds_barrier();
-    for (int i = tid; i < 2 * TW_H; i += TW_THREADS) a.affpart[(size_t)blockIdx.x * 2 * TW_H + i] = affl[i];
 }
 
-// One launch: partial tiles -> wgrad_reduce (dW, db), affine partial rows -> affine_reduce (LN weight / bias gradients).
-// `wa` carries the reduce's view of the problem (MA, NB = 96, dW, dbias, part).
-int wgrad_reduce_launch(const WgradArgs& a, int ntot, int xb, hipStream_t st);
+// Second pass: block (tile, slice) sums its slice of the workgroups' partial D tiles (and the bias sums of the tile's rows) and adds
+//   dW[o][i] += D gamma[i] + db[o] beta[i],   db[o] (nt == 0 tiles),   dgamma[i] += sum_o W[o][i] D[o][i],   dbeta[i] += sum_o W[o][i] db[o]
+// W = the fp32 master weight [MA][96].  Tile tl = nt * MTA + mt; thread (r = tid >> 6, lane): row 16 mt + 4 (lane >> 4) + r, column 16 nt + (lane & 15).
+#define TW_RSL 8
+__global__ __launch_bounds__(256) void tailw_finalize_kernel(const float* __restrict__ part, int xb, int MTA, const float* __restrict__ W,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
+                                                             float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    NBSS_LDS(smem);
+    float (*red)[4][16] = reinterpret_cast<float (*)[4][16]>(smem);  // [2][4 waves][16 columns]
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int ntot = gridDim.x, tl = blockIdx.x, nt = tl / MTA, mt = tl % MTA;
+    const int x0 = (int)((long)xb * blockIdx.y / gridDim.y), x1 = (int)((long)xb * (blockIdx.y + 1) / gridDim.y);
+    const float* pt = part + (size_t)tl * 256 + tid;
+    const float* pb = part + (size_t)xb * ntot * 256 + (size_t)mt * 16 + 4 * g4 + r;  // bias sums of tile (nt = 0, mt): rows 4 g4 + r
+    const size_t xs = (size_t)ntot * 256, bs = (size_t)ntot * 16;
+    float s0 = 0.f, s1 = 0.f, b0 = 0.f;
+    int x = x0;
+    for (; x + 2 <= x1; x += 2) {
+        s0 += pt[(size_t)x * xs];
+        s1 += pt[(size_t)(x + 1) * xs];
+        b0 += pb[(size_t)x * bs] + pb[(size_t)(x + 1) * bs];
+    }
+    for (; x < x1; ++x) {
+        s0 += pt[(size_t)x * xs];
+        b0 += pb[(size_t)x * bs];
+    }
+    const float D = s0 + s1;
+    const int o = mt * 16 + 4 * g4 + r, i = nt * 16 + l15;
+    const float w = W[(size_t)o * TW_H + i];
+    atomicAdd(dW + (size_t)o * TW_H + i, D * gamma[i] + b0 * beta[i]);
+    if (nt == 0 && l15 == 0) atomicAdd(dbias + o, b0);
+    // column sums over the tile's 16 rows (4 lane groups x 4 waves)
+    float tg = w * D, tb = w * b0;
+    tg += __shfl_xor(tg, 16); tg += __shfl_xor(tg, 32);
+    tb += __shfl_xor(tb, 16); tb += __shfl_xor(tb, 32);
+    if (g4 == 0) { red[0][r][l15] = tg; red[1][r][l15] = tb; }
+    __syncthreads();
+    if (tid < 16) {
+        atomicAdd(dgamma + nt * 16 + tid, (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]));
+        atomicAdd(dbeta + nt * 16 + tid, (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]));
+    }
+}
 
-template <int MA, int NBUF>
+template <int MA, int NBUF, int NTW>
 static int tailw_go(const TailArgs& t, int grid, hipStream_t st) {
     constexpr int LDA = MA + 16;
-    const size_t lds = (size_t)NBUF * TW_KC * (LDA + 112) * sizeof(bf16_t) + (size_t)6 * (MA / 32) * 512 * sizeof(bf16_t) + 4 * TW_H * sizeof(float);
+    const size_t lds = (size_t)NBUF * TW_KC * (LDA + 112) * sizeof(bf16_t) + (size_t)6 * (MA / 32) * 512 * sizeof(bf16_t) + TW_H * sizeof(float);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
-    int e = NBSS_SET_MAX_LDS((tailw_kernel<MA, NBUF>), lds);
+    int e = NBSS_SET_MAX_LDS((tailw_kernel<MA, NBUF, NTW>), lds);
     if (e) return e;
-    NBSS_LAUNCH((tailw_kernel<MA, NBUF>), dim3(grid), dim3(TW_THREADS), lds, st, t);
+    NBSS_LAUNCH((tailw_kernel<MA, NBUF, NTW>), dim3(grid), dim3(TW_THREADS), lds, st, t);
     return NBSS_CHECK_LAUNCH();
 }
 
-// MA = 192 (T-ConvFFN W1) or 288 (attention in_proj); dW / dbias / LN-affine gradients accumulate into G at the given offsets
-int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes, float* dW, float* dbias, float* G, long long off_lnw, long long off_lnb,
+// MA = 192 (T-ConvFFN W1) or 288 (attention in_proj).  W: fp32 master weight [MA][96]; the gradients accumulate into dW / dbias / dgamma / dbeta
+int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes, const float* W, float* dW, float* dbias, float* dgamma, float* dbeta,
                  hipStream_t st) {
     TailArgs t = t0;
     const int nchunks = cdiv(t.Ntok, TW_KC);
     const int grid = nchunks < 256 ? nchunks : 256;
     const int ntot = (MA / 16) * (TW_H / 16);
-    const size_t need = (size_t)grid * ntot * 272 * sizeof(float) + (size_t)grid * 2 * TW_H * sizeof(float);
-    if (need > wgpart_bytes) return NBSS_EUNSUPPORTED;
+    if ((size_t)grid * ntot * 272 * sizeof(float) > wgpart_bytes) return NBSS_EUNSUPPORTED;
     t.part = wgpart;
-    t.affpart = wgpart + (size_t)grid * ntot * 272;
-    // (MA = 288, the attention's in_proj, is the same template: its 108 tiles are 27 per accumulator wave and spill 78 registers; with 6
-    //  accumulator + 2 tail waves the tail path spills instead (9 k-steps of W^T fragments) — not instantiated until one of them fits)
-    int e = MA == 192 ? tailw_go<192, 2>(t, grid, st) : NBSS_EUNSUPPORTED;
+    int e = MA == 192 ? tailw_go<192, 2, 4>(t, grid, st) : MA == 288 ? tailw_go<288, 1, 2>(t, grid, st) : NBSS_EUNSUPPORTED;
     if (e) return e;
-    WgradArgs a;
-    a.A = nullptr; a.lda = MA; a.MA = MA; a.B = nullptr; a.ldb = TW_H; a.NB = TW_H; a.groups = 1; a.mvalid = 0; a.nvalid = 0; a.taps = 1;
-    a.shift_stride = 1; a.shift_dim = 0; a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr; a.dW = dW; a.dbias = dbias; a.Ntok = t.Ntok; a.F = 1; a.T = 1;
-    a.part = wgpart;
-    if ((e = wgrad_reduce_launch(a, ntot, grid, st))) return e;
-    AffSegs sg;
-    sg.n = 2;
-    sg.off[0] = off_lnw; sg.cnt[0] = TW_H;
-    sg.off[1] = off_lnb; sg.cnt[1] = TW_H;
-    return affine_reduce_launch(t.affpart, grid, sg, G, st);
+    NBSS_LAUNCH(tailw_finalize_kernel, dim3(ntot, grid < TW_RSL ? grid : TW_RSL), dim3(256), 2 * 4 * 16 * sizeof(float), st, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias,
+                dgamma, dbeta);
+    return NBSS_CHECK_LAUNCH();
 }
 
 // T-ConvFFN: da1 (FFN = 192), W1^T fragments K_TF_W1_TN, LayerNorm P_TF_LN_*; dW1 / db1 / LN-affine gradients into G
@@ -260,8 +286,21 @@ int tailw_tconvffn(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, i
     t.A = (const bf16_t*)da1; t.x = (const bf16_t*)x; t.dy = (const bf16_t*)dy; t.dx = (bf16_t*)dx; t.stats = stats;
     t.gamma = lp.p[P_TF_LN_W]; t.beta = lp.p[P_TF_LN_B];
     t.WT = (const bf16_t*)packed + pack_off(c, layer, K_TF_W1_TN);
-    t.part = nullptr; t.affpart = nullptr;
+    t.part = nullptr;
     t.Ntok = c.B * c.F * c.T;
-    return tailw_launch(192, t, wgpart, WGPART_BYTES, G + param_off(c, layer, P_TF_W1), G + param_off(c, layer, P_TF_B1), G,
-                        param_off(c, layer, P_TF_LN_W), param_off(c, layer, P_TF_LN_B), st);
+    return tailw_launch(192, t, wgpart, WGPART_BYTES, lp.p[P_TF_W1], G + param_off(c, layer, P_TF_W1), G + param_off(c, layer, P_TF_B1),
+                        G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), st);
+}
+
+// attention: dqkv (3H = 288), in_proj^T fragments K_INP_TN, LayerNorm P_MH_LN_*
+int tailw_mhsa(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
+               const void* dqkv, float* wgpart, float* G, hipStream_t st) {
+    TailArgs t;
+    t.A = (const bf16_t*)dqkv; t.x = (const bf16_t*)x; t.dy = (const bf16_t*)dy; t.dx = (bf16_t*)dx; t.stats = stats;
+    t.gamma = lp.p[P_MH_LN_W]; t.beta = lp.p[P_MH_LN_B];
+    t.WT = (const bf16_t*)packed + pack_off(c, layer, K_INP_TN);
+    t.part = nullptr;
+    t.Ntok = c.B * c.F * c.T;
+    return tailw_launch(288, t, wgpart, WGPART_BYTES, lp.p[P_INP_W], G + param_off(c, layer, P_INP_W), G + param_off(c, layer, P_INP_B),
+                        G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B), st);
 }
