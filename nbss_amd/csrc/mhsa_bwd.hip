@@ -107,7 +107,9 @@ NBSS_DEV void col_frag_rm(Frag<T>& f, const T* __restrict__ rowmajor, int half, 
 // FULL: T in (240, 256] — all 16 strips of every wave exist, so the strip / tile-existence tests are compile-time true and the
 // tile loops have constant trip counts (wave-uniform but dynamic branches kept the compiler from scheduling across them: the same
 // effect cost wgrad 24 %, profiles/README.md row 27)
-template <class T, bool FULL>
+// XT (bf16): the tail — du = Win^T dqkv, LayerNorm backward, dx, LN-affine sums — runs in tailw.hip's fused tail / in_proj weight-gradient
+// kernel instead; this kernel then ends with the dqkv operand and writes the LayerNorm row statistics for it.
+template <class T, bool FULL, bool XT>
 __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Win, const T* __restrict__ WinT, const T* __restrict__ WoutT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ osave,
@@ -179,6 +181,10 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 #pragma unroll
             for (int j = 0; j < 8; ++j) q += (v[ks][j] - smean[si]) * (v[ks][j] - smean[si]);
         srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / MB_H) + 1e-5f);
+        if (XT && tv[si] && g4 == 0) {
+            stats[(n0 + tt[si]) * 2] = smean[si];
+            stats[(n0 + tt[si]) * 2 + 1] = srstd[si];
+        }
     }
     lds_barrier();  // lnp is read below
     PHASE(0);
@@ -474,6 +480,10 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         PHASE(9);
     }
 
+    if constexpr (XT) {
+        PHASE_END();
+        return;
+    }
     // du = Win^T dqkv from the [N][3H] operand this workgroup has just written (full barrier: the other waves' stores are
     // complete, and these lines were never read before, so no stale L1 copies exist)
     __syncthreads();
@@ -526,7 +536,10 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 }
 PHASE_READER(nbss_phase_read_mhsa_bwd)
 
-template <class T, bool FULL>
+int tailw_mhsa(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
+               const void* dqkv, float* wgpart, float* G, hipStream_t st);
+
+template <class T, bool FULL, bool XT>
 static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                       void* dx, float* stats, void* dqkv, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
@@ -535,11 +548,10 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const size_t lds = (size_t)(sizeof(T) == 2 ? 4 : 6) * tp * MB_DH * sizeof(T) + (size_t)(3 * tp + 4 * MB_H) * sizeof(float) + 64 + (sizeof(T) == 2 ? (size_t)96 * 512 * sizeof(T) : 0) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const T* pk = (const T*)packed;
-    int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T, FULL>), lds);
+    int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T, FULL, XT>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.F), block(512);
-    ProfScope ps(PK_MHSA_B, st);
-    NBSS_LAUNCH((mhsa_bwd_kernel<T, FULL>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
+    dim3 grid(c.B * c.F), block(512);  // (timed by the caller's ProfScope, together with the fused tail kernel when there is one)
+    NBSS_LAUNCH((mhsa_bwd_kernel<T, FULL, XT>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
                 pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)),
                 (T*)dx, stats, (T*)dqkv);
     return NBSS_CHECK_LAUNCH();
@@ -553,15 +565,29 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     void* dqkv = (char*)ws + ws_align(N * 2 * sizeof(float));
     float* part = (float*)((char*)ws + ws_part_offset(c));
     const bool full = cdiv(c.T, 16) == MB_NT;
-    int e = c.dtype != NBSS_BF16 ? mhsa_bwd_t<float, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
-            : full               ? mhsa_bwd_t<bf16_t, true>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
-                                 : mhsa_bwd_t<bf16_t, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st);
+#if defined(NBSS_NO_TAILW) || defined(NBSS_NO_TAILW_MHSA)
+    const bool xt = false;
+#else
+    const bool xt = c.dtype == NBSS_BF16;  // tail + in_proj weight gradient in tailw.hip
+#endif
+    int e;
+    {
+    ProfScope ps(PK_MHSA_B, st);  // ONE profiler interval per nbss_mhsa_bwd call: data-gradient kernel (+ fused tail / in_proj wgrad kernel)
+    e = c.dtype != NBSS_BF16 ? mhsa_bwd_t<float, false, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+            : xt ? (full ? mhsa_bwd_t<bf16_t, true, true>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+                         : mhsa_bwd_t<bf16_t, false, true>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st))
+            : full ? mhsa_bwd_t<bf16_t, true, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+                   : mhsa_bwd_t<bf16_t, false, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st);
     if (e) return e;
-    AffSegs sg;
-    sg.n = 2;
-    sg.off[0] = param_off(c, layer, P_MH_LN_W); sg.cnt[0] = MB_H;
-    sg.off[1] = param_off(c, layer, P_MH_LN_B); sg.cnt[1] = MB_H;
-    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
+    if (xt && (e = tailw_mhsa(c, lp, packed, layer, x, dy, dx, stats, dqkv, (float*)((char*)ws + ws_wgpart_offset(c)), G, st))) return e;
+    }
+    if (!xt) {
+        AffSegs sg;
+        sg.n = 2;
+        sg.off[0] = param_off(c, layer, P_MH_LN_W); sg.cnt[0] = MB_H;
+        sg.off[1] = param_off(c, layer, P_MH_LN_B); sg.cnt[1] = MB_H;
+        if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
+    }
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
@@ -571,6 +597,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     a.dW = G + param_off(c, layer, P_OUTP_W); a.dbias = G + param_off(c, layer, P_OUTP_B);
     if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    if (xt) return NBSS_OK;
     // in_proj: dWin[3H][H] = dqkv^T LN(x) ; dbin = colsum(dqkv)
     a.A = dqkv; a.lda = 3 * MB_H; a.MA = 3 * MB_H; a.B = x; a.ldb = MB_H; a.NB = MB_H;
     if (c.dtype == NBSS_BF16) { a.a_gw = MB_DH; a.a_gs = (int)(N * MB_DH); }  // group-major dqkv
