@@ -556,6 +556,7 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     if (fused) part = (float*)((char*)ws + ws_fcpart_offset(c));
     int e = c.dtype != NBSS_BF16 ? fconv_bwd_t<float, 1, 8, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
             : big                ? fconv_bwd_t<bf16_t, 1, 8, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
+            : fused && nine      ? fconv_bwd_t<bf16_t, FC_BWD_TT, 9, true>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
             : fused              ? fconv_bwd_t<bf16_t, FC_BWD_TT, 8, true>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
             : nine               ? fconv_bwd_t<bf16_t, FC_BWD_TT, 9, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st)
                                  : fconv_bwd_t<bf16_t, FC_BWD_TT, 8, false>(c, P, part, packed, layer, which, x, dy, dx, stats, dv, st);
