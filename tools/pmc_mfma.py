@@ -7,7 +7,7 @@ import csv, glob, json, os, sys
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 out = {"batch": B, "commit": os.environ.get("NBSS_COMMIT"), "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "kernels": {}}
-MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du", "tailw_kernel"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
+MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du", "tailw_kernel"], "mhsa_bwd": ["mhsa_bwd", "tailw_kernel"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
 for k in ["fconv_fwd", "full_fwd", "mhsa_fwd", "tconvffn_fwd", "fconv_bwd", "full_bwd", "mhsa_bwd", "tconvffn_bwd"]:
     vals, per = {}, {}
     for tag in ("SQ", "GRBM"):

@@ -6,7 +6,7 @@ import csv, glob, json, os, sys
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = 129 * 251 * 96 * 2 * B
 out = {"batch": B, "commit": os.environ.get("NBSS_COMMIT"), "units": "bytes per launch", "correction": "2 * FETCH_SIZE KiB (gfx950 half-count) + WRITE_SIZE KiB", "kernels": {}}
-MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du", "tailw_kernel"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
+MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du", "tailw_kernel"], "mhsa_bwd": ["mhsa_bwd", "tailw_kernel"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
 KERNELS = os.environ.get("NBSS_PMC_KERNELS", "fconv_fwd full_fwd mhsa_fwd tconvffn_fwd fconv_bwd full_bwd mhsa_bwd tconvffn_bwd").split()
 for k in ["fconv_fwd", "full_fwd", "mhsa_fwd", "tconvffn_fwd", "fconv_bwd", "full_bwd", "mhsa_bwd", "tconvffn_bwd"]:
     vals = {}
