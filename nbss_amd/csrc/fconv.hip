@@ -8,7 +8,8 @@
 // grouped conv is 8 independent GEMMs  out^T[12(16) x F] = W_g[12 x 60(64)] * im2col(u_g)[60 x F]
 // on the matrix cores (form 2: weights = A, frequencies = N).  Results return through LDS so the
 // residual add + store are full 16-byte coalesced accesses.  bf16: 8 waves, one conv group per wave, two
-// workgroups per CU; the backward kernel (below) alternates row phases and group phases on the same slab.
+// workgroups per CU; the backward kernel (below) alternates row phases and group phases on the same slab and (bf16, two-frame slabs)
+// contracts the conv weight gradient between them, while both of its operands sit in the LDS images.
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"

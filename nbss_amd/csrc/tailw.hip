@@ -2,14 +2,15 @@
 //
 // Both the T-ConvFFN (W1: H -> FFN) and the attention (in_proj: H -> 3H) start with  a = W LN(x) + b  and their data-gradient kernels end
 // with the same three steps on the emitted pre-activation gradient `da` ([MA/24][N][24] group-major operand):
-//     du = W^T da            LayerNorm backward + residual:  dx = dy + LN'(du)            dW = da^T LN(x),  db = colsum(da)
+//     du = W^T da            LayerNorm backward + residual:  dx = dy + LN'(du)            dW = da^T LN(x),  db = colsum(da),  dgamma, dbeta
 // Done as separate kernels (a tail kernel and a wgrad problem) `da` and `x` are read from HBM twice: 3 S·B of the 8 S·B the pair moves.
 // Here one persistent kernel (256 workgroups x 8 waves, 64-token chunks, wgrad.hip's staging scheme: register prefetch of the next chunk,
 // ROW-major LDS images, transposing reads for the token-contraction) reads them once:
-//   * all 8 waves contract the chunk's dW tiles (A = da image, B = LN(x) image, K = the 64 tokens),
-//   * waves 0-3 then take one 16-token tile each: du = W^T da with the B operand straight from the da image rows (natural K order) and the
-//     W^T fragments resident in LDS, LayerNorm backward in registers (x, dy as 8-byte C-layout pieces, requested before the MFMA section),
-//     dx stored.
+//   * the accumulator waves (4 for W1's 72 tiles, 6 for in_proj's 108: 18 tiles each) contract the chunk's dW tiles (A = da image, B = xhat
+//     image, K = the 64 tokens),
+//   * the tail waves (4 resp. 2) take the chunk's 16-token tiles: du = W^T da with the B operand straight from the da image rows (natural K
+//     order) and the W^T fragments resident in LDS, LayerNorm backward in registers (x, dy as 8-byte C-layout pieces), dx stored.
+//   The two roles are two chunk loops with the same barrier sequence, so that their register sets have disjoint live ranges.
 // The LayerNorm affine gradients need no per-token work at all: the B image holds xhat = (x - mean) rstd (not LN(x)), so the contraction
 // yields D = da^T xhat, and with db = colsum(da):   dW = D gamma + db (x) beta,   dgamma[i] = sum_o W[o][i] D[o][i],   dbeta[i] = sum_o W[o][i] db[o]
 // (du = W^T da summed against xhat / 1 over the tokens, reordered) — tailw_finalize_kernel applies them while it folds the partial tiles.

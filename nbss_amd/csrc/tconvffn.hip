@@ -935,7 +935,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_kernel(nbss_cfg c, LayerPtrs
 PHASE_READER(nbss_phase_read_tconvffn_bwd)
 
 // ---------------------------------------------------------------------------------------------
-// Tail of the backward pass as its own kernel (bf16 stream, after tconvffn_s.hip's data-gradient kernel): du = W1^T da1 over all
+// Tail of the backward pass as its own kernel — since tailw.hip fused it with the W1 weight gradient, built only into the A/B flavour
+// (-DNBSS_NO_TAILW) that the fusion was measured against (bf16 stream, after tconvffn_s.hip's data-gradient kernel): du = W1^T da1 over all
 // FFN channels from the group-major [G][N][24] operand, LayerNorm backward + residual in registers, row statistics for the weight-
 // gradient kernel, and the LayerNorm affine partial sums of the workgroup (entries [2 FFN, 2 FFN + 2 H) of its `part` row; the
 // GroupNorm entries are written by the data-gradient kernel).  One workgroup = one (b,f) sequence, 16 waves x one 16-frame strip

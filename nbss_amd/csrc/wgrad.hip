@@ -1,4 +1,5 @@
-// wgrad.hip — weight gradients of every linear map on the SpatialNet hot path.
+// wgrad.hip — weight gradients of the linear maps on the SpatialNet hot path (bf16 stream: all but the three that are contracted where
+// their operands already are — the f-convs inside fconv_bwd, W1 / in_proj inside tailw.hip's fused tail kernel; fp32 stream: all of them).
 //
 // All of them are the same contraction over tokens n = (b,f,t):
 //     dW[o][i][tap] = sum_n dY[n][o] * X[n + (tap - taps/2) * shift][i]          (grouped)
