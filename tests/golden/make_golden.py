@@ -16,7 +16,51 @@ HERE = Path(__file__).resolve().parent
 REF = Path("/root/reference")
 
 
+def large_16k():
+    """SpatialNet-large (the "for large" comments of configs/SpatialNet.yaml: 192 / 384 / squeeze 16) and the 16-kHz STFT setting
+    (n_fft 512, hop 256): `python tests/golden/make_golden.py large16k` writes only these two fixtures."""
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[m]
+    sys.path.insert(0, str(REF))
+    from models.arch.SpatialNet import SpatialNet  # noqa: E402  (reference)
+    from models.io.norm import Norm  # noqa: E402
+    from models.io.stft import STFT  # noqa: E402
+    assert "/root/reference" in sys.modules["models.arch.SpatialNet"].__file__
+    torch.manual_seed(7)
+    torch.set_num_threads(1)
+    F, T, L = 17, 21, 1
+    net = SpatialNet(dim_input=12, dim_output=4, num_layers=L, dim_hidden=192, dim_ffn=384, kernel_size=(5, 3), conv_groups=(8, 8),
+                     norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=16, num_freqs=F, num_heads=4, full_share=0).eval()
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+        x = torch.randn(1, F, T, 12)
+        y = net(x)
+    out = {"x": x.numpy(), "y": y.numpy(), "F": F, "T": T, "L": L}
+    for k, v in net.state_dict().items():
+        out["param/" + k] = v.numpy().astype(np.float16) if v.dim() > 1 else v.numpy()  # (weights stored in fp16: the loader widens them, the fixture's y was computed from the widened values below)
+    # recompute y from the fp16-rounded weights so that the fixture is self-consistent
+    with torch.no_grad():
+        sd = {k: (v.half().float() if v.dim() > 1 else v) for k, v in net.state_dict().items()}
+        net.load_state_dict(sd)
+        out["y"] = net(x).numpy()
+    np.savez_compressed(HERE / "spatialnet_large_F17_T21_L1.npz", **out)
+    stft, norm = STFT(n_fft=512, n_hop=256), Norm(mode="frequency")
+    sig = torch.randn(2, 3, 3000)
+    X, n = stft.stft(sig)
+    Xn, (Xr, XrMM) = norm.norm(X.clone(), ref_channel=1)
+    Xl = torch.view_as_real(Xn.permute(0, 2, 3, 1)).reshape(2, 257, X.shape[-1], 6)
+    back = stft.istft(X, n)
+    np.savez_compressed(HERE / "stft_norm_n3000_16k.npz", sig=sig.numpy(), X_re=X.real.numpy(), X_im=X.imag.numpy(), Xl=Xl.numpy(),
+                        XrMM=XrMM.numpy(), back=back.numpy())
+    print("written: spatialnet_large_F17_T21_L1.npz, stft_norm_n3000_16k.npz")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "large16k":
+        assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
+        return large_16k()
     assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
     # the repo root shadows `models`: import the reference's package explicitly from its own root
     for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:

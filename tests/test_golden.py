@@ -76,3 +76,49 @@ def test_kernels_reproduce_reference_stft_norm(backend):
     assert rel_l2(mm, z["XrMM"][:, 0]) < 2e-5
     assert rel_l2(X.cpu().double() * torch.from_numpy(z["XrMM"][:, 0]).double()[..., None], z["Xl"].astype(np.float64) * z["XrMM"][:, 0][..., None]) < 2e-5
     assert rel_l2(X, z["Xl"]) < 1e-3
+
+
+def load_large():
+    z = np.load(G / "spatialnet_large_F17_T21_L1.npz")
+    p = {k[6:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("param/")}  # (2-D+ weights stored in fp16)
+    return z, p
+
+
+def test_oracle_reproduces_reference_large_network():
+    """SpatialNet-large built BY THE REFERENCE (192 / 384 / squeeze 16, 4 heads of 48): pins the oracle's geometry-generic restatement"""
+    z, p = load_large()
+    y = ref.spatialnet(torch.from_numpy(z["x"]).double(), {k: v.double() for k, v in p.items()}, int(z["L"]))
+    assert rel_l2(y, torch.from_numpy(z["y"])) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [pytest.param(NBSS_F32, id="f32"), pytest.param(NBSS_BF16, id="bf16")])
+def test_kernels_reproduce_reference_large_network(backend, dtype):
+    """the large-geometry forward kernels against the reference's own output (fp32 stream <= 1e-4, north-star bar 1e-3)"""
+    z, p = load_large()
+    F, L = int(z["F"]), int(z["L"])
+    eng = SpatialNetEngine(backend.lib, backend.device, dim_input=12, dim_output=4, num_freqs=F, num_layers=L, dtype=dtype, dim_hidden=192, dim_ffn=384,
+                           dim_squeeze=16)
+    eng.load_params(p)
+    x = torch.from_numpy(z["x"]).to(eng.stream_dtype()).to(backend.device)
+    y = eng.forward(x, train=False)
+    assert rel_l2(y, z["y"]) < (1e-4 if dtype == NBSS_F32 else 2e-2)
+
+
+def test_oracle_and_kernels_reproduce_reference_stft_16khz(backend):
+    """n_fft 512 / hop 256 (paras_16k of the reference's models/io/stft.py): STFT + per-bin norm + layout glue, iSTFT round trip"""
+    z = np.load(G / "stft_norm_n3000_16k.npz")
+    sig64 = torch.from_numpy(z["sig"]).double()
+    X = io_ref.stft(sig64, 512, 256)
+    assert rel_l2(X.real, z["X_re"]) < 1e-6 and rel_l2(X.imag, z["X_im"]) < 1e-6
+    assert rel_l2(io_ref.istft(X, 3000, 512, 256), z["back"]) < 1e-6
+    sig = torch.from_numpy(z["sig"]).to(backend.device)
+    tab = ops.stft_tables(backend.lib, 512, 0, backend.device)
+    Xk, mm = ops.stft_norm_fwd(backend.lib, 512, NBSS_F32, tab, sig, 1)
+    assert rel_l2(mm, z["XrMM"][:, 0]) < 2e-5
+    assert rel_l2(Xk, z["Xl"]) < 1e-3
+    # inverse: the reference's iSTFT of its own (un-normalised) spectrum, through inorm + iSTFT kernels fed with X / XrMM
+    mm_t = torch.from_numpy(z["XrMM"][:, 0]).to(backend.device)
+    Xc = torch.complex(torch.from_numpy(z["X_re"]), torch.from_numpy(z["X_im"]))  # [B, C, F, T]
+    out = torch.view_as_real((Xc[:, :2] / torch.from_numpy(z["XrMM"])).permute(0, 2, 3, 1).contiguous()).reshape(2, 257, Xc.shape[-1], 4).float()
+    y = ops.inorm_istft_fwd(backend.lib, 512, tab, out.to(backend.device).contiguous(), mm_t.contiguous(), 3000)
+    assert rel_l2(y, z["back"][:, :2]) < 2e-5
