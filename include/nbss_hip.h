@@ -32,9 +32,15 @@ extern "C" {
 #define NBSS_EUNSUPPORTED (-2) /* shape/config this build has no kernel for */
 #define NBSS_ELAUNCH (-3)      /* HIP launch error */
 
-/* SpatialNet hyper-parameters: models/arch/SpatialNet.py:154-171 (ctor) + batch geometry. */
+/* SpatialNet hyper-parameters: models/arch/SpatialNet.py:154-171 (ctor) + batch geometry.
+ * Geometries this build has kernels for (anything else: NBSS_EUNSUPPORTED):
+ *   small  H 96,  FFN 192, SQ 8,  4 heads   (configs/SpatialNet.yaml:16-24)          forward + backward
+ *   large  H 192, FFN 384, SQ 16, 4 heads   (the "for large" comments of that file)  forward only (every *_bwd refuses it)
+ *   both with conv groups (8, 8), kernel sizes (5, 3), encoder kernel 5; C_in % 4 == 0, C_in / C_out <= 16.
+ *   F <= 272 (n_fft 256 -> 129, n_fft 512 -> 257); fp32-stream backward: F <= 160.
+ *   T <= 256 for a forward that saves state and for every backward; forward without `acts`: T <= 4096. */
 typedef struct nbss_cfg {
-    int32_t B, F, T;         /* batch, frequencies (129), frames (251) */
+    int32_t B, F, T;         /* batch, frequencies (129 | 257), frames (251 for 4 s) */
     int32_t C_in, C_out;     /* dim_input (2*channels), dim_output (2*speakers) */
     int32_t H, FFN, SQ;      /* dim_hidden, dim_ffn, dim_squeeze */
     int32_t L, heads;        /* num_layers, num_heads */
