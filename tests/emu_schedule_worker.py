@@ -48,6 +48,13 @@ def main():
         x, _ = cs.stream(seed=32)
         out[f"{nm}_long_mhsa"] = ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=ops.mhsa_save(cs.lib, cs.cfg, x.device))
         out[f"{nm}_long_tconvffn"] = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
+        # SpatialNet-large forward kernels (geometry templates; tconvffn_g.hip's chunked two-pass walk, 64/128-key attention blocks)
+        cs = Case(be, 1, 3, 40, dtype, geo="large")
+        x, _ = cs.stream(seed=33)
+        out[f"{nm}_large_fconv"] = ops.fconv_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, 0, x)
+        out[f"{nm}_large_full"] = ops.full_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
+        out[f"{nm}_large_mhsa"] = ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=ops.mhsa_save(cs.lib, cs.cfg, x.device))
+        out[f"{nm}_large_tconvffn"] = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
     torch.save(out, sys.argv[1])
 
 
