@@ -272,7 +272,13 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
     const int ntot = (MA / 16) * (TW_H / 16);
     if ((size_t)grid * ntot * 272 * sizeof(float) > wgpart_bytes) return NBSS_EUNSUPPORTED;
     t.part = wgpart;
-    int e = MA == 192 ? tailw_go<192, 2, 4>(t, grid, st) : MA == 288 ? tailw_go<288, 1, 2>(t, grid, st) : NBSS_EUNSUPPORTED;
+    int e = MA == 192 ? tailw_go<192, 2, 4>(t, grid, st)
+#ifdef NBSS_TW288_NBUF1
+            : MA == 288 ? tailw_go<288, 1, 2>(t, grid, st)
+#else
+            : MA == 288 ? tailw_go<288, 2, 2>(t, grid, st)  // both buffers + the 54 W^T fragments: 162 176 of 163 840 bytes
+#endif
+            : NBSS_EUNSUPPORTED;
     if (e) return e;
     NBSS_LAUNCH(tailw_finalize_kernel, dim3(ntot, grid < TW_RSL ? grid : TW_RSL), dim3(256), 2 * 4 * 16 * sizeof(float), st, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias,
                 dgamma, dbeta);
