@@ -210,6 +210,26 @@ __global__ __launch_bounds__(WG_THREADS, TPW <= 4 ? 4 : 2) void wgrad_kernel(Wgr
     }
 
     // ---- flush ----
+    if (a.part) {  // two-stage: partial tiles in fragment order (+ the bias sums of the nt = 0 tiles), folded by wgrad_reduce_kernel.
+        // The atomicAdd flush below costs the LinearGroup problem (8 groups x 81 tiles x 48 x-blocks = 8 M same-address-heavy atomics) most
+        // of its 96 us for 34 MB of operands.
+        const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        float* pt = a.part + wg * ntot * 256;
+        float* pbias = a.part + (size_t)gridDim.y * gridDim.x * ntot * 256 + wg * ntot * 16;
+#pragma unroll
+        for (int s = 0; s < TPW; ++s) {
+            const int tl = s * WG_WAVES + w;
+            if (tl < ntot) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[s][r];
+            }
+        }
+        if (do_bias && tid < rowsA) {
+            const int gl = tid / mgp, m = tid % mgp;
+            pbias[(size_t)(gl * tpg + (m >> 4) * ntiles) * 16 + (m & 15)] = bsum;
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < TPW; ++s) {
         const int tl = s * WG_WAVES + w;
@@ -530,7 +550,8 @@ int wgrad_reduce_launch(const WgradArgs& a, int ntot, int xb, hipStream_t st) {
 }
 
 template <class T>
-static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
+static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
+    const WgradArgs& a = a_in;
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     const int mtiles = cdiv(mg, 16), ntiles = cdiv(a.taps * ng, 16), tpg = mtiles * ntiles;
     const int cap = WG_WAVES * WG_TPW;
@@ -608,17 +629,28 @@ static int wgrad_launch_t(const WgradArgs& a, hipStream_t st) {
     dim3 grid(xbl, ybl, nz), block(WG_THREADS);
     ProfScope ps(PK_WGRAD, st);
     int e;
+    WgradArgs ak = a_in;
+    const int ntot_k = (all ? a.groups : 1) * tpg;
+#ifdef NBSS_WG_ATOMIC_FLUSH
+    ak.part = nullptr;
+#endif
+    if (nz > 1 || (size_t)ybl * xbl * ntot_k * 272 * sizeof(float) > WGPART_BYTES) ak.part = nullptr;  // (column-tile ranges / huge grids: atomic flush)
 #define WK_GO(CW, TPW)                                                             \
     do {                                                                           \
         if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, CW, TPW>), lds))) return e;     \
-        NBSS_LAUNCH((wgrad_kernel<T, CW, TPW>), grid, block, lds, st, a);          \
+        NBSS_LAUNCH((wgrad_kernel<T, CW, TPW>), grid, block, lds, st, ak);         \
     } while (0)
     if (cw8 && small) WK_GO(8, 4);
     else if (cw8) WK_GO(8, WG_TPW);
     else if (small) WK_GO(4, 4);
     else WK_GO(4, WG_TPW);
 #undef WK_GO
-    return NBSS_CHECK_LAUNCH();
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if (ak.part) {
+        NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot_k, xbl < WG_RSL ? xbl : WG_RSL, ybl), dim3(256), 0, st, ak, xbl, 0);
+        return NBSS_CHECK_LAUNCH();
+    }
+    return NBSS_OK;
 }
 
 int wgrad_launch(const WgradArgs& a0, int dtype, hipStream_t st) {
