@@ -1,3 +1,6 @@
+#!/bin/bash
+# One diagnostic GPU-box call: in-kernel phase shares of the big kernels (needs `python -m nbss_amd.build phase` first) and the
+# wait / issue / active split of every kernel's wave cycles (tools/pmc_stall.sh).  Output: gpurun_out/<tag>_phase_prof.txt, pmc_stall.txt
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export NBSS_HIP_FLAVOUR=phase
 ( python tools/phase_prof.py tconvffn_bwd 32 224 tconvffn_bwd_s
