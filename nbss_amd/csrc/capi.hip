@@ -23,7 +23,7 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
                   hipStream_t st);
 int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, const void* x, const float* dout, void* dx, void* ws,
                      hipStream_t st);
-int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, hipStream_t st);
+int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, void* ws, hipStream_t st);
 
 size_t stft_tables_bytes_impl(int nfft);
 int stft_tables_impl(int nfft, int win_kind, float* tab, hipStream_t st);
@@ -178,7 +178,7 @@ int nbss_decoder_bwd(const nbss_cfg* cfg, const float* params, float* grads, con
 int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const void* dy, void* stream) {
     CHECK_CFG_TRAIN(cfg);
     if (!grads || !xin || !dy) return NBSS_EINVAL;
-    return encoder_bwd_impl(*cfg, grads, xin, dy, (hipStream_t)stream);
+    return encoder_bwd_impl(*cfg, grads, xin, dy, nullptr, (hipStream_t)stream);
 }
 
 // ---- whole network: native sequencing of the sub-block kernels (one C call per direction) --------
@@ -253,7 +253,7 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
         void* t = dA; dA = dB; dB = t;
         k -= 5;
     }
-    return layer_lo == 0 ? encoder_bwd_impl(c, grads, xin, dA, st) : NBSS_OK;
+    return layer_lo == 0 ? encoder_bwd_impl(c, grads, xin, dA, ws, st) : NBSS_OK;
 }
 
 int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,

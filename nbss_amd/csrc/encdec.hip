@@ -178,12 +178,15 @@ int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pa
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     a.A = ws; a.lda = CP; a.MA = CP; a.B = x; a.ldb = ENC_H; a.NB = ENC_H;
     a.dW = G + param_off_dec_w(c); a.dbias = G + param_off_dec_b(c);
+    a.part = (float*)((char*)ws + ws_wgpart_offset(c));  // two-stage flush (1024 x-blocks of same-address atomics otherwise)
     return wgrad_launch(a, c.dtype, st);
 }
 
 // encoder: the network input needs no gradient; only dW[o][i][tap] = sum_n dy[n][o] xin[n+tap-2][i] and db
-int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, hipStream_t st) {
+// ws: the backward workspace when the caller has one (nbss_spatialnet_bwd*): partial tiles + reduce instead of the atomicAdd flush
+int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, void* ws, hipStream_t st) {
     WgradArgs a;
+    if (ws) a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = c.B * c.F * c.T; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = c.enc_ks;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
