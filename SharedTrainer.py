@@ -281,6 +281,15 @@ def _fused_step_for(module: "TrainModule", cfg: dict, dev):
     return eng, ts, gamma
 
 
+def _check_train_geometry(module: "TrainModule") -> None:
+    """`fit` on a SpatialNet shape without training kernels fails here, before the first step, with the reason"""
+    hp = getattr(module.arch, "hp", {})
+    if (hp.get("dim_hidden"), hp.get("dim_ffn"), hp.get("dim_squeeze"), hp.get("num_heads")) != (96, 192, 8, 4):
+        raise NotImplementedError("fit: the MI355X TRAINING kernels are built for the SpatialNet-small geometry (dim_hidden 96, dim_ffn 192, dim_squeeze 8, "
+                                  f"4 heads; configs/SpatialNet.yaml as shipped); got {hp.get('dim_hidden')}/{hp.get('dim_ffn')}/{hp.get('dim_squeeze')}/"
+                                  f"{hp.get('num_heads')} — SpatialNet-large is served by validate | test | predict")
+
+
 def fit(cfg: dict) -> Dict[str, Any]:
     tr = cfg.get("trainer", {})
     if tr.get("accelerator", "gpu") == "cpu" or not torch.cuda.is_available():
@@ -301,6 +310,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
         data = SyntheticDataModule()
     if cfg.get("ckpt_path"):
         load_checkpoint(cfg["ckpt_path"], module)  # weights first: the engine binds the parameters below
+    _check_train_geometry(module)
     eng, ts, gamma = _fused_step_for(module, cfg, dev)
     first_epoch = 0
     if cfg.get("ckpt_path"):

@@ -144,6 +144,16 @@ def test_unsupported_training_configs_fail_loudly():
             _fused_step_for(m, c, torch.device("cpu"))
 
 
+def test_fit_refuses_the_large_geometry_with_the_reason():
+    from SharedTrainer import _check_train_geometry
+    base = ["fit", "--config", str(ROOT / "configs" / "SpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml")] + ARGS
+    _, c = parse_cli(base + ["--model.arch.dim_hidden=192", "--model.arch.dim_ffn=384", "--model.arch.dim_squeeze=16", "--model.arch.num_layers=2"])
+    with pytest.raises(NotImplementedError, match="SpatialNet-small geometry"):
+        _check_train_geometry(build_module(c))
+    _, c = parse_cli(base + ["--model.arch.num_layers=2"])
+    _check_train_geometry(build_module(c))  # the shipped geometry passes
+
+
 class SimpleNamespaceEngine:
     dtype = 0
 
