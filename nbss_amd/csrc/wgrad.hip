@@ -579,7 +579,13 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
         // 64-token chunks, one X image for all taps: dense problems, T-convs and (96-row chunks of 48 frequencies x 2 frames) F-convs
         const bool fmode3 = a.taps > 1 && a.shift_dim == 1 && a.shift_stride == a.T && a.Ntok % (a.F * a.T) == 0;
         const bool tmode3 = a.taps > 1 && a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0;
-        const int kc3 = fmode3 ? 96 : 64, h3 = a.taps / 2, rowsB3 = kc3 + 2 * h3 * (fmode3 ? 2 : 1), nfirst3 = (all ? a.groups : 1) * mtiles;
+        // skinny dense problems (squeeze / unsqueeze: 6 tiles, 13 KB per 64 tokens): 128-token chunks halve the barrier rounds per byte
+#ifdef NBSS_WG_KC64
+        const bool skinny = false;
+#else
+        const bool skinny = a.taps == 1 && cdiv((all ? a.groups : 1) * mtiles * ntiles, WG_WAVES) <= 2;
+#endif
+        const int kc3 = fmode3 ? 96 : skinny ? 128 : 64, h3 = a.taps / 2, rowsB3 = kc3 + 2 * h3 * (fmode3 ? 2 : 1), nfirst3 = (all ? a.groups : 1) * mtiles;
         const size_t img3 = ((size_t)kc3 * tr_ld(ncA) + (size_t)rowsB3 * tr_ld(ncB)) * 2;
         const int nvec3 = (cdiv(kc3 * (ncA / 8), WG_THREADS) + cdiv(rowsB3 * (ncB / 8), WG_THREADS)) * WG_THREADS;  // whole A slots + whole B slots
         const bool gm_ok = (!a.a_gw || a.a_gw % 8 == 0) && (!a.b_gw || (a.b_gw % 8 == 0 && !a.stats));
@@ -604,7 +610,8 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
             if (fmode3) {
                 if (need <= 5) W3_GO(96, 5);
                 else W3_GO(96, 14);
-            } else if (need <= 2) W3_GO(64, 2);  // squeeze / unsqueeze (6 tiles for 8 waves): no dummy slots
+            } else if (skinny) W3_GO(128, 2);   // squeeze / unsqueeze (6 tiles for 8 waves): no dummy slots
+            else if (need <= 2) W3_GO(64, 2);
             else if (need <= 5) W3_GO(64, 5);
             else if (need <= 10) W3_GO(64, 10);
             else W3_GO(64, 14);
