@@ -106,6 +106,37 @@ class TrainModule(nn.Module):
             Yr_hat = self.norm.inorm(out, (Xr, XrMM))
         return (self.stft.istft(Yr_hat, length) if istft else torch.view_as_real(Yr_hat)), loss_paras
 
+    @torch.no_grad()
+    def forward_streaming(self, x: Tensor, chunk: int = 8, use_graph: Optional[bool] = None):
+        """causal chunked inference of an OnlineSpatialNet: x [B,C,N] -> (yr_hat [B,Spk,N], stats).  STFT and the (online) normalisation
+        are frame-local, so the network is fed `chunk` frames at a time through OnlineStreamer (fixed-shape state; one HIP graph replay
+        per chunk on a HIP device) and the result equals forward() on the whole signal (reference OnlineSpatialNet.py:333-354)."""
+        from models.arch.OnlineSpatialNet import OnlineStreamer
+        assert self.norm.online or self.norm.mode in ("none", None), "streaming needs a causal (online) normalisation"
+        X, length = self.stft.stft(x[:, self.channels])
+        B, C, F, T = X.shape
+        X, (Xr, XrMM) = self.norm.norm(X, ref_channel=self.channels.index(self.ref_channel))
+        feats = torch.view_as_real(X.permute(0, 2, 3, 1).contiguous()).reshape(B, F, T, 2 * C)
+        Tp = (T + chunk - 1) // chunk * chunk
+        if Tp != T:
+            feats = torch.nn.functional.pad(feats, (0, 0, 0, Tp - T))
+        key = (B, chunk, str(x.device))
+        if getattr(self, "_streamer_key", None) != key:
+            self._streamer, self._streamer_key = OnlineStreamer(self.arch, B, chunk, device=x.device, use_graph=use_graph), key
+        s = self._streamer
+        s.reset()
+        if x.is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.time()
+        out = torch.cat([s.step(feats[:, :, c:c + chunk]) for c in range(0, Tp, chunk)], 2)[:, :, :T]
+        if x.is_cuda:
+            torch.cuda.synchronize()
+        dt = time.time() - t0
+        out = torch.view_as_complex(out.float().reshape(B, F, T, -1, 2).contiguous()).permute(0, 3, 1, 2)
+        Yr_hat = self.norm.inorm(out, (Xr, XrMM))
+        stats = {"chunks": Tp // chunk, "graph_replays": Tp // chunk if s.graph is not None else 0, "frames_per_s": B * Tp / max(dt, 1e-9)}
+        return self.stft.istft(Yr_hat, length), stats
+
     def training_step(self, batch, batch_idx=0):
         x, ys, paras = batch
         yr = ys[:, :, self.ref_channel, :]
@@ -202,7 +233,9 @@ def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, g
     """Lightning-shaped checkpoint that the reference's trainer can load: `state_dict` with the reference's keys (`arch.*` and the
     persistent `stft.window` buffer, general_steps.py:189-199), `optimizer_states[0]` as a torch.optim.Adam state_dict (per-parameter
     `exp_avg` / `exp_avg_sq` / `step` sliced out of the fused optimizer's flat buffers, in `module.parameters()` order),
-    `lr_schedulers`, `epoch`, `global_step`, `pytorch-lightning_version`."""
+    `lr_schedulers` (a full ExponentialLR state_dict), `epoch`, `global_step`, `pytorch-lightning_version`.  Weights, optimizer and
+    scheduler are Lightning-resumable; `loops` (Lightning's fit-loop progress counters) is left empty — Lightning then restarts its
+    epoch counter from `epoch`."""
     sd = {"arch." + k: v.detach().cpu().clone() for k, v in module.arch.state_dict().items()}
     sd["stft.window"] = module.stft.window.detach().cpu().clone()
     ck = {"epoch": epoch, "global_step": global_step, "pytorch-lightning_version": "2.0.0", "state_dict": sd, "loops": {}, "callbacks": {},
@@ -218,7 +251,11 @@ def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, g
         group = {"lr": float(ts.lr), "betas": tuple(ts.betas), "eps": ts.eps, "weight_decay": ts.wd, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
         ck["optimizer_states"] = [{"state": state, "param_groups": [group]}]
-        ck["lr_schedulers"] = [{"last_epoch": epoch + 1, "_last_lr": [float(ts.lr)]}]
+        # a complete torch.optim.lr_scheduler.ExponentialLR.state_dict() (what Lightning stores and restores)
+        gamma = float((module.lr_scheduler or (None, {}))[1].get("gamma", 1.0)) if module.lr_scheduler else 1.0
+        base_lr = float(module.optimizer[1].get("lr", 1e-3))
+        ck["lr_schedulers"] = [{"gamma": gamma, "base_lrs": [base_lr], "last_epoch": epoch + 1, "verbose": False, "_step_count": epoch + 2,
+                                "_get_lr_called_within_step": False, "_last_lr": [float(ts.lr)]}]
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ck, path)
 
@@ -281,20 +318,42 @@ def _fused_step_for(module: "TrainModule", cfg: dict, dev):
     return eng, ts, gamma
 
 
-def _check_train_geometry(module: "TrainModule") -> None:
+def _check_train_geometry(module: "TrainModule", data=None) -> None:
     """`fit` on a SpatialNet shape without training kernels fails here, before the first step, with the reason"""
     hp = getattr(module.arch, "hp", {})
+    F = hp.get("num_freqs")
+    if module.precision not in ("bf16-mixed", "bf16") and F is not None and F > 160:
+        raise NotImplementedError(f"fit: the fp32-stream BACKWARD kernels hold whole frequency axes in LDS and stop at 160 bins (got num_freqs={F}); "
+                                  "train 16-kHz models with trainer.precision=bf16-mixed")
+    seg = getattr(data, "audio_time_len", None)
+    if seg and getattr(data, "sr", None):
+        frames = int(seg[0] * data.sr) // module.stft.n_hop + 1
+        if frames > 256:
+            raise NotImplementedError(f"fit: training segments of {seg[0]} s are {frames} frames; the training kernels keep one whole sequence per workgroup "
+                                      "in LDS (<= 256 frames: 4 s at n_hop 128 / 8 kHz) — cut data.audio_time_len[0]")
     if (hp.get("dim_hidden"), hp.get("dim_ffn"), hp.get("dim_squeeze"), hp.get("num_heads")) != (96, 192, 8, 4):
         raise NotImplementedError("fit: the MI355X TRAINING kernels are built for the SpatialNet-small geometry (dim_hidden 96, dim_ffn 192, dim_squeeze 8, "
                                   f"4 heads; configs/SpatialNet.yaml as shipped); got {hp.get('dim_hidden')}/{hp.get('dim_ffn')}/{hp.get('dim_squeeze')}/"
                                   f"{hp.get('num_heads')} — SpatialNet-large is served by validate | test | predict")
 
 
+def _is_fused_arch(cfg: dict) -> bool:
+    """models.arch.SpatialNet.SpatialNet is served by the fused HIP step / forward-only path; every other arch (NBSS narrow-band
+    models, OnlineSpatialNet) runs its torch.nn modules on the selected device through the generic loop"""
+    arch = (cfg.get("model") or {}).get("arch")
+    return isinstance(arch, dict) and arch.get("class_path") == "models.arch.SpatialNet.SpatialNet"
+
+
+def _on_host(cfg: dict) -> bool:
+    return cfg.get("trainer", {}).get("accelerator", "gpu") == "cpu" or not torch.cuda.is_available()
+
+
 def fit(cfg: dict) -> Dict[str, Any]:
     tr = cfg.get("trainer", {})
-    if tr.get("accelerator", "gpu") == "cpu" or not torch.cuda.is_available():
+    if _on_host(cfg) or not _is_fused_arch(cfg):
+        # the narrow-band archs / OnlineSpatialNet on either device (BASELINE configs 1, 4, 5), and trainer.accelerator=cpu
         from nbss_amd.host_trainer import fit_generic
-        return fit_generic(cfg, build_module, _instantiate)  # plumbing path of the non-SpatialNet archs (BASELINE config 1)
+        return fit_generic(cfg, build_module, _instantiate)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -310,7 +369,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
         data = SyntheticDataModule()
     if cfg.get("ckpt_path"):
         load_checkpoint(cfg["ckpt_path"], module)  # weights first: the engine binds the parameters below
-    _check_train_geometry(module)
+    _check_train_geometry(module, data)
     eng, ts, gamma = _fused_step_for(module, cfg, dev)
     first_epoch = 0
     if cfg.get("ckpt_path"):
@@ -357,9 +416,73 @@ def _setup(cfg: dict):
     return dev, module, data, ts
 
 
+def _setup_generic(cfg: dict):
+    """device, module, data module for the archs that run as torch.nn modules (PyTorch-ROCm compute on a HIP device, host otherwise)"""
+    tr = cfg.get("trainer", {})
+    dev = torch.device("cpu") if _on_host(cfg) else torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    torch.manual_seed(int(cfg.get("seed_everything", 2)))
+    module = build_module(cfg).to(dev).eval()
+    module.precision = str(tr.get("precision", "32"))
+    if cfg.get("ckpt_path"):
+        load_checkpoint(cfg["ckpt_path"], module)
+    data = _instantiate(cfg["data"]) if "data" in cfg else None
+    if data is None:
+        from data_loaders.synthetic import SyntheticDataModule
+        data = SyntheticDataModule()
+    return dev, module, data
+
+
+def _evaluate_generic(cfg: dict, stage: int) -> Dict[str, Any]:
+    dev, module, data = _setup_generic(cfg)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    tot, tot_in, n = 0.0, 0.0, 0
+    with torch.no_grad():
+        for x, ys, _ in data.batches(stage, rank, world, 0):
+            x, yr = x.to(dev), ys[:, :, module.ref_channel].to(dev).contiguous()
+            yr_hat, _ = module.forward(x)
+            loss, _, _ = module.loss(yr_hat=yr_hat, yr=yr, reorder=False, reduce_batch=True)
+            mix = x[:, module.ref_channel][:, None].expand_as(yr).contiguous()
+            loss_in, _, _ = module.loss(yr_hat=mix, yr=yr, reorder=False, reduce_batch=True)
+            tot, tot_in, n = tot + float(loss), tot_in + float(loss_in), n + 1
+    name = "val" if stage == 1 else "test"
+    rec = {f"{name}/neg_si_sdr": tot / max(n, 1), f"{name}/si_sdr_improvement_dB": (tot_in - tot) / max(n, 1), "batches": n, "device": str(dev)}
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    return rec
+
+
+def _predict_generic(cfg: dict) -> Dict[str, Any]:
+    """`predict` for the torch.nn archs.  OnlineSpatialNet with a fixed-size state ('mhsa(N)', 'ret(..)' without rotary positions) is
+    evaluated the way it is deployed: causal, `stream_chunk` frames at a time (CLI: --stream_chunk N, default 8) through
+    OnlineStreamer, whose step is captured once into a HIP graph on a HIP device and replayed (BASELINE config 5)."""
+    from models.arch.OnlineSpatialNet import OnlineSpatialNet
+    dev, module, data = _setup_generic(cfg)
+    out_dir = cfg.get("trainer", {}).get("default_root_dir")
+    chunk = int(cfg.get("stream_chunk", 8))
+    outs, info = [], {"device": str(dev), "streamed": False, "graph_replays": 0}
+    with torch.no_grad():
+        for bi, (x, ys, paras) in enumerate(data.batches(2, 0, 1, 0)):
+            x = x.to(dev)
+            if isinstance(module.arch, OnlineSpatialNet) and chunk > 0:
+                yr_hat, st = module.forward_streaming(x, chunk)
+                info["streamed"], info["graph_replays"] = True, info["graph_replays"] + st["graph_replays"]
+                info["frames_per_s"] = st["frames_per_s"]
+            else:
+                yr_hat, _ = module.forward(x)
+            outs.append(yr_hat.cpu())
+            if out_dir:
+                os.makedirs(out_dir, exist_ok=True)
+                torch.save({"yr_hat": outs[-1], "paras": paras}, os.path.join(out_dir, f"predict_{bi:05d}.pt"))
+    return {"yr_hat": outs, **info}
+
+
 def evaluate(cfg: dict, stage: int) -> Dict[str, Any]:
     """`validate` (stage 1) / `test` (stage 2): uPIT neg-SI-SDR of the separated signals and the SI-SDR improvement over the
     unprocessed reference-channel mixture, through the forward-only path (SharedTrainer.py:151-205 without the PESQ/STOI pools)."""
+    if not _is_fused_arch(cfg):
+        return _evaluate_generic(cfg, stage)
     from nbss_amd import ops
     dev, module, data, ts = _setup(cfg)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -382,6 +505,8 @@ def evaluate(cfg: dict, stage: int) -> Dict[str, Any]:
 
 def predict(cfg: dict) -> Dict[str, Any]:
     """`predict`: separated waveforms [B,Spk,N] of the test split (returned; written as .pt files when trainer.default_root_dir is set)"""
+    if not _is_fused_arch(cfg):
+        return _predict_generic(cfg)
     dev, module, data, ts = _setup(cfg)
     out_dir = cfg.get("trainer", {}).get("default_root_dir")
     outs = []

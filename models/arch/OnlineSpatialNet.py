@@ -323,6 +323,12 @@ class OnlineStreamer:
             b.copy_(s0)
 
     @torch.no_grad()
+    def reset(self) -> None:
+        """back to the empty state (a new utterance); the captured graph stays valid: it only refers to the buffers"""
+        for b in self._buffers():
+            b.zero_()
+
+    @torch.no_grad()
     def step(self, x_chunk: Tensor) -> Tensor:
         self.x.copy_(x_chunk)
         if self.use_graph:

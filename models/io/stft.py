@@ -36,7 +36,7 @@ class STFT(nn.Module):
         self.hip_ok = self.n_hop * 2 == self.n_fft and self.win_len == self.n_fft and n_fft in (256, 512)
         self.win = win
         self.repr = str((n_fft, n_hop, win, win_len))
-        w = torch.hann_window(self.win_len)
+        w = torch.hann_window(self.n_fft)  # (n_fft, not win_len: the reference's buffer shape, stft.py:29-35; `stft.window` is a checkpoint key)
         self.register_buffer("window", w if win == "hann_window" else w.sqrt())
         self._tab = {}
 
@@ -57,7 +57,7 @@ class STFT(nn.Module):
         from nbss_amd import ops
         from nbss_amd._lib import NBSS_F32, hip
         shape = list(x.shape)
-        if not x.is_cuda:  # host path
+        if not x.is_cuda or not self.hip_ok:  # host tensors, and STFT geometries outside the HIP kernels' {256, 512} / hop = n_fft/2
             X = torch.stft(x.reshape(-1, shape[-1]).float(), n_fft=self.n_fft, hop_length=self.n_hop, win_length=self.win_len,
                            window=self.window.to(x.device), return_complex=True)
             return X.reshape(shape[:-1] + list(X.shape[-2:])), shape[-1]
@@ -68,7 +68,7 @@ class STFT(nn.Module):
 
     def istft(self, X: Tensor, original_len: int = None) -> Tensor:
         shape = list(X.shape)
-        if not X.is_cuda:  # host path
+        if not X.is_cuda or not self.hip_ok:
             Xf = X.reshape(-1, *shape[-2:]).to(torch.complex64)
             y = torch.istft(Xf, n_fft=self.n_fft, hop_length=self.n_hop, win_length=self.win_len, window=self.window.to(X.device), length=original_len)
             return y.reshape(shape[:-2] + [original_len])

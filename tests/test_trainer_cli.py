@@ -187,3 +187,61 @@ def test_dropin_module_autograd_on_gpu():
         losses.append(float(loss))
     assert losses[-1] < losses[0]
     assert all(p.grad is not None for p in net.parameters())
+
+
+# ---- the archs that are NOT the fused SpatialNet step go through the generic loop on whichever device is selected (BASELINE configs 4, 5)
+NBC2_ARGS = ["--config", str(ROOT / "configs" / "NBC2.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml"),
+             "--model.arch.dim_input=16", "--model.arch.dim_output=6", "--model.channels=[0,1,2,3,4,5,6,7]", "--data.num_channels=8",
+             "--data.num_speakers=3", "--data.audio_time_len=[1.0,1.0,1.0]", "--data.num_samples=[4,2,2]", "--trainer.max_epochs=1"]
+ONLINE_ARGS = ["--config", str(ROOT / "configs" / "onlineSpatialNet.yaml"), "--config", str(ROOT / "configs" / "datasets" / "synthetic.yaml"),
+               "--model.arch.dim_input=12", "--model.arch.dim_output=4", "--model.arch.num_freqs=129", "--data.num_samples=[4,2,2]",
+               "--trainer.max_epochs=1"]
+
+
+def _finite(rec):
+    return all(torch.isfinite(torch.tensor(float(v))) for v in rec.values() if isinstance(v, (int, float)))
+
+
+def test_generic_archs_route_on_cpu(tmp_path):
+    """NBC2 (8 ch -> 3 spk) and OnlineSpatialNet ret(2): fit / validate / predict through TrainCLI with trainer.accelerator=cpu — the same
+    routing the gpu tests below exercise on the device; predict streams the OnlineSpatialNet chunk by chunk through OnlineStreamer"""
+    small = ["--trainer.accelerator=cpu", "--model.arch.n_layers=1", "--model.arch.dim_hidden=16", "--model.arch.dim_ffn=32"]
+    log = TrainCLI(argv=["fit"] + NBC2_ARGS + small).result["log"]
+    assert len(log) == 1 and log[0]["device"] == "cpu" and _finite(log[0])
+    rec = TrainCLI(argv=["validate"] + NBC2_ARGS + small).result
+    assert rec["batches"] >= 1 and rec["device"] == "cpu" and _finite(rec)
+    osmall = ["--trainer.accelerator=cpu", "--model.arch.num_layers=1", "--model.arch.dim_hidden=32", "--model.arch.dim_ffn=64",
+              "--model.arch.dim_squeeze=4", "--data.audio_time_len=[0.5,0.5,1.0]"]
+    log = TrainCLI(argv=["fit"] + ONLINE_ARGS + osmall + [f"--trainer.default_root_dir={tmp_path}"]).result["log"]
+    assert len(log) == 1 and _finite(log[0])
+    ck = str(tmp_path / "checkpoints" / "last.ckpt")
+    whole = TrainCLI(argv=["predict"] + ONLINE_ARGS + osmall + ["--ckpt_path", ck, "--stream_chunk=0"]).result
+    res = TrainCLI(argv=["predict"] + ONLINE_ARGS + osmall + ["--ckpt_path", ck, "--stream_chunk=8"]).result
+    assert res["streamed"] and not whole["streamed"] and res["yr_hat"][0].shape == (2, 2, 8000)
+    # the streamed (recurrent retention, 8 frames per step) output equals the whole-utterance (parallel retention) forward
+    a, b = res["yr_hat"][0], whole["yr_hat"][0]
+    assert float((a - b).norm() / b.norm()) < 5e-3
+
+
+@pytest.mark.gpu
+def test_nbc2_8ch_3spk_fit_validate_on_gpu():
+    """BASELINE config 4: NBC2 narrow-band Conformer, 8 channels -> 3 speakers, fp32, from the shipped YAML (accelerator: gpu)"""
+    log = TrainCLI(argv=["fit"] + NBC2_ARGS + ["--model.arch.n_layers=2"]).result["log"]
+    assert len(log) == 1 and log[0]["device"].startswith("cuda") and _finite(log[0])
+    rec = TrainCLI(argv=["validate"] + NBC2_ARGS + ["--model.arch.n_layers=2"]).result
+    assert rec["batches"] >= 1 and rec["device"].startswith("cuda") and _finite(rec)
+
+
+@pytest.mark.gpu
+def test_online_spatialnet_fit_and_streamed_predict_on_gpu(tmp_path):
+    """BASELINE config 5: OnlineSpatialNet ret(2) from the shipped YAML: one epoch of fit on the device, then `predict` on a 32-s input as
+    causal chunked inference with HIP-graph-replayed steps (OnlineStreamer), equal to the whole-utterance forward"""
+    args = ONLINE_ARGS + ["--model.arch.num_layers=2", "--data.audio_time_len=[1.0,1.0,32.0]", "--data.batch_size=[2,1]"]
+    log = TrainCLI(argv=["fit"] + args + [f"--trainer.default_root_dir={tmp_path}"]).result["log"]
+    assert len(log) == 1 and log[0]["device"].startswith("cuda") and _finite(log[0])
+    ck = str(tmp_path / "checkpoints" / "last.ckpt")
+    res = TrainCLI(argv=["predict"] + args + ["--ckpt_path", ck, "--stream_chunk=16"]).result
+    assert res["streamed"] and res["graph_replays"] >= 32 * 8000 // 128 // 16 and res["yr_hat"][0].shape == (1, 2, 256000)
+    whole = TrainCLI(argv=["predict"] + args + ["--ckpt_path", ck, "--stream_chunk=0"]).result
+    a, b = res["yr_hat"][0], whole["yr_hat"][0]
+    assert torch.isfinite(a).all() and float((a - b).norm() / b.norm()) < 1e-2
