@@ -104,6 +104,22 @@ NBSS_DEV void col_frag_rm(Frag<T>& f, const T* __restrict__ rowmajor, int half, 
     }
 }
 
+// four consecutive stream elements as loaded (converted only on use)
+template <class T> struct RawRow4;
+template <> struct RawRow4<bf16_t> {
+    u32x2 v;
+    NBSS_DEV void load(const bf16_t* p) { v = *reinterpret_cast<const u32x2*>(p); }
+    NBSS_DEV void get(float (&o)[4]) const {
+        o[0] = bf2f((bf16_t)(v[0] & 0xFFFF)); o[1] = bf2f((bf16_t)(v[0] >> 16));
+        o[2] = bf2f((bf16_t)(v[1] & 0xFFFF)); o[3] = bf2f((bf16_t)(v[1] >> 16));
+    }
+};
+template <> struct RawRow4<float> {
+    f32x4 v;
+    NBSS_DEV void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+    NBSS_DEV void get(float (&o)[4]) const { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+
 // FULL: T in (240, 256] — all 16 strips of every wave exist, so the strip / tile-existence tests are compile-time true and the
 // tile loops have constant trip counts (wave-uniform but dynamic branches kept the compiler from scheduling across them: the same
 // effect cost wgrad 24 %, profiles/README.md row 27)
@@ -134,11 +150,6 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     constexpr int WL_FR = TR ? 96 : 0;
     PHASE_BEGIN(wl + (size_t)WL_FR * 512);
     const size_t ntok = (size_t)c.B * c.F * T_;
-    if (TR) {
-        for (int v = threadIdx.x; v < 72 * 64; v += blockDim.x) reinterpret_cast<u32x4*>(wl)[v] = reinterpret_cast<const u32x4*>(Win)[v];
-        for (int v = threadIdx.x; v < 24 * 64; v += blockDim.x) reinterpret_cast<u32x4*>(wl + 72 * 512)[v] = reinterpret_cast<const u32x4*>(WoutT)[v];
-    }
-    for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) aff[i] = 0.f;
     const int bf = blockIdx.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)bf * T_;
@@ -157,38 +168,6 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
         tv[si] = tt[si] < T_;
         sact[si] = FULL || (w * MB_NSW + si) < nst;  // wave-uniform
     }
-
-    // Only the row statistics persist across the head loop: LN(x) and dy fragments are rebuilt per head and du is formed after
-    // the loop from the emitted dqkv operand (keeping them live spilled 336 B/lane in the first version).
-    for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) lnp[i] = i < MB_H ? lp.p[P_MH_LN_W][i] : lp.p[P_MH_LN_B][i - MB_H];
-    float smean[MB_NSW], srstd[MB_NSW];
-#pragma unroll
-    for (int si = 0; si < MB_NSW; ++si) {
-        float v[MB_KS][8], sum = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < MB_KS; ++ks) {
-            if (tv[si]) load8(xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4, v[ks]);
-            else
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += v[ks][j];
-        }
-        smean[si] = wave_sum16(sum) * (1.0f / MB_H);
-        float q = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < MB_KS; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) q += (v[ks][j] - smean[si]) * (v[ks][j] - smean[si]);
-        srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / MB_H) + 1e-5f);
-        if (XT && tv[si] && g4 == 0) {
-            stats[(n0 + tt[si]) * 2] = smean[si];
-            stats[(n0 + tt[si]) * 2 + 1] = srstd[si];
-        }
-    }
-    lds_barrier();  // lnp is read below
-    PHASE(0);
-
     // dqkv operand of the in_proj weight gradient.  bf16: group-major [12 (q|k|v x head)][N][24], a strip writes 768 contiguous
     // bytes (48-byte pieces of 576-byte token rows were partial-line writes); fp32: token-major [N][3H]
     auto dqkv_row = [&](int grp, size_t n) -> T* {
@@ -198,19 +177,71 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
     // and re-normalised per head (PMC: the per-head re-reads of x, dy missed L2 — 3 GB fetched per launch for 0.6 GB of inputs)
     constexpr bool DYREG = sizeof(T) == 2;
     Frag<T> uf[MB_NSW][MB_KS], dr[MB_NSW][MB_KS];
-    if (DYREG) {
+    float smean[MB_NSW], srstd[MB_NSW];
+    // saved attention output / log-sum-exp rows of the NEXT head, requested one head ahead (raw: no conversion, so nothing waits on them)
+    RawRow4<T> onx0[MB_NSW], onx1[MB_NSW];
+    float lsenx[MB_NSW];
+    auto request_o1 = [&](int head, int si) {
+        const int tc = tv[si] ? tt[si] : T_ - 1;  // clamped: the padding frames' values are replaced on use
+        onx0[si].load(ob + (size_t)tc * MB_H + head * MB_DH + 4 * g4);
+        onx1[si].load(ob + (size_t)tc * MB_H + head * MB_DH + 16 + 4 * (g4 & 1));
+        lsenx[si] = lse[(n0 + tc) * MB_HEADS + head];
+    };
+    auto request_o = [&](int head) {
 #pragma unroll
-        for (int si = 0; si < MB_NSW; ++si)
+        for (int si = 0; si < MB_NSW; ++si) request_o1(head, si);
+    };
+    if constexpr (DYREG) {
+        // Prologue of the bf16 kernel: EVERY global request of the workgroup's start is issued before anything waits — x / dy fragments,
+        // the 96 weight fragments (12 16-byte pieces per thread, parked in registers), head 0's saved O rows.  (One workgroup per CU:
+        // nothing else hides this latency; the serial form — weights through a load/store loop, then the statistics' reads, then the
+        // fragment reads, then O — was 14 % + most of another 18 % of the kernel's wave time, profiles/r03a_phase_prof.txt.)
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+            const int tc = tv[si] ? tt[si] : T_ - 1;
 #pragma unroll
             for (int ks = 0; ks < MB_KS; ++ks) {
-                if (tv[si]) {
-                    frag_load(uf[si][ks], xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
-                    frag_load(dr[si][ks], dyb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4);
-                } else {
-                    frag_zero(uf[si][ks]);
-                    frag_zero(dr[si][ks]);
-                }
+                frag_load(uf[si][ks], xb + (size_t)tc * MB_H + ks * 32 + 8 * g4);
+                frag_load(dr[si][ks], dyb + (size_t)tc * MB_H + ks * 32 + 8 * g4);
             }
+        }
+        constexpr int NWV = 96 * 64 / 512;  // 16-byte pieces per thread (blockDim.x == 512)
+        u32x4 wreg[NWV];
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int v = threadIdx.x + i * 512;
+            wreg[i] = v < 72 * 64 ? reinterpret_cast<const u32x4*>(Win)[v] : reinterpret_cast<const u32x4*>(WoutT)[v - 72 * 64];
+        }
+        request_o(0);
+        for (int i = threadIdx.x; i < 2 * MB_H; i += 512) {
+            aff[i] = 0.f;
+            lnp[i] = i < MB_H ? lp.p[P_MH_LN_W][i] : lp.p[P_MH_LN_B][i - MB_H];
+        }
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) reinterpret_cast<u32x4*>(wl)[threadIdx.x + i * 512] = wreg[i];
+        // LayerNorm statistics from the fragments already in registers, then LN(x) in place
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+            float sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += frag_get(uf[si][ks], j);
+            smean[si] = wave_sum16(sum) * (1.0f / MB_H);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = frag_get(uf[si][ks], j) - smean[si];
+                    q += d * d;
+                }
+            srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / MB_H) + 1e-5f);
+            if (XT && tv[si] && g4 == 0) {
+                stats[(n0 + tt[si]) * 2] = smean[si];
+                stats[(n0 + tt[si]) * 2 + 1] = srstd[si];
+            }
+        }
 #pragma unroll
         for (int si = 0; si < MB_NSW; ++si)
 #pragma unroll
@@ -221,7 +252,41 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     frag_set(uf[si][ks], j, tv[si] ? (frag_get(uf[si][ks], j) - smean[si]) * srstd[si] * gm[j] + bt[j] : bt[j]);
+                if (!tv[si]) frag_zero(dr[si][ks]);
             }
+        lds_barrier();  // weights, lnp, aff are in LDS
+        PHASE(0);
+    } else {
+        for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) aff[i] = 0.f;
+        // Only the row statistics persist across the head loop: LN(x) and dy fragments are rebuilt per head and du is formed after
+        // the loop from the emitted dqkv operand (keeping them live spilled 336 B/lane in the first version).
+        for (int i = threadIdx.x; i < 2 * MB_H; i += blockDim.x) lnp[i] = i < MB_H ? lp.p[P_MH_LN_W][i] : lp.p[P_MH_LN_B][i - MB_H];
+#pragma unroll
+        for (int si = 0; si < MB_NSW; ++si) {
+            float v[MB_KS][8], sum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                if (tv[si]) load8(xb + (size_t)tt[si] * MB_H + ks * 32 + 8 * g4, v[ks]);
+                else
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += v[ks][j];
+            }
+            smean[si] = wave_sum16(sum) * (1.0f / MB_H);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q += (v[ks][j] - smean[si]) * (v[ks][j] - smean[si]);
+            srstd[si] = rsqrtf(wave_sum16(q) * (1.0f / MB_H) + 1e-5f);
+            if (XT && tv[si] && g4 == 0) {
+                stats[(n0 + tt[si]) * 2] = smean[si];
+                stats[(n0 + tt[si]) * 2 + 1] = srstd[si];
+            }
+        }
+        lds_barrier();  // lnp is read below
+        PHASE(0);
     }
     for (int head = 0; head < MB_HEADS; ++head) {
         Frag<T> qf[MB_NSW], dof[MB_NSW];
@@ -242,15 +307,18 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                     frag_zero(dr[si][ks]);
                 }
             }
+            // this head's saved O / log2-sum-exp rows: bf16 — requested one head ago; fp32 — requested here (no registers to park them)
+            if (!DYREG) request_o1(head, si);
+            onx0[si].get(o0[si]);
+            onx1[si].get(o1[si]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o0[si][r] = o1[si][r] = 0.f;
-            lsev[si] = 1e30f;  // padding frame: P = exp2(S - lse) = 0
-            if (tv[si]) {
-                load4(ob + (size_t)tt[si] * MB_H + head * MB_DH + 4 * g4, o0[si]);
-                if (g4 < 2) load4(ob + (size_t)tt[si] * MB_H + head * MB_DH + 16 + 4 * g4, o1[si]);
-                lsev[si] = lse[(n0 + tt[si]) * MB_HEADS + head];  // log2-sum-exp of the score row, saved by the forward pass
+            for (int r = 0; r < 4; ++r) {
+                o0[si][r] = keep_if(tv[si], o0[si][r]);
+                o1[si][r] = keep_if(tv[si] && g4 < 2, o1[si][r]);
             }
+            lsev[si] = tv[si] ? lsenx[si] : 1e30f;  // padding frame: P = exp2(S - lse) = 0
         }
+        if (DYREG) request_o(head + 1 < MB_HEADS ? head + 1 : head);  // (last head: a harmless re-read, keeps the loop body uniform)
 #pragma unroll
         for (int si = 0; si < MB_NSW; ++si)
 #pragma unroll
