@@ -89,8 +89,13 @@ int nbss_full_fwd(const nbss_cfg* cfg, const float* params, const void* packed, 
  * before out_proj ([B,F,T,H] of cfg->dtype) followed by the fp32 log2-sum-exp of every (token, head) score row. */
 int64_t nbss_mhsa_save_bytes(const nbss_cfg* cfg);
 int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* o_save, void* stream);
-/* x + _tconvffn (SpatialNet.py:90,102-114,61-73). */
-int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream);
+/* x + _tconvffn (SpatialNet.py:90,102-114,61-73).
+ * t_save (optional, nbss_tconvffn_save_bytes(cfg) bytes; that is 0 — pass NULL — for the geometries / stream types whose backward
+ * recomputes the chain instead): what a training-mode forward keeps for nbss_tconvffn_bwd — the bf16 outputs of the 1x1 conv and of
+ * the three grouped T-convs (tconvffn.1 / .3 / .5 / .8 of SpatialNet.py:61-73, group-major), the LayerNorm statistics of every token
+ * and the GroupNorm statistics of every (sequence, group). */
+int64_t nbss_tconvffn_save_bytes(const nbss_cfg* cfg);
+int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* t_save, void* stream);
 
 /* ---- SpatialNet sub-blocks, backward (autograd of the forward entry points) ------------------
  * x: the forward INPUT of the block (the only saved activation; everything else is recomputed
@@ -100,8 +105,9 @@ int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* pack
  * nbss_workspace_bytes(cfg) bytes (per-token LayerNorm statistics and the operands of the
  * weight-gradient contractions). */
 int64_t nbss_workspace_bytes(const nbss_cfg* cfg);
+/* t_save: the forward's saved state (see nbss_tconvffn_fwd), or NULL: the forward chain is recomputed from x */
 int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
-                      void* dx, void* ws, void* stream);
+                      const void* t_save, void* dx, void* ws, void* stream);
 int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
                   const void* o_save, void* dx, void* ws, void* stream);
 int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, int which, const void* x,
@@ -117,8 +123,8 @@ int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const v
 /* ---- whole network (SpatialNet.forward, SpatialNet.py:202-220, and its autograd) ---------------
  * Native sequencing of the sub-block kernels: encoder, L x [fconv1, full, fconv2, mhsa, tconvffn],
  * decoder.  xin [B,F,T,C_in] of cfg->dtype, out/dout [B,F,T,C_out] fp32.
- * acts: nbss_acts_bytes() bytes holding the 5L+1 block inputs and the L attention outputs that
- * backward re-reads; pass NULL for inference (then ws, >= nbss_train_ws_bytes(), is used as two
+ * acts: nbss_acts_bytes() bytes holding the 5L+1 block inputs, the L attention outputs and the L T-ConvFFN
+ * saves that backward re-reads; pass NULL for inference (then ws, >= nbss_train_ws_bytes(), is used as two
  * ping-pong stream buffers).  Backward accumulates into `grads` and needs ws >= nbss_train_ws_bytes(). */
 int64_t nbss_acts_bytes(const nbss_cfg* cfg);
 int64_t nbss_train_ws_bytes(const nbss_cfg* cfg);

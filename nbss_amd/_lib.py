@@ -50,10 +50,11 @@ SIGNATURES = {
     "nbss_fconv_fwd": (_I, [_CP, _P, _P, _I, _I, _P, _P, _P]),
     "nbss_full_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
     "nbss_mhsa_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P, _P]),
-    "nbss_tconvffn_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P]),
+    "nbss_tconvffn_save_bytes": (C.c_int64, [_CP]),
+    "nbss_tconvffn_fwd": (_I, [_CP, _P, _P, _I, _P, _P, _P, _P]),
     "nbss_workspace_bytes": (C.c_int64, [_CP]),
     "nbss_mhsa_save_bytes": (C.c_int64, [_CP]),
-    "nbss_tconvffn_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "nbss_tconvffn_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "nbss_mhsa_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "nbss_fconv_bwd": (_I, [_CP, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "nbss_full_bwd": (_I, [_CP, _P, _P, _P, _I, _P, _P, _P, _P, _P]),

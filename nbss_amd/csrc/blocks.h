@@ -252,8 +252,8 @@ NBSS_DEV void ln_bwd_row96_raw_na(f32x4 (&du)[BK_MT], const RawC4<T> (&xr)[BK_MT
 // system and stalled the barriers of the first version: 24.7 ms -> see profiles/.)
 struct AffSegs {
     int n;
-    long long off[6];  // destination offsets in the flat gradient buffer
-    int cnt[6];        // consecutive elements per segment; the partial row is the concatenation
+    long long off[8];  // destination offsets in the flat gradient buffer
+    int cnt[8];        // consecutive elements per segment; the partial row is the concatenation
 };
 int affine_reduce_launch(const float* part, int nwg, const AffSegs& segs, float* G, hipStream_t st);
 

@@ -12,10 +12,11 @@ int full_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int lay
 int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st);
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                   void* dx, void* ws, hipStream_t st);
-int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
+int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st);
+size_t tconvffn_save_bytes(const nbss_cfg& c);
 
-int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
-                      void* ws, hipStream_t st);
+int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,
+                      void* dx, void* ws, hipStream_t st);
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                    void* ws, hipStream_t st);
@@ -132,11 +133,17 @@ int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const 
     return mhsa_bwd_impl(*cfg, params, grads, packed, layer, x, dy, o_save, dx, ws, (hipStream_t)stream);
 }
 
-int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* stream) {
+int64_t nbss_tconvffn_save_bytes(const nbss_cfg* cfg) {
+    if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
+    return (int64_t)tconvffn_save_bytes(*cfg);
+}
+
+int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* packed, int layer, const void* x, void* y, void* t_save, void* stream) {
     CHECK_CFG(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !packed || !x || !y || x == y) return NBSS_EINVAL;
-    return tconvffn_fwd_impl(*cfg, params, packed, layer, x, y, (hipStream_t)stream);
+    if (t_save && tconvffn_save_bytes(*cfg) == 0) return NBSS_EUNSUPPORTED;
+    return tconvffn_fwd_impl(*cfg, params, packed, layer, x, y, t_save, (hipStream_t)stream);
 }
 
 int64_t nbss_workspace_bytes(const nbss_cfg* cfg) {
@@ -145,11 +152,12 @@ int64_t nbss_workspace_bytes(const nbss_cfg* cfg) {
 }
 
 int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
-                      void* dx, void* ws, void* stream) {
+                      const void* t_save, void* dx, void* ws, void* stream) {
     CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
-    return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
+    if (t_save && tconvffn_save_bytes(*cfg) == 0) return NBSS_EUNSUPPORTED;
+    return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, t_save, dx, ws, (hipStream_t)stream);
 }
 
 int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, int which, const void* x,
@@ -186,9 +194,19 @@ static size_t stream_bytes(const nbss_cfg& c) {
     return ws_align((size_t)c.B * c.F * c.T * c.H * (c.dtype == NBSS_BF16 ? 2 : 4));
 }
 
+// saved state of the whole network: [5L+1 block inputs | L attention saves | L T-ConvFFN saves (bf16 stream; NBSS_TCF_RECOMPUTE flavour: none)]
+static size_t tcf_save_bytes(const nbss_cfg& c) {
+#ifdef NBSS_TCF_RECOMPUTE
+    return 0;
+#else
+    return ws_align(tconvffn_save_bytes(c));
+#endif
+}
+static size_t acts_tcf_offset(const nbss_cfg& c) { return (size_t)(5 * c.L + 1) * stream_bytes(c) + (size_t)c.L * mhsa_save_bytes(c); }
+
 int64_t nbss_acts_bytes(const nbss_cfg* cfg) {
     if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
-    return (int64_t)((size_t)(5 * cfg->L + 1) * stream_bytes(*cfg) + (size_t)cfg->L * mhsa_save_bytes(*cfg));
+    return (int64_t)(acts_tcf_offset(*cfg) + (size_t)cfg->L * tcf_save_bytes(*cfg));
 }
 
 int64_t nbss_train_ws_bytes(const nbss_cfg* cfg) {
@@ -218,7 +236,8 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
         if ((e = full_fwd_impl(c, params, packed, l, buf(k + 1), buf(k + 2), st))) return e;
         if ((e = fconv_fwd_impl(c, params, packed, l, 1, buf(k + 2), buf(k + 3), st))) return e;
         if ((e = mhsa_fwd_impl(c, params, packed, l, buf(k + 3), buf(k + 4), osave, st))) return e;
-        if ((e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), st))) return e;
+        void* tsave = acts && tcf_save_bytes(c) ? (void*)((char*)acts + acts_tcf_offset(c) + (size_t)l * tcf_save_bytes(c)) : nullptr;
+        if ((e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), tsave, st))) return e;
         k += 5;
     }
     return decoder_fwd_impl(c, params, packed, buf(k), out, st);
@@ -245,7 +264,8 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
     if (layer_hi == c.L && (e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, dA, ws, st))) return e;
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const void* osave = (const char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c);
-        if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), dA, dB, ws, st))) return e;
+        const void* tsave = tcf_save_bytes(c) ? (const void*)((const char*)acts + acts_tcf_offset(c) + (size_t)l * tcf_save_bytes(c)) : nullptr;
+        if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), dA, tsave, dB, ws, st))) return e;
         if ((e = mhsa_bwd_impl(c, params, grads, packed, l, act(k - 2), dB, osave, dA, ws, st))) return e;
         if ((e = fconv_bwd_impl(c, params, grads, packed, l, 1, act(k - 3), dA, dB, ws, st))) return e;
         if ((e = full_bwd_impl(c, params, grads, packed, l, act(k - 4), dB, dA, ws, st))) return e;

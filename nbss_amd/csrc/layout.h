@@ -215,11 +215,17 @@ NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // whole conv weight gradient [H][H / groups][ks] + its bias [H] as this workgroup's two frames see it; affine_reduce folds the rows
 #define NBSS_FC_PROW(c) (3 * (c).H + (c).H * ((c).H / (c).f_groups) * (c).f_ks + (c).H)
 NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * ((c.T + 1) / 2) * NBSS_FC_PROW(c) * sizeof(float); }
+// T-ConvFFN backward from saved pre-activations (tconvffn_s.hip: tconvffn_bwd_v_kernel; bf16 stream, small geometry): one partial row per
+// sequence = the GroupNorm affine sums (2 FFN) + the three conv weight gradients [FFN][FFN / groups][ks] with their biases [FFN]
+#define NBSS_TC_PROW(c) (2 * (c).FFN + 3 * ((c).FFN * ((c).FFN / (c).t_groups) * (c).t_ks + (c).FFN))
+NBSS_HD size_t tc_part_bytes(const nbss_cfg& c) {
+    return c.dtype == NBSS_BF16 && c.H == 96 && c.T <= 256 ? (size_t)c.B * c.F * NBSS_TC_PROW(c) * sizeof(float) : 0;
+}
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
     return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) +
-           ws_align(fc_part_bytes(c)) + 256;
+           ws_align(fc_part_bytes(c)) + ws_align(tc_part_bytes(c)) + 256;
 }
 // attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32
 NBSS_HD size_t mhsa_lse_offset(const nbss_cfg& c) {
@@ -244,6 +250,8 @@ NBSS_HD size_t ws_wgpart_offset(const nbss_cfg& c) {
 
 // the fused f-conv weight-gradient partial rows live behind the wgrad partial tiles
 NBSS_HD size_t ws_fcpart_offset(const nbss_cfg& c) { return ws_wgpart_offset(c) + ws_align(WGPART_BYTES); }
+// ... and the T-ConvFFN partial rows behind those
+NBSS_HD size_t ws_tcpart_offset(const nbss_cfg& c) { return ws_fcpart_offset(c) + ws_align(fc_part_bytes(c)); }
 
 NBSS_HD int check_cfg(const nbss_cfg& c) {
     if (c.B <= 0 || c.F <= 0 || c.T <= 0 || c.L <= 0) return NBSS_EINVAL;

@@ -1111,8 +1111,52 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
     return NBSS_CHECK_LAUNCH();
 }
 
-int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx,
-                      void* ws, hipStream_t st) {
+int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5,
+                          void* op_da1, hipStream_t st);
+float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave);
+
+// bf16 stream, from the pre-activations a training-mode forward saved (tconvffn_s.hip): data gradient + the three T-conv weight gradients in
+// one kernel, the tail + W1 weight gradient in tailw.hip, one fold of the per-sequence partial rows, the W2 weight gradient through wgrad.hip
+static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* tsave,
+                              void* dx, void* ws, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const size_t N = (size_t)c.B * c.F * c.T;
+    char* base = (char*)ws + ws_align(N * 2 * sizeof(float));
+    void* op_h5 = base + (size_t)3 * ws_align(N * TF_FFN * 2);
+    void* op_da1 = base + (size_t)4 * ws_align(N * TF_FFN * 2);
+    float* part = (float*)((char*)ws + ws_tcpart_offset(c));
+    float* wgpart = (float*)((char*)ws + ws_wgpart_offset(c));
+    int e;
+    {
+        ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
+        if ((e = tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_h5, op_da1, st))) return e;
+        if ((e = tailw_tconvffn(c, lp, packed, layer, x, dy, dx, tconvffn_save_ln_stats(c, tsave), op_da1, wgpart, G, P, st))) return e;
+    }
+    const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convBias[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
+    AffSegs sg;
+    sg.n = 8;
+    sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
+    sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
+    for (int k = 0; k < 3; ++k) {
+        sg.off[2 + 2 * k] = param_off(c, layer, convW[k]); sg.cnt[2 + 2 * k] = TF_FFN * TF_CG * 3;
+        sg.off[3 + 2 * k] = param_off(c, layer, convBias[k]); sg.cnt[3 + 2 * k] = TF_FFN;
+    }
+    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
+    // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
+    WgradArgs a;
+    a.part = wgpart;
+    a.mvalid = 0; a.nvalid = 0;
+    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = op_h5; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
+    a.b_gw = TF_CG; a.b_gs = (int)(N * TF_CG);
+    a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
+    return wgrad_launch(a, c.dtype, st);
+}
+
+int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,
+                      void* dx, void* ws, hipStream_t st) {
+    if (tsave && c.dtype == NBSS_BF16) return tconvffn_bwd_saved(c, P, G, packed, layer, x, dy, const_cast<void*>(tsave), dx, ws, st);
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats [N][2] f32 | h1 h2 h4 h5 da1 da2 da3 da5, each [N][FFN] of the stream dtype
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
@@ -1177,14 +1221,15 @@ static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed,
     return NBSS_CHECK_LAUNCH();
 }
 
-int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, float* gn_save, hipStream_t st);
+int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st);
 
 int tconvffn_fwd_large_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
 
-int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+// tsave (optional; bf16 stream, T <= 256, small geometry — tconvffn_save_bytes() > 0): the training-mode forward keeps its pre-activations there
+int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st) {
     if (c.H != TF_H) return tconvffn_fwd_large_impl(c, P, packed, layer, x, y, st);  // SpatialNet-large, forward only (tconvffn_g.hip)
     // bf16 stream: the streaming wave-per-group kernel (tconvffn_s.hip); fp32 stream: the group-serial kernel above
     // sequences beyond 256 frames (forward only): the chunked two-pass variant of the group-serial kernel
     if (c.T > TF_TP) return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t, 1, true>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float, 2, true>(c, P, packed, layer, x, y, st);
-    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, nullptr, st) : tconvffn_fwd_t<float, 2, false>(c, P, packed, layer, x, y, st);
+    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, tsave, st) : tconvffn_fwd_t<float, 2, false>(c, P, packed, layer, x, y, st);
 }

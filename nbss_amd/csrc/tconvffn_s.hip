@@ -86,6 +86,21 @@ NBSS_DEV void silu_pack(const f32x16& a, uint32_t vm, P6& out) {
     for (int i = 0; i < 6; ++i) out.d[i] = pack2bf(silu_f(a[2 * i]), silu_f(a[2 * i + 1])) & vm;
 }
 
+NBSS_DEV void p6_gstore(bf16_t* __restrict__ g, const P6& p, bool ok, bool nt) {  // g = &op[group][token][4 h]
+#ifdef NBSS_K1_NOSTORE  // knock-out probe (flavour build): how much of the kernel is the operand stores?
+    return;
+#endif
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x2 v = {p.d[2 * q], p.d[2 * q + 1]};
+#ifndef NBSS_EMU
+        if (nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(g + 8 * q));
+        else
+#endif
+            *reinterpret_cast<u32x2*>(g + 8 * q) = v;
+    }
+}
 NBSS_DEV FragH frag_const_one() {  // K slot 0 = 1.0, the rest 0: the B side of a bias slot
     u32x4 v = {TS_ONE, 0u, 0u, 0u};
     FragH f;
@@ -140,9 +155,19 @@ struct TsFwdW {  // packed fragment bases of one layer
 
 #define TS_SB 2  // strips per block of a group phase (independent MFMA chains in flight)
 
-// gn_save: optional [B*F][G][2] (mean, rstd) of every GroupNorm group for the backward pass
+// What a training-mode forward keeps for the backward pass (tconvffn_bwd_v_kernel below): the four pre-activations a1 (W1 output), a2, a3
+// (conv1 / conv2 outputs; a3 = GroupNorm input) and a5 (conv3 output) as group-major [G][N][24] bf16 tensors — what the reference's
+// autocast graph holds as bf16 conv outputs —, the LayerNorm (mean, rstd) of every token and the GroupNorm (mean, rstd) of every
+// (sequence, group).  With them the backward pass evaluates each SiLU / SiLU' pair from ONE sigmoid and recomputes no convolution.
+struct TsSave {
+    bf16_t *a1, *a2, *a3, *a5;
+    float *ln, *gn;  // [N][2], [B*F][G][2]
+};
+
+// SAVE: training-mode forward (sv is filled); inference launches the SAVE = false instance (no stores, no extra packing)
+template <bool SAVE>
 __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPtrs lp, TsFwdW W, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                             float* __restrict__ gn_save) {
+                                                             TsSave sv) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32;
     bf16_t* img = reinterpret_cast<bf16_t*>(smem);  // [NT + TS_PAD][TS_RS]
@@ -158,6 +183,7 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
     // One workgroup per sequence.  (A persistent grid of 256 workgroups looping over sequences was measured SLOWER, 675 vs 524 us
     // per launch at batch 31: all CUs then march through the HBM-latency and the VALU-bound phases in lock step.)
     const int bf = blockIdx.x;
+    const size_t n0 = (size_t)bf * T_, ntok = (size_t)c.B * c.F * T_;
     {
     const bf16_t* xb = x + (size_t)bf * T_ * TS_H;
     bf16_t* yb = y + (size_t)bf * T_ * TS_H;
@@ -209,6 +235,10 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
             }
         sq += __shfl_xor(sq, 32);
         const float rstd = rsqrtf(sq * (1.0f / TS_H) + 1e-5f);
+        if (SAVE && tv && L.h == 0) {
+            sv.ln[(n0 + t) * 2] = mean;
+            sv.ln[(n0 + t) * 2 + 1] = rstd;
+        }
         FragH u[7];
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
@@ -237,6 +267,12 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
             P6 h1;
             silu_pack(a1, vm, h1);
             p6_store(orow + g * TS_CG, h1);
+            if (SAVE) {
+                P6 pa;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a1[2 * i], a1[2 * i + 1]);
+                p6_gstore(sv.a1 + ((size_t)g * ntok + n0 + t) * TS_CG + 4 * L.h, pa, tv, true);
+            }
         }
     }
     PHASE(0);
@@ -254,6 +290,7 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
     // ---- group phases: wave g owns channels 24g..24g+23 of every row ------------------------------------------------------------
     const int g = w, cbase = g * TS_CG;
     bf16_t* col = img + cbase;  // &img[0][24 g]
+    const size_t gsave = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;  // this lane's piece of token 0 in a saved [G][N][24] tensor
     // conv1: h1 (rows 3 + t) -> h2 = SiLU(.) (rows 2 + t)
 #pragma unroll 1
     for (int s0 = 0; s0 < NS; s0 += TS_SB) {
@@ -268,6 +305,12 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                 P6 h2;
                 silu_pack(a2, lane_mask(32 * (s0 + k) + L.n < T_), h2);
                 p6_store(col + (size_t)(2 + 32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, h2);
+                if (SAVE) {
+                    P6 pa;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a2[2 * i], a2[2 * i + 1]);
+                    p6_gstore(sv.a2 + gsave + (size_t)(32 * (s0 + k) + L.n) * TS_CG, pa, 32 * (s0 + k) + L.n < T_, true);
+                }
             }
     }
     if (L.lane < 6) *reinterpret_cast<u32x2*>(col + (size_t)(2 + NT) * TS_RS + 4 * L.lane) = (u32x2){0u, 0u};  // "frame NT" of the next stage
@@ -300,6 +343,7 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                     s2 += v0 * v0 + v1 * v1;
                 }
                 p6_store(col + (size_t)(1 + 32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, a3p);
+                if (SAVE) p6_gstore(sv.a3 + gsave + (size_t)(32 * (s0 + k) + L.n) * TS_CG, a3p, 32 * (s0 + k) + L.n < T_, true);
             }
     }
     if (L.lane < 6) *reinterpret_cast<u32x2*>(col + (size_t)(1 + NT) * TS_RS + 4 * L.lane) = (u32x2){0u, 0u};
@@ -308,9 +352,9 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
     const float cnt = (float)(TS_CG * T_);
     const float mean = s1 / cnt;
     const float rstd = rsqrtf(fmaxf(s2 / cnt - mean * mean, 0.f) + 1e-5f);
-    if (gn_save && L.lane == 0) {
-        gn_save[((size_t)bf * TS_G + g) * 2] = mean;
-        gn_save[((size_t)bf * TS_G + g) * 2 + 1] = rstd;
+    if (SAVE && L.lane == 0) {
+        sv.gn[((size_t)bf * TS_G + g) * 2] = mean;
+        sv.gn[((size_t)bf * TS_G + g) * 2 + 1] = rstd;
     }
     PHASE(3);
     // GroupNorm + SiLU in place (each lane rewrites the values it wrote: no cross-lane hazard)
@@ -353,6 +397,12 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                 P6 h5;
                 silu_pack(a5, lane_mask(32 * (s0 + k) + L.n < T_), h5);
                 p6_store(col + (size_t)(32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, h5);
+                if (SAVE) {
+                    P6 pa;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a5[2 * i], a5[2 * i + 1]);
+                    p6_gstore(sv.a5 + gsave + (size_t)(32 * (s0 + k) + L.n) * TS_CG, pa, 32 * (s0 + k) + L.n < T_, true);
+                }
             }
     }
     PHASE(5);
@@ -423,8 +473,25 @@ size_t tconvffn_s_fwd_lds(int T) {
     return (NT + TS_PAD) * TS_RS * sizeof(bf16_t) + (size_t)TS_WL_FR * 512 * sizeof(bf16_t) + PHASE_LDS_BYTES;
 }
 
-// bf16 stream only; returns NBSS_EUNSUPPORTED when the sequence does not fit the LDS image
-int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, float* gn_save, hipStream_t st) {
+// layout of one layer's saved state (tconvffn_save_bytes(c) bytes): a1 | a2 | a3 | a5 ([G][N][24] bf16 each) | LayerNorm stats [N][2] f32 |
+// GroupNorm stats [B*F][G][2] f32
+size_t tconvffn_save_bytes(const nbss_cfg& c) {
+    if (c.dtype != NBSS_BF16 || c.H != TS_H || c.T > 256) return 0;
+    const size_t N = (size_t)c.B * c.F * c.T;
+    return 4 * ws_align(N * TS_FFN * sizeof(bf16_t)) + ws_align(N * 2 * sizeof(float)) + ws_align((size_t)c.B * c.F * TS_G * 2 * sizeof(float));
+}
+TsSave ts_save_ptrs(const nbss_cfg& c, void* tsave) {
+    const size_t N = (size_t)c.B * c.F * c.T, tb = ws_align(N * TS_FFN * sizeof(bf16_t));
+    char* b = (char*)tsave;
+    TsSave sv;
+    sv.a1 = (bf16_t*)b; sv.a2 = (bf16_t*)(b + tb); sv.a3 = (bf16_t*)(b + 2 * tb); sv.a5 = (bf16_t*)(b + 3 * tb);
+    sv.ln = (float*)(b + 4 * tb);
+    sv.gn = (float*)(b + 4 * tb + ws_align(N * 2 * sizeof(float)));
+    return sv;
+}
+
+// bf16 stream only; returns NBSS_EUNSUPPORTED when the sequence does not fit the LDS image.  tsave != nullptr: training-mode forward
+int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st) {
     if (c.dtype != NBSS_BF16) return NBSS_EUNSUPPORTED;
     const size_t lds = tconvffn_s_fwd_lds(c.T);
     if (lds > 160 * 1024 || c.T > 256) return NBSS_EUNSUPPORTED;
@@ -432,11 +499,17 @@ int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, i
     const bf16_t* pk = (const bf16_t*)packed;
     TsFwdW W = {pk + pack_off(c, layer, K_TS_W1), pk + pack_off(c, layer, K_TS_C1), pk + pack_off(c, layer, K_TS_C2), pk + pack_off(c, layer, K_TS_C3),
                 pk + pack_off(c, layer, K_TS_W2)};
-    int e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel, lds);
-    if (e) return e;
     dim3 grid(c.B * c.F), block(512);
     ProfScope ps(PK_TCF_F, st);
-    NBSS_LAUNCH(tconvffn_fwd_s_kernel, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, gn_save);
+    int e;
+    if (tsave) {
+        if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<true>, lds))) return e;
+        NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave));
+    } else {
+        TsSave none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<false>, lds))) return e;
+        NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none);
+    }
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -485,21 +558,6 @@ NBSS_DEV void p6_unpack(const P6& p, float (&v)[12]) {
 NBSS_DEV void p6_pack(const float (&v)[12], uint32_t vm, P6& p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) p.d[i] = pack2bf(v[2 * i], v[2 * i + 1]) & vm;
-}
-NBSS_DEV void p6_gstore(bf16_t* __restrict__ g, const P6& p, bool ok, bool nt) {  // g = &op[group][token][4 h]
-#ifdef NBSS_K1_NOSTORE  // knock-out probe (flavour build): how much of the kernel is the operand stores?
-    return;
-#endif
-    if (!ok) return;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        u32x2 v = {p.d[2 * q], p.d[2 * q + 1]};
-#ifndef NBSS_EMU
-        if (nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(g + 8 * q));
-        else
-#endif
-            *reinterpret_cast<u32x2*>(g + 8 * q) = v;
-    }
 }
 NBSS_DEV void p6_gload(const bf16_t* __restrict__ g, P6& p) {
 #pragma unroll
@@ -1084,3 +1142,466 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     NBSS_LAUNCH(tconvffn_bwd_s_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, (const bf16_t*)x, (const bf16_t*)dy, part, ops, stats, pstride);
     return NBSS_CHECK_LAUNCH();
 }
+
+// =====================================================================================================================================
+// Backward (data gradient + the three T-conv weight gradients) from the pre-activations a training-mode forward SAVED (TsSave above).
+// Round-2's kernel above recomputes the forward chain (LayerNorm, W1, three convolutions, GroupNorm statistics: two thirds of its wave
+// time, profiles/r03a_phase_prof.txt) and then writes six of its activations / gradients out as operands of three wgrad launches.  Here
+//   * nothing is recomputed: each stage loads ONE saved pre-activation tensor (group-major, the owning wave's own strips), evaluates
+//     SiLU and SiLU' from one sigmoid, puts the activation into a second LDS image H and parks the derivative in registers;
+//   * the gradient chain lives in the in-place image S exactly as before (dh5 = W2^T dy in the strip phase, then conv3^T, GroupNorm
+//     backward, conv2^T, conv1^T with the two T-halves shifting towards each other);
+//   * between two gradient stages both operands of a conv weight gradient are resident as row-major [frame][channel] images —
+//     da_{k+1} in S, h_k in H — so wave (group, m) contracts dW[g] = sum_t da[t]^T h[t + tap - 1] over the WHOLE sequence with
+//     transposing LDS reads (K = 32 frames per MFMA; m = which 16 of the group's 24 output channels; the 72 (tap, input-channel)
+//     columns are five 16-wide tiles whose 4-column pieces carry their own tap shift in the read address), bias gradients through a
+//     constant-one operand, and the workgroup's partial leaves in dW's own memory order inside the sequence's `part` row, which
+//     affine_reduce folds (the fconv_bwd pattern, profiles/README.md row 45).
+// Gone per layer: 12 S.B of operand stores, 12 S.B of operand reads, three wgrad_tr3 launches; new: 8 S.B of saved pre-activations written
+// by the forward and read here, 170 KB of partial row per sequence.  Still emitted: h5 (W2 weight gradient) and da1 (tail + W1 weight
+// gradient, tailw.hip).
+struct TvIn {
+    const bf16_t *a1, *a2, *a3, *a5;
+    const float* gn;
+};
+struct TvW {
+    const bf16_t *W2T, *C1T, *C2T, *C3T;
+};
+#define TV_CONVW (TS_FFN * TS_CG * 3)                 // one conv weight [192][24][3]
+#define TV_PSTRIDE (2 * TS_FFN + 3 * (TV_CONVW + TS_FFN))  // floats per `part` row: GN w | GN b | (conv W | conv b) x 3
+
+// dW tile accumulation of one conv group over the whole sequence.  Sg = &S[0][24 gl], Hg = &H[0][24 gl]; bases (bl, bu) as in the stage that
+// wrote S; H holds token t at row t + 1 (rows 0 and NT + 1 are zero).
+NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, int NS, int NSL, int mt, f32x4 (&acc)[5], f32x4& bsum) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int rowoff = 4 * g4 + (l15 >> 2);
+    int boff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int pc = 4 * j + (l15 & 3);
+        pc = pc < 18 ? pc : 17;  // (the last tile's two dummy pieces re-read a valid one; their columns are never flushed)
+        const int tap = pc / 6, ch4 = pc - 6 * tap;
+        boff[j] = (tap + rowoff) * TB_RS + 4 * ch4;
+    }
+    const int aoff = rowoff * TB_RS + 16 * mt + 4 * (l15 & 3);
+    Frag<bf16_t> ones;
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) frag_set(ones, jq, 1.0f);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[j] = F32X4_ZERO;
+    bsum = F32X4_ZERO;
+    for (int ks = 0; ks < NS; ++ks) {
+        const int base = (ks < NSL ? bl : bu) + 32 * ks;
+        Frag<bf16_t> fa, fb[5];
+        frag_load_tr(fa, Sg + (size_t)base * TB_RS + aoff, TB_RS);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) frag_load_tr(fb[j], Hg + (size_t)(32 * ks) * TB_RS + boff[j], TB_RS);
+        bsum = mma(fa, ones, bsum);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[j] = mma(fa, fb[j], acc[j]);
+    }
+}
+// prow = the sequence's partial row at the conv's weight block ([192][24][3] in the parameter's own order, then its [192] bias)
+NBSS_DEV void tv_flush(float* __restrict__ prow, int g, int mt, const f32x4 (&acc)[5], const f32x4& bsum) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = 16 * mt + 4 * g4 + r;
+        if (oc < TS_CG) {
+            const int o = g * TS_CG + oc;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int pc = 4 * j + (l15 >> 2);
+                if (pc < 18) {
+                    const int tap = pc / 6, i = (pc - 6 * tap) * 4 + (l15 & 3);
+                    prow[((size_t)o * TS_CG + i) * 3 + tap] = acc[j][r];
+                }
+            }
+            if (l15 == 0) prow[TV_CONVW + o] = bsum[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPtrs lp, TvW W, TvIn sv, const bf16_t* __restrict__ dy, float* __restrict__ part,
+                                                             bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1) {
+    NBSS_LDS(smem);
+    const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
+    bf16_t* S = reinterpret_cast<bf16_t*>(smem);         // [NT + TB_PAD][TB_RS]  the gradient chain, in place
+    bf16_t* H = S + (size_t)(NT + TB_PAD) * TB_RS;      // [NT + 2][TB_RS]       the activation of the current stage (first: the W2^T window)
+    const size_t h_el = (size_t)(NT + 2) * TB_RS > (size_t)24 * 512 ? (size_t)(NT + 2) * TB_RS : (size_t)24 * 512;
+    float* red = reinterpret_cast<float*>(H + h_el);     // [4 groups][2 halves][2]
+    float* gnp = red + 16;                               // [2 halves][2 kinds][96] GroupNorm affine partial sums
+    bf16_t* mbox = reinterpret_cast<bf16_t*>(gnp + 4 * 96);  // [8 waves][24]
+    bf16_t* wl = H;
+    PHASE_BEGIN(mbox + 8 * TS_CG);
+    const TsLane L;
+    const int w = wave_id_u(), tid = threadIdx.x;
+    const int row = blockIdx.x >> 1, gh = blockIdx.x & 1;
+    const size_t n0 = (size_t)row * T_, ntok = (size_t)c.B * c.F * T_;
+    const bf16_t* dyb = dy + n0 * TS_H;
+
+    // group-phase roles (wave = (group gl, half th)) — needed already here: the FIRST group stage's input (a3 of the wave's own strips)
+    // is requested together with the strip phase's inputs
+    const int gl = w >> 1, th = w & 1, g = 4 * gh + gl;
+    const int s_beg = th ? NSL : 0, s_end = th ? NS : NSL, nblk = (s_end - s_beg + TB_SB - 1) / TB_SB;
+    const size_t gsv = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;  // this lane's piece of token 0 in a saved [G][N][24] tensor
+    P6 pn0, pn1, pn2, pn3, pd0, pd1, pd2, pd3, ra0, ra1, ra2, ra3;
+#define TV_LOADA(k, src, dst)                                                        \
+    {                                                                                \
+        const int t_ = 32 * (s_beg + (k)) + L.n, tc_ = t_ < T_ ? t_ : T_ - 1;        \
+        if (s_beg + (k) < s_end) p6_gload((src) + gsv + (size_t)tc_ * TS_CG, dst);   \
+        else                                                                         \
+            for (int i_ = 0; i_ < 6; ++i_) dst.d[i_] = 0u;                           \
+    }
+#define TV_LOADA4(src) TV_LOADA(0, src, ra0) TV_LOADA(1, src, ra1) TV_LOADA(2, src, ra2) TV_LOADA(3, src, ra3)
+    // ---- strip phase: dh5 = W2^T dy, (h5, SiLU'(a5)) from the saved a5: da5 -> S at bases (1,7), h5 -> operand --------------------------------
+    {
+        u32x4 wr[3];  // 24 W2^T fragments of this workgroup's four groups
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wr[i] = reinterpret_cast<const u32x4*>(W.W2T + (size_t)gh * 24 * 512)[tid + i * 512];
+        u32x4 rawd[6];
+        P6 a5r[4];
+        const int t = 32 * w + L.n, tc = t < T_ ? t : T_ - 1;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) rawd[ks] = *reinterpret_cast<const u32x4*>(dyb + (size_t)tc * TS_H + 16 * ks + 8 * L.h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p6_gload(sv.a5 + ((size_t)(4 * gh + q) * ntok + n0 + tc) * TS_CG + 4 * L.h, a5r[q]);
+        TV_LOADA4(sv.a3)
+        for (int i = tid; i < 4 * TB_RS / 2; i += 512) reinterpret_cast<uint32_t*>(S)[i] = 0u;
+        for (int i = tid; i < 5 * TB_RS / 2; i += 512) reinterpret_cast<uint32_t*>(S + (size_t)(NT + 4) * TB_RS)[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) reinterpret_cast<u32x4*>(wl)[tid + i * 512] = wr[i];
+        PHASE(0);
+        lds_barrier();
+        PHASE(1);
+        if (w < NS) {
+            const bool tv = t < T_;
+            const uint32_t vm = lane_mask(tv);
+            FragH dq[6];
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) dq[ks].v = __builtin_bit_cast(s16x8, rawd[ks]);
+            bf16_t* srow = S + (size_t)((w < NSL ? 1 : 7) + t) * TB_RS + 4 * L.h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                FragH w2t[6];
+                load_wfrags<6>(w2t, wl, q, L.lane);
+                f32x16 d5 = mma32(w2t[0], dq[0], f32x16_zero());
+#pragma unroll
+                for (int ks = 1; ks < 6; ++ks) d5 = mma32(w2t[ks], dq[ks], d5);
+                float a5[12], hv[12], dv[12];
+                p6_unpack(a5r[q], a5);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) {
+                    silu_dsilu(a5[r], hv[r], dv[r]);
+                    dv[r] *= d5[r];
+                }
+                P6 ph, pd;
+                p6_pack(hv, vm, ph);
+                p6_pack(dv, vm, pd);
+                p6_store(srow + q * TS_CG, pd);
+                p6_gstore(op_h5 + ((size_t)(4 * gh + q) * ntok + n0 + t) * TS_CG + 4 * L.h, ph, tv, true);
+            }
+        }
+    }
+    PHASE(2);
+
+    // ---- group phases: wave = (group gl, half th) ------------------------------------------------------------------------------------------------
+    bf16_t* Sc = S + gl * TS_CG;
+    bf16_t* Hc = H + gl * TS_CG;
+    const int run0 = 32 * s_beg, nrun = 32 * (s_end - s_beg);
+    auto rowp = [&](int tt, int bl, int bu) -> const bf16_t* { return Sc + (size_t)((tt < TS ? bl : bu) + tt) * TB_RS; };
+    auto orow = [&](int tt, int bl, int bu) -> bf16_t* { return Sc + (size_t)((th ? bu : bl) + tt) * TB_RS + 4 * L.h; };
+    bf16_t* mb = mbox + w * TS_CG;
+    auto fetch_cross = [&](int bl, int bu) {  // (see tconvffn_bwd_s_kernel: the one row a wave reads across the middle is copied before the stage writes)
+        const bf16_t* src = Sc + (size_t)(th ? bl + TS - 1 : bu + TS) * TB_RS;
+        if (L.lane < 6) *reinterpret_cast<u32x2*>(mb + 4 * L.lane) = *reinterpret_cast<const u32x2*>(src + 4 * L.lane);
+        lds_barrier();
+    };
+    auto rowx = [&](int tt, int bl, int bu) -> const bf16_t* {
+        const bool lower = tt < TS;
+        const bf16_t* r = Sc + (size_t)((lower ? bl : bu) + tt) * TB_RS;
+        return lower != (th == 0) ? mb : r;
+    };
+    float gw[12], gb[12];
+    chan_vec12(lp.p[P_TF_GN_W] + g * TS_CG, L.h, gw);
+    chan_vec12(lp.p[P_TF_GN_B] + g * TS_CG, L.h, gb);
+    const float cnt = (float)(TS_CG * T_);
+    const float gmean = sv.gn[((size_t)row * TS_G + g) * 2], grstd = sv.gn[((size_t)row * TS_G + g) * 2 + 1];
+    float* prow = part + (size_t)row * TV_PSTRIDE + 2 * TS_FFN;
+
+    FragH wt[5];
+    load_wfrags<5>(wt, W.C3T, g, L.lane);
+    // per-strip parks pn* / pd* / ra*: named registers + per-dword selects (indexed structs become scratch arrays, see the kernel above)
+#define TV_PICK(dst, k_, hib_, q0, q1, q2, q3)                                                            \
+    for (int i_ = 0; i_ < 6; ++i_) {                                                                      \
+        const uint32_t lo_ = (k_) == 0 ? q0.d[i_] : q1.d[i_], hi_ = (k_) == 0 ? q2.d[i_] : q3.d[i_];      \
+        dst.d[i_] = (hib_) ? hi_ : lo_;                                                                   \
+    }
+#define TB_BLOCKS(fwd_dir)                                                   \
+    for (int bi_ = 0; bi_ < nblk; ++bi_)                                     \
+        for (int s0 = s_beg + TB_SB * (((fwd_dir) == (th == 0)) ? bi_ : nblk - 1 - bi_), once_ = 1; once_; once_ = 0)
+
+    // stage 1: a3 -> a3hat (parked), h4 = SiLU(a3hat gw + gb) -> H, SiLU' parked
+    lds_barrier();  // S = da5 is complete; the weight window (aliasing H) is dead
+    PHASE(3);
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(Hc + (size_t)(th ? NT + 1 : 0) * TB_RS + 4 * L.lane) = (u32x2){0u, 0u};  // H's halo rows
+#define TV_STAGE1(k, RA, PN, PD)                                                          \
+    if (s_beg + (k) < s_end) {                                                            \
+        const int t = 32 * (s_beg + (k)) + L.n;                                           \
+        const uint32_t vm = lane_mask(t < T_);                                            \
+        float a3[12], hv[12], dv[12];                                                     \
+        p6_unpack(RA, a3);                                                                \
+        for (int q = 0; q < 12; ++q) a3[q] = (a3[q] - gmean) * grstd;                     \
+        p6_pack(a3, vm, PN);                                                              \
+        p6_unpack(PN, a3);                                                                \
+        for (int q = 0; q < 12; ++q) silu_dsilu(a3[q] * gw[q] + gb[q], hv[q], dv[q]);     \
+        P6 ph;                                                                            \
+        p6_pack(hv, vm, ph);                                                              \
+        p6_pack(dv, vm, PD);                                                              \
+        p6_store(Hc + (size_t)(1 + t) * TB_RS + 4 * L.h, ph);                             \
+    } else {                                                                              \
+        for (int i_ = 0; i_ < 6; ++i_) PN.d[i_] = PD.d[i_] = 0u;                          \
+    }
+    TV_STAGE1(0, ra0, pn0, pd0)
+    TV_STAGE1(1, ra1, pn1, pd1)
+    TV_STAGE1(2, ra2, pn2, pd2)
+    TV_STAGE1(3, ra3, pn3, pd3)
+#undef TV_STAGE1
+    TV_LOADA4(sv.a2)  // needed in B3b: requested now, AHEAD of the contraction's partial-row stores (loads and stores share vmcnt)
+    PHASE(4);
+    lds_barrier();
+    PHASE(5);
+    // stage 2: conv3 weight gradient: da5 (1,7) x h4
+    {
+        f32x4 acc[5], bsum;
+        tv_contract(Sc, Hc, 1, 7, NS, NSL, th, acc, bsum);
+        tv_flush(prow + 2 * (TV_CONVW + TS_FFN), g, th, acc, bsum);
+    }
+    PHASE(6);
+    // B3: conv3^T: da5 (1,7) -> dh4; dn3 = dh4 * SiLU'(n3) -> S (2,6); GroupNorm backward sums and affine gradients
+    fetch_cross(1, 7);
+    PHASE(7);
+    {
+        float sa = 0.f, sb = 0.f, dgw[12], dgb[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) dgw[r] = dgb[r] = 0.f;
+#pragma unroll 1
+        TB_BLOCKS(false) {
+            FragH b[TB_SB][5];
+            const bool hib = s0 - s_beg >= 2;
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    conv_bfrags3(L, rowx(t - 1, 1, 7), rowp(t, 1, 7), rowx(t + 1, 1, 7), b[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    const uint32_t vm = lane_mask(t < T_);
+                    const f32x16 dh4 = conv_mma(wt, b[k]);
+                    P6 pn, pdv, pd;
+                    TV_PICK(pn, k, hib, pn0, pn1, pn2, pn3)
+                    TV_PICK(pdv, k, hib, pd0, pd1, pd2, pd3)
+                    float ah[12], d4[12], dn[12];
+                    p6_unpack(pn, ah);
+                    p6_unpack(pdv, d4);
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) dn[r] = dh4[r] * d4[r];
+                    p6_pack(dn, vm, pd);
+                    p6_unpack(pd, dn);  // masked, bf16 (what the next stage reads back)
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) {
+                        dgw[r] += dn[r] * ah[r];
+                        dgb[r] += dn[r];
+                        sa += gw[r] * dn[r];
+                        sb += gw[r] * dn[r] * ah[r];
+                    }
+                    p6_store(orow(t, 2, 6), pd);
+                }
+        }
+        sa = wave_sum64(sa);
+        sb = wave_sum64(sb);
+        if (L.lane == 0) {
+            red[(gl * 2 + th) * 2] = sa;
+            red[(gl * 2 + th) * 2 + 1] = sb;
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const float a = half_sum32(dgw[r]), bq = half_sum32(dgb[r]);
+            if (L.n == 0) {
+                const int ch = gl * TS_CG + (r & 3) + 8 * (r >> 2) + 4 * L.h;
+                gnp[(th * 2 + 0) * 96 + ch] = a;
+                gnp[(th * 2 + 1) * 96 + ch] = bq;
+            }
+        }
+        if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 6 : 1) * TB_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    }
+    load_wfrags<5>(wt, W.C2T, g, L.lane);
+    PHASE(8);
+    lds_barrier();
+    PHASE(9);
+    // B3b (in place, own values): da3 = rstd (gw dn3 - mean(gw dn3) - a3hat mean(gw dn3 a3hat)) -> S (2,6);
+    // and the next activation: (h2, SiLU'(a2)) from the saved a2: h2 -> H (every wave is past its conv3 contraction), SiLU' parked
+    {
+        const float msa = (red[gl * 4] + red[gl * 4 + 2]) / cnt, msb = (red[gl * 4 + 1] + red[gl * 4 + 3]) / cnt;
+#define TV_STAGE3B(k, RA, PN, PD)                                                         \
+    if (s_beg + (k) < s_end) {                                                            \
+        const int t = 32 * (s_beg + (k)) + L.n;                                           \
+        const uint32_t vm = lane_mask(t < T_);                                            \
+        bf16_t* r = orow(t, 2, 6);                                                        \
+        P6 pdn, po, ph;                                                                   \
+        p6_load(r, pdn);                                                                  \
+        float dn[12], ah[12], a2[12], hv[12], dv[12];                                     \
+        p6_unpack(pdn, dn);                                                               \
+        p6_unpack(PN, ah);                                                                \
+        for (int q = 0; q < 12; ++q) dn[q] = grstd * (gw[q] * dn[q] - msa - ah[q] * msb); \
+        p6_pack(dn, vm, po);                                                              \
+        p6_store(r, po);                                                                  \
+        p6_unpack(RA, a2);                                                                \
+        for (int q = 0; q < 12; ++q) silu_dsilu(a2[q], hv[q], dv[q]);                     \
+        p6_pack(hv, vm, ph);                                                              \
+        p6_pack(dv, vm, PD);                                                              \
+        p6_store(Hc + (size_t)(1 + t) * TB_RS + 4 * L.h, ph);                             \
+    }
+        TV_STAGE3B(0, ra0, pn0, pd0)
+        TV_STAGE3B(1, ra1, pn1, pd1)
+        TV_STAGE3B(2, ra2, pn2, pd2)
+        TV_STAGE3B(3, ra3, pn3, pd3)
+#undef TV_STAGE3B
+        TV_LOADA4(sv.a1)  // needed at the end of B2: requested ahead of the conv2 contraction's stores
+    }
+    PHASE(10);
+    lds_barrier();
+    PHASE(11);
+    // conv2 weight gradient: da3 (2,6) x h2
+    {
+        f32x4 acc[5], bsum;
+        tv_contract(Sc, Hc, 2, 6, NS, NSL, th, acc, bsum);
+        tv_flush(prow + 1 * (TV_CONVW + TS_FFN), g, th, acc, bsum);
+    }
+    PHASE(12);
+    // B2: conv2^T: da3 (2,6) -> dh2; da2 = dh2 * SiLU'(a2) (parked) -> S (3,5)
+    fetch_cross(2, 6);
+    PHASE(13);
+#pragma unroll 1
+    TB_BLOCKS(false) {
+        FragH b[TB_SB][5];
+        const bool hib = s0 - s_beg >= 2;
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowx(t - 1, 2, 6), rowp(t, 2, 6), rowx(t + 1, 2, 6), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const uint32_t vm = lane_mask(t < T_);
+                const f32x16 dh2 = conv_mma(wt, b[k]);
+                P6 pdv, po;
+                TV_PICK(pdv, k, hib, pd0, pd1, pd2, pd3)
+                float d2[12], o[12];
+                p6_unpack(pdv, d2);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) o[r] = dh2[r] * d2[r];
+                p6_pack(o, vm, po);
+                p6_store(orow(t, 3, 5), po);
+            }
+    }
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 5 : 2) * TB_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    load_wfrags<5>(wt, W.C1T, g, L.lane);
+    // (h1, SiLU'(a1)) from the saved a1: h1 -> H (every wave passed fetch_cross' barrier, i.e. its conv2 contraction), SiLU' parked in pn*
+#define TV_STAGE5(k, RA, PN)                                                              \
+    if (s_beg + (k) < s_end) {                                                            \
+        const int t = 32 * (s_beg + (k)) + L.n;                                           \
+        const uint32_t vm = lane_mask(t < T_);                                            \
+        float a1[12], hv[12], dv[12];                                                     \
+        P6 ph;                                                                            \
+        p6_unpack(RA, a1);                                                                \
+        for (int q = 0; q < 12; ++q) silu_dsilu(a1[q], hv[q], dv[q]);                     \
+        p6_pack(hv, vm, ph);                                                              \
+        p6_pack(dv, vm, PN);                                                              \
+        p6_store(Hc + (size_t)(1 + t) * TB_RS + 4 * L.h, ph);                             \
+    }
+    TV_STAGE5(0, ra0, pn0)
+    TV_STAGE5(1, ra1, pn1)
+    TV_STAGE5(2, ra2, pn2)
+    TV_STAGE5(3, ra3, pn3)
+#undef TV_STAGE5
+    PHASE(14);
+    lds_barrier();
+    PHASE(15);
+    // conv1 weight gradient: da2 (3,5) x h1
+    {
+        f32x4 acc[5], bsum;
+        tv_contract(Sc, Hc, 3, 5, NS, NSL, th, acc, bsum);
+        tv_flush(prow, g, th, acc, bsum);
+    }
+    PHASE(16);
+    // B1: conv1^T: da2 (3,5) -> dh1; da1 = dh1 * SiLU'(a1) (parked) -> S (4,4) -> operand (whole rows, this wave's own run)
+    fetch_cross(3, 5);
+    PHASE(17);
+#pragma unroll 1
+    TB_BLOCKS(false) {
+        FragH b[TB_SB][5];
+        const bool hib = s0 - s_beg >= 2;
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowx(t - 1, 3, 5), rowp(t, 3, 5), rowx(t + 1, 3, 5), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const uint32_t vm = lane_mask(t < T_);
+                const f32x16 dh1 = conv_mma(wt, b[k]);
+                P6 pdv, po;
+                TV_PICK(pdv, k, hib, pn0, pn1, pn2, pn3)
+                float d1[12], o[12];
+                p6_unpack(pdv, d1);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) o[r] = dh1[r] * d1[r];
+                p6_pack(o, vm, po);
+                p6_store(orow(t, 4, 4), po);
+            }
+    }
+    wave_lds_sync();
+    rows_gstore<128 * 3>(op_da1 + ((size_t)g * ntok + n0 + run0) * TS_CG, Sc + (size_t)(4 + run0) * TB_RS, nrun, T_ - run0);
+    PHASE(18);
+#undef TB_BLOCKS
+#undef TV_PICK
+#undef TV_LOADA4
+#undef TV_LOADA
+    // GroupNorm affine partial sums of this workgroup's 96 channels -> the sequence's `part` row (written in B3, two barriers ago)
+    for (int i = tid; i < 2 * 96; i += 512) {
+        const int kind = i / 96, ch = i % 96;
+        part[(size_t)row * TV_PSTRIDE + kind * TS_FFN + gh * 96 + ch] = gnp[(0 * 2 + kind) * 96 + ch] + gnp[(1 * 2 + kind) * 96 + ch];
+    }
+    PHASE_END();
+}
+PHASE_READER(nbss_phase_read_tconvffn_bwd_v)
+
+size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * TV_PSTRIDE * sizeof(float); }
+
+// data-gradient + T-conv weight-gradient kernel from saved pre-activations; `part`: [B*F][TV_PSTRIDE] floats
+int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5,
+                          void* op_da1, hipStream_t st) {
+    if (c.dtype != NBSS_BF16 || c.T > 256 || !tsave) return NBSS_EUNSUPPORTED;
+    const size_t NT = (size_t)((c.T + 31) / 32) * 32;
+    const size_t h_el = (NT + 2) * TB_RS > (size_t)24 * 512 ? (NT + 2) * TB_RS : (size_t)24 * 512;
+    const size_t lds = ((NT + TB_PAD) * TB_RS + h_el) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + 8 * TS_CG * sizeof(bf16_t) + PHASE_LDS_BYTES;
+    const bf16_t* pk = (const bf16_t*)packed;
+    TvW W = {pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1_T), pk + pack_off(c, layer, K_TS_C2_T), pk + pack_off(c, layer, K_TS_C3_T)};
+    const TsSave s = ts_save_ptrs(c, tsave);
+    TvIn in = {s.a1, s.a2, s.a3, s.a5, s.gn};
+    int e = NBSS_SET_MAX_LDS(tconvffn_bwd_v_kernel, lds);
+    if (e) return e;
+    NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, (bf16_t*)op_h5, (bf16_t*)op_da1);
+    return NBSS_CHECK_LAUNCH();
+}
+float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave) { return ts_save_ptrs(c, tsave).ln; }

@@ -145,9 +145,16 @@ def mhsa_bwd(lib, cfg, flat, grads, packed, layer, x, dy, o_save, ws):
     return dx
 
 
-def tconvffn_fwd(lib, cfg, flat, packed, layer, x):
+def tconvffn_save(lib, cfg, device) -> Optional[Tensor]:
+    """buffer for what a training-mode T-ConvFFN forward keeps for backward (None: this geometry / stream type recomputes instead)"""
+    n = lib.nbss_tconvffn_save_bytes(C.byref(cfg))
+    return scratch(n, device) if n > 0 else None
+
+
+def tconvffn_fwd(lib, cfg, flat, packed, layer, x, t_save=None):
     y = torch.empty_like(x)
-    lib.call("nbss_tconvffn_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y), _stream(lib, x))
+    lib.call("nbss_tconvffn_fwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, packed), layer, _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, y),
+             _ptr(lib, t_save, torch.uint8) if t_save is not None else None, _stream(lib, x))
     return y
 
 
@@ -155,10 +162,11 @@ def workspace(lib, cfg, device) -> Tensor:
     return scratch(lib.nbss_workspace_bytes(C.byref(cfg)), device)
 
 
-def tconvffn_bwd(lib, cfg, flat, grads, packed, layer, x, dy, ws):
+def tconvffn_bwd(lib, cfg, flat, grads, packed, layer, x, dy, ws, t_save=None):
     dx = torch.empty_like(x)
     lib.call("nbss_tconvffn_bwd", C.byref(cfg), _ptr(lib, flat), _ptr(lib, grads, torch.float32), _ptr(lib, packed), layer,
-             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, dx), _ptr(lib, ws), _stream(lib, x))
+             _ptr(lib, x, stream_dtype(cfg)), _ptr(lib, dy, stream_dtype(cfg)), _ptr(lib, t_save, torch.uint8) if t_save is not None else None,
+             _ptr(lib, dx), _ptr(lib, ws), _stream(lib, x))
     return dx
 
 

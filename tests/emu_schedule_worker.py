@@ -43,6 +43,14 @@ def main():
                 ws.zero_()
                 out[key + name] = fn(G, ws)
                 out[key + name + "_G"] = G
+            tsv = ops.tconvffn_save(cs.lib, cs.cfg, x.device)
+            if tsv is not None:  # bf16 stream: training-mode forward + the backward kernel that reads what it saved
+                out[key + "tconvffn_fwd_save"] = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, t_save=tsv)
+                G = torch.zeros_like(cs.flat)
+                ws = ops.workspace(cs.lib, cs.cfg, x.device)
+                ws.zero_()
+                out[key + "tconvffn_bwd_saved"] = ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws, t_save=tsv)
+                out[key + "tconvffn_bwd_saved_G"] = G
         # long-sequence forward kernels (chunk / key-block boundaries)
         cs = Case(be, 1, 1, 300, dtype)
         x, _ = cs.stream(seed=32)

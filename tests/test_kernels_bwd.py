@@ -82,6 +82,30 @@ def test_tconvffn_bwd(backend, dtype):
                       lambda cs, G, x, dy, ws: ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws), TF_NAMES, seed=20)
 
 
+def test_tconvffn_bwd_from_saved_preactivations(backend):
+    """bf16 stream: the training-mode forward keeps its four pre-activations + LayerNorm / GroupNorm statistics; the backward kernel that
+    reads them (no forward recompute, the three T-conv weight gradients contracted in-kernel) meets the same bars as the recomputing one,
+    and the forward output is bitwise the inference forward's"""
+    shapes = [(1, 5, 19), (2, 33, 40), (1, 2, 256), (1, 3, 70)] + ([(2, 129, 251)] if backend.name == "hip" else [(1, 1, 251)])
+    for (B, F, T) in shapes:
+        saved = {}
+
+        def bwd(cs, G, x, dy, ws):
+            sv = ops.tconvffn_save(cs.lib, cs.cfg, backend.device)
+            assert sv is not None
+            y = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, t_save=sv)
+            saved["same"] = torch.equal(y, ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x))
+            return ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws, t_save=sv)
+
+        run_block_bwd(backend, NBSS_BF16, B, F, T, lambda x, p: ref.tconvffn(x, p, "layers.0"), bwd, TF_NAMES, seed=20)
+        assert saved["same"]
+
+
+def test_tconvffn_save_is_refused_where_backward_recomputes(backend):
+    cs = Case(backend, 1, 5, 19, NBSS_F32)
+    assert ops.tconvffn_save(cs.lib, cs.cfg, backend.device) is None  # fp32 stream: nbss_tconvffn_save_bytes == 0
+
+
 MH_NAMES = ["layers.0.norm_mhsa.weight", "layers.0.norm_mhsa.bias", "layers.0.mhsa.in_proj_weight", "layers.0.mhsa.in_proj_bias",
             "layers.0.mhsa.out_proj.weight", "layers.0.mhsa.out_proj.bias"]
 

@@ -27,6 +27,9 @@ def main():
     G = torch.zeros_like(flat)
     ws = ops.workspace(lib, cfg, dev)
     o = ops.mhsa_save(lib, cfg, dev)
+    tsv = ops.tconvffn_save(lib, cfg, dev)  # the training-mode forward's saved pre-activations (what the product backward reads)
+    if tsv is not None:
+        ops.tconvffn_fwd(lib, cfg, flat, packed, 0, x, t_save=tsv)
     fns = {
         "fconv_fwd": lambda: ops.fconv_fwd(lib, cfg, flat, packed, 0, 0, x),
         "mhsa_fwd": lambda: ops.mhsa_fwd(lib, cfg, flat, packed, 0, x, o_save=o),
@@ -34,7 +37,9 @@ def main():
         "fconv_bwd": lambda: ops.fconv_bwd(lib, cfg, flat, G, packed, 0, 0, x, dy, ws),
         "full_bwd": lambda: ops.full_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws),
         "mhsa_bwd": lambda: ops.mhsa_bwd(lib, cfg, flat, G, packed, 0, x, dy, o, ws),
-        "tconvffn_bwd": lambda: ops.tconvffn_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws),
+        "tconvffn_bwd": lambda: ops.tconvffn_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws, t_save=tsv),
+        "tconvffn_bwd_recompute": lambda: ops.tconvffn_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws),
+        "tconvffn_fwd_train": lambda: ops.tconvffn_fwd(lib, cfg, flat, packed, 0, x, t_save=tsv),
     }
     if name == "mhsa_bwd":
         fns["mhsa_fwd"]()
