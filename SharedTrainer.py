@@ -375,6 +375,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
     if cfg.get("ckpt_path"):
         first_epoch = load_checkpoint(cfg["ckpt_path"], module, ts) + 1  # (weights again: a no-op; now also the Adam state)
         eng.version += 1
+    ts.sync_replicas()  # rank 0's parameters / Adam state / step / lr on every rank (Lightning DDP's broadcast at fit start); no-op on one GPU
     ckpt_dir = tr.get("default_root_dir")
     log = []
     for epoch in range(first_epoch, int(tr.get("max_epochs", 1))):
@@ -384,6 +385,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
             tot += float(loss)
             n += 1
         ts.lr *= gamma
+        ts.check_replicas()  # every N steps (here: once per epoch): all ranks must still hold bitwise the same parameters and moments
         rec = {"epoch": epoch, "train/neg_si_sdr": tot / max(n, 1), "steps": n, "sec": time.time() - t0}
         log.append(rec)
         if rank == 0:

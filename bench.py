@@ -29,7 +29,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 S_BYTES_BF16 = 129 * 251 * 96 * 2  # one utterance's residual stream (S)
-HBM_PEAK = 8.0e12
+HBM_PEAK = 8.0e12    # B/s   (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_PEAK = 2.5e15   # FLOP/s dense bf16 (same guide; the 2:1-sparsity headline figure is not used)
+# algorithmic forward FLOPs per utterance of one sub-block launch (backward = 2x):
+# f-conv 373 M; full 49.7 + 66.8 + 49.7 M; attention 1 790 + 3 120 + 597 M; T-ConvFFN 5 072 M
+FWD_FLOPS = {"fconv": 373e6, "full": 166.2e6, "mhsa": 5507e6, "tconvffn": 5072e6}
+STEP_FLOPS = 277.0e9  # per utterance-train-step
 
 
 def synth_batch(B, C, S, N, seed, device):
@@ -63,6 +68,42 @@ def algorithmic_bytes(name, B):
     if name.endswith("_bwd") and name.split("_")[0] in ("fconv", "full", "mhsa", "tconvffn"):
         return 3 * S
     return None
+
+
+def algorithmic_flops(name, B):
+    """per-launch algorithmic FLOPs of a sub-block kernel (forward table above; backward = 2 x forward)"""
+    blk, _, d = name.rpartition("_")
+    if blk in FWD_FLOPS and d in ("fwd", "bwd"):
+        return FWD_FLOPS[blk] * B * (2 if d == "bwd" else 1)
+    return None
+
+
+def csrc_hash():
+    """identifies the kernel sources a PMC file was measured on (.git does not travel to the GPU box)"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted((ROOT / "nbss_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
+def roofline_entry(name, B, ms, cnt, share):
+    """both lower bounds of one sub-block kernel: algorithmic bytes at 8 TB/s and algorithmic FLOPs at 2.5 PFLOP/s (dense bf16 MFMA);
+    `bound` names the larger one — the kernel's own roofline — and `frac` is that bound's time over the measured launch duration"""
+    t = ms / cnt * 1e-3
+    by, fl = algorithmic_bytes(name, B), algorithmic_flops(name, B)
+    t_hbm, t_mfma = by / HBM_PEAK, fl / MFMA_PEAK
+    bound = "mfma" if t_mfma > t_hbm else "hbm"
+    e = {"kernel": name, "bound": bound, "avg_launch_us": t * 1e6, "launches": cnt,
+         "frac_hbm": t_hbm / t, "frac_mfma": t_mfma / t, "frac": max(t_hbm, t_mfma) / t,
+         "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl, "share_of_gpu_time": share}
+    if bound == "mfma":
+        e.update(achieved=fl / t / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s")
+    else:
+        e.update(achieved=by / t / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s")
+    return e
 
 
 def _cpu_train_step_fn(B, use_reference):
@@ -160,9 +201,58 @@ def self_launch(args):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(Path(__file__).resolve()), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--batch", str(args.batch)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+           "--batch", str(args.batch)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--dry-run"] if args.dry_run else [])
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the images this runs on export it (the host driver supports dmabuf IPC only; without it RCCL's
+    # hipIpcGetMemHandle fails between processes) — inherited when set, defaulted for shells that lost it; nothing else is altered
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def dry_run(args, rank, world):
+    """the launch / rendezvous / exchange skeleton of a multi-GPU run WITHOUT a GPU (tests, CPU containers): gloo instead of RCCL, the
+    real gradient-bucket table of the benchmark model, one all-reduce per bucket per step on host tensors, the same barrier + max-over-
+    ranks timing, the same JSON contract keys (value is meaningless and says so: "dry_run": true)"""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("gloo")
+    from nbss_amd.build import build_emu
+    from nbss_amd._lib import Lib, make_cfg
+    from nbss_amd.params import param_table
+    lib = Lib(build_emu())  # (parameter table only: arithmetic on the configuration, no kernel runs)
+    cfg = make_cfg(1, 129, 16, 12, 4, L=8)
+    n = max(off + int(torch.tensor(shape).prod()) for _, (off, shape) in param_table(lib, cfg).items())
+    grads = torch.full((n,), float(rank + 1))
+    bounds = [(i * n // 8, (i + 1) * n // 8) for i in range(8)]
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            hs = [torch.distributed.all_reduce(grads[lo:hi], async_op=True) for lo, hi in reversed(bounds)]
+            for h in hs:
+                h.wait()
+            grads.mul_(1.0 / world)
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    worlds = [world]
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+        worlds = [None] * world
+        torch.distributed.all_gather_object(worlds, torch.distributed.get_world_size())
+    if rank == 0:
+        print(json.dumps({"metric": "utterances/sec (4 s, 6ch, 129 freqs) SpatialNet bf16 train at 1/2/4/8 MI355X", "value": 0.0, "unit": "utterances/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "dry_run": True,
+                          "rccl_world": worlds, "backend": "gloo", "grad_elements": n,
+                          "config": {"workload": "launch / rendezvous / bucketed all-reduce skeleton only (no GPU)", "batch_per_gpu": args.batch,
+                                     "global_batch": args.batch * world, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main():
@@ -173,6 +263,7 @@ def main():
     # headline batch 32 (SURVEY.md §8(d) names B/GPU in {2, 8, 32}); the line also carries a short sweep over the other two
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-process launch + gradient exchange (gloo); no measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,6 +273,8 @@ def main():
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             self_launch(args)
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -200,6 +293,7 @@ def main():
     eng = SpatialNetEngine(lib, dev, dtype=NBSS_BF16, **net.hp)
     eng.load_params({k: v for k, v in net.named_parameters(remove_duplicate=False)})
     ts = TrainStep(eng, n_fft=256, ref_channel=0, lr=1e-3, clip=5.0)
+    ts.sync_replicas()  # rank 0's parameters / Adam state on every rank (what DDP's init broadcast does); no-op on one GPU
     B = args.batch
     x, yr = synth_batch(B, 6, 2, 32000, 1234 + rank, dev)
 
@@ -229,6 +323,8 @@ def main():
     # ---- timed region: EXACTLY --steps steps, events only around the dominant kernel ------------------
     if dom_id is not None:
         lib.nbss_profile_enable(1 << dom_id)
+    if world > 1:
+        ts.comm_wait_ms = 0.0  # accumulate the host-visible wait for the gradient buckets behind backward
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -242,32 +338,45 @@ def main():
         dt = float(tt)
     timed_prof = profile_read(lib)
     final_loss = float(loss)
+    comm_ms, worlds = None, [1]
+    if world > 1:
+        comm_ms = ts.comm_wait_read() / args.steps
+        ts.check_replicas()  # raises when the replicas' parameters / optimizer state differ after the timed steps
+        worlds = [None] * world
+        torch.distributed.all_gather_object(worlds, torch.distributed.get_world_size())  # what RCCL's group says on every rank
 
     if rank == 0:
         roof = None
         if dominant and timed_prof[dominant][1] > 0:
             ms, cnt = timed_prof[dominant]
-            per_launch = algorithmic_bytes(dominant, B)
-            ach = per_launch / (ms / cnt * 1e-3)
             total_gpu_ms = sum(v[0] for v in prof.values())
-            # HBM traffic and MFMA utilisation of the dominant kernel come from separate rocprofv3 --pmc passes of THIS kernel build
-            # (tools/round_artefacts.sh writes them with the commit they were measured on); a bench run cannot collect counters itself
+            roof = roofline_entry(dominant, B, ms, cnt, prof[dominant][0] / total_gpu_ms if total_gpu_ms > 0 else None)
+            # HBM traffic and MFMA utilisation of the dominant kernel come from separate rocprofv3 --pmc passes (tools/round_artefacts.sh writes
+            # them with the commit and a hash of nbss_amd/csrc they were measured on); a bench run cannot collect counters itself, so it
+            # says whether the committed figures belong to THIS build of the kernels
             traffic = traffic_commit = mfma_util = None
+            stale = None
+            here = csrc_hash()
             tfile = ROOT / "profiles" / "pmc_traffic.json"
             if tfile.exists():
                 tj = json.loads(tfile.read_text())
                 if tj.get("batch") == B and dominant in tj.get("kernels", {}):
-                    traffic, traffic_commit = tj["kernels"][dominant]["hbm_bytes"], tj.get("commit")
+                    k = tj["kernels"][dominant]
+                    traffic, traffic_commit = k["hbm_bytes"], k.get("commit", tj.get("commit"))
+                    stale = k.get("csrc_hash", tj.get("csrc_hash")) != here
             mfile = ROOT / "profiles" / "pmc_mfma.json"
             if mfile.exists():
                 mj = json.loads(mfile.read_text())
                 if dominant in mj.get("kernels", {}):
                     mfma_util = mj["kernels"][dominant].get("mfma_busy_frac")
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                    "traffic": traffic, "traffic_commit": traffic_commit, "mfma_util": mfma_util, "avg_launch_us": ms / cnt * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": per_launch,
-                    "share_of_gpu_time": prof[dominant][0] / total_gpu_ms if total_gpu_ms > 0 else None,
-                    "step_algorithmic": {"bytes_per_utt": 204 * S_BYTES_BF16, "achieved_GBps": world * B * args.steps / dt * 204 * S_BYTES_BF16 / 1e9 / world,
-                                         "frac_of_hbm_per_gpu": (B * args.steps / dt) * 204 * S_BYTES_BF16 / HBM_PEAK}}
+            roof.update(traffic=traffic, traffic_commit=traffic_commit, traffic_stale=stale, csrc_hash=here, mfma_util=mfma_util)
+            # the other sub-block kernels, same two bounds (from the profiled warm-up steps)
+            roof["all_kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in roofline_entry(k, B, v[0], v[1], None).items()
+                                       if kk in ("bound", "frac", "frac_hbm", "frac_mfma", "avg_launch_us")}
+                                   for k, v in prof.items() if algorithmic_bytes(k, B) and v[1] > 0}
+            ups = B * args.steps / dt  # per GPU
+            roof["step"] = {"bytes_per_utt": 204 * S_BYTES_BF16, "flops_per_utt": STEP_FLOPS, "frac_hbm": ups * 204 * S_BYTES_BF16 / HBM_PEAK,
+                            "frac_mfma": ups * STEP_FLOPS / MFMA_PEAK, "bound": "hbm" if 204 * S_BYTES_BF16 / HBM_PEAK > STEP_FLOPS / MFMA_PEAK else "mfma"}
         base = None
         sweep = None
         if world == 1 and not args.no_cpu_baseline:
@@ -294,6 +403,7 @@ def main():
                                    f"full train step (STFT..Adam), bf16 stream + fp32 master/stats, {B} utterances per GPU per step", "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "final_loss": final_loss},
             "roofline": roof, "cpu_baseline": base, "utt_per_s_by_batch": sweep,
+            "rccl_world": worlds, "comm_ms_per_step": comm_ms,
             "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in prof.items() if v[1] > 0},
         }
         print(json.dumps(line), flush=True)

@@ -179,6 +179,41 @@ class TrainStep:
             self.world = torch.distributed.get_world_size(process_group)
         # collectives run when world > 1; tests force them on a 1-rank RCCL group to exercise the stream ordering on hardware
         self.collectives = self.world > 1 or force_collectives
+        self.comm_wait_ms = None  # set to 0.0 by a caller that wants the host-visible time of the bucket waits accumulated (bench.py)
+
+    # ---- replica consistency (what Lightning's DDP does at fit start: broadcast of the module state from rank 0) --------
+    def sync_replicas(self, src: int = 0) -> None:
+        """rank `src`'s parameters, Adam moments and step count become every rank's (identical seeds already make them equal; this makes
+        it a guarantee, e.g. after a resume from a checkpoint only rank 0 read)"""
+        if not self.collectives:
+            return
+        e = self.e
+        for t in (e.params, self.m, self.v):
+            torch.distributed.broadcast(t, src=src, group=self.pg)
+        sc = torch.tensor([float(self.step_count), float(self.lr)], dtype=torch.float64, device=e.device)
+        torch.distributed.broadcast(sc, src=src, group=self.pg)
+        self.step_count, self.lr = int(sc[0].item()), float(sc[1].item())
+        e.version += 1
+        e.packed_for(e.dtype)
+
+    def replica_checksum(self) -> Tensor:
+        """[sum(params), sum(|params|), sum(exp_avg), sum(exp_avg_sq)] in fp64 on the device"""
+        p = self.e.params.double()
+        return torch.stack([p.sum(), p.abs().sum(), self.m.double().sum(), self.v.double().sum()])
+
+    def check_replicas(self) -> float:
+        """every rank must hold bitwise the same parameters and optimizer state (each applies the same reduced gradient with the same
+        kernel): all-reduces the min and the max of a checksum and raises when they differ; returns the spread (0.0 when consistent)"""
+        if not self.collectives:
+            return 0.0
+        c = self.replica_checksum()
+        lo, hi = c.clone(), c.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        spread = float((hi - lo).abs().max())
+        if spread != 0.0:
+            raise RuntimeError(f"data-parallel replicas diverged: checksum spread {spread:g} (min {lo.tolist()}, max {hi.tolist()})")
+        return spread
 
     def forward_loss(self, x: Tensor, yr: Tensor, need_grad: bool = True):
         """x [B,C,N] fp32 mixture, yr [B,S,N] fp32 targets -> (loss [1], yr_hat [B,S,N], dout or None, xin, xrmm)"""
@@ -207,12 +242,29 @@ class TrainStep:
             handles = []
             e.backward(xin, dout, on_bucket=lambda lo, hi: handles.append(
                 torch.distributed.all_reduce(e.grads[lo:hi], group=self.pg, async_op=True)))
-            for h in handles:
-                h.wait()
+            if self.comm_wait_ms is None:
+                for h in handles:
+                    h.wait()
+            else:  # how long the step's own stream has to wait for the exchange AFTER backward is enqueued: events around the waits
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for h in handles:
+                    h.wait()
+                e1.record()
+                self._comm_events = getattr(self, "_comm_events", []) + [(e0, e1)]
             self.apply_gradients(reduced=True)
         else:
             e.backward(xin, dout)
             self.apply_gradients()
+
+    def comm_wait_read(self) -> float:
+        """ms the compute stream spent in the bucket waits since the last call (needs comm_wait_ms = 0.0 before the steps)"""
+        ev = getattr(self, "_comm_events", [])
+        self._comm_events = []
+        if not ev:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in ev))
 
     def apply_gradients(self, reduced: bool = False) -> None:
         """[all-reduce] + clip + Adam + re-pack on whatever is in engine.grads (reduced=True: the buckets were summed already)"""

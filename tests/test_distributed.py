@@ -98,3 +98,43 @@ def test_overlapped_bucket_allreduce_equals_single_allreduce(tmp_path):
     a, b = outs[0]["bucketed"], outs[0]["single"]
     assert abs(a["norm"] - b["norm"]) < 1e-5 * b["norm"] and b["norm"] > 0
     assert float((a["params"] - b["params"]).norm() / b["params"].norm()) < 1e-6
+
+
+def _replica_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from nbss_amd._lib import NBSS_F32, Lib
+    from nbss_amd.build import build_emu
+    from nbss_amd.engine import SpatialNetEngine, TrainStep
+    lib = Lib(build_emu())
+    torch.manual_seed(10 + rank)  # DIFFERENT parameters / optimizer state per rank: what a resume on rank 0 only looks like
+    eng = SpatialNetEngine(lib, "cpu", dim_input=4, dim_output=4, num_freqs=9, num_layers=1, dtype=NBSS_F32)
+    eng.params.copy_(torch.randn_like(eng.params) * 0.1)
+    ts = TrainStep(eng, lr=1e-2 * (rank + 1), clip=0.5)
+    ts.m.copy_(torch.randn_like(ts.m))
+    ts.v.copy_(torch.rand_like(ts.v))
+    ts.step_count = 5 + rank
+    diverged = False
+    try:
+        ts.check_replicas()
+    except RuntimeError:
+        diverged = True
+    ts.sync_replicas()
+    spread = ts.check_replicas()
+    torch.save({"params": eng.params.clone(), "m": ts.m.clone(), "v": ts.v.clone(), "step": ts.step_count, "lr": ts.lr, "diverged": diverged, "spread": spread},
+               f"{tmp}/q{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_replica_broadcast_and_checksum(tmp_path):
+    """TrainStep.sync_replicas makes rank 0's parameters, Adam moments, step count and learning rate everyone's (DDP's init broadcast,
+    SURVEY.md §2.4); check_replicas raises while they differ and returns 0.0 afterwards"""
+    world, port = 2, 33500 + os.getpid() % 2000
+    mp.spawn(_replica_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (torch.load(tmp_path / f"q{r}.pt") for r in range(world))
+    assert a["diverged"] and b["diverged"] and a["spread"] == 0.0 and b["spread"] == 0.0
+    for k in ("params", "m", "v"):
+        assert torch.equal(a[k], b[k])
+    assert a["step"] == b["step"] == 5 and a["lr"] == b["lr"] == 1e-2

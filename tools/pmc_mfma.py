@@ -3,10 +3,21 @@ mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs
 in which a matrix pipe was busy (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles, summed over the SIMDs by rocprofv3's
 aggregation; GRBM_GUI_ACTIVE is summed over the 8 XCDs and is divided by 8 here).  valu_active_frac: the same for SQ_ACTIVE_INST_VALU
 (quad-cycles -> x4)."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
+from pathlib import Path
+
+
+def csrc_hash():  # same as bench.py: which kernel sources these counters belong to
+    h = hashlib.sha1()
+    for f in sorted((Path(__file__).resolve().parent.parent / "nbss_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-out = {"batch": B, "commit": os.environ.get("NBSS_COMMIT"), "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "kernels": {}}
+out = {"batch": B, "commit": os.environ.get("NBSS_COMMIT"), "csrc_hash": csrc_hash(), "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "kernels": {}}
 MEMBERS = {"tconvffn_bwd": ["tconvffn_bwd", "tconvffn_du", "tailw_kernel"], "mhsa_bwd": ["mhsa_bwd", "tailw_kernel"], "mhsa_fwd": ["mhsa_fwd", "mhsa_kv", "mhsa_flash"]}
 for k in ["fconv_fwd", "full_fwd", "mhsa_fwd", "tconvffn_fwd", "fconv_bwd", "full_bwd", "mhsa_bwd", "tconvffn_bwd"]:
     vals, per = {}, {}

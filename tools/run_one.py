@@ -30,13 +30,13 @@ def main():
         "fconv_fwd": lambda: ops.fconv_fwd(lib, cfg, flat, packed, 0, 0, x),
         "full_fwd": lambda: ops.full_fwd(lib, cfg, flat, packed, 0, x),
         "mhsa_fwd": lambda: ops.mhsa_fwd(lib, cfg, flat, packed, 0, x, o_save=o),
-        "tconvffn_fwd": lambda: ops.tconvffn_fwd(lib, cfg, flat, packed, 0, x),
+        "tconvffn_fwd": lambda: ops.tconvffn_fwd(lib, cfg, flat, packed, 0, x, t_save=tsv),  # training mode (what the step runs)
+        "tconvffn_fwd_infer": lambda: ops.tconvffn_fwd(lib, cfg, flat, packed, 0, x),
         "fconv_bwd": lambda: ops.fconv_bwd(lib, cfg, flat, G, packed, 0, 0, x, dy, ws),
         "full_bwd": lambda: ops.full_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws),
         "mhsa_bwd": lambda: ops.mhsa_bwd(lib, cfg, flat, G, packed, 0, x, dy, o, ws),
         "tconvffn_bwd": lambda: ops.tconvffn_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws, t_save=tsv),
         "tconvffn_bwd_recompute": lambda: ops.tconvffn_bwd(lib, cfg, flat, G, packed, 0, x, dy, ws),
-        "tconvffn_fwd_train": lambda: ops.tconvffn_fwd(lib, cfg, flat, packed, 0, x, t_save=tsv),
     }
     if name.startswith("mhsa_bwd"):
         fns["mhsa_fwd"]()
