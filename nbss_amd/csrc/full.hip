@@ -183,7 +183,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]   s, later dz
     T* sp = s + FL_SQ * FL_TT * FK;                // [FM][TT][SQ]   s_pre
     T* z = sp + FM * FL_TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
-    float* aff = reinterpret_cast<float*>(z + FM * FL_TT * FL_SQ);  // [2H] LN weight | bias gradient sums
+    float* aff = reinterpret_cast<float*>(z + FM * FL_TT * FL_SQ);  // [2H + SQ] LN weight | LN bias | squeeze bias gradient sums
     const int ntt = cdiv(T_, FL_TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     const float* bu = lp.p[P_USQ_B];
 
     for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
-    for (int i = tid; i < 2 * FL_H; i += nthr) aff[i] = 0.f;
-    PHASE_BEGIN(aff + 2 * FL_H);
+    for (int i = tid; i < 2 * FL_H + FL_SQ; i += nthr) aff[i] = 0.f;
+    PHASE_BEGIN(aff + 2 * FL_H + FL_SQ);
     lds_barrier();
     PHASE(0);
 
@@ -367,16 +367,23 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
                 acc = mma(a[ks], bq, acc);
             }
         }
+        // the squeeze BIAS gradient is summed here from the fp32 values: as a column sum of the bf16 ds_pre operand over all ~10^6 tokens
+        // (wgrad.hip) its rounding noise was the worst parameter-gradient error of the whole network (9.6e-2 on layers.0.squeeze.0.bias)
+        float dbs = 0.f;
         if (l15 < FL_TT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = mt * 16 + 4 * g4 + r;
                 if (h < F) {
                     const float pre = load1(sp + ((size_t)h * FL_TT + l15) * FL_SQ + ch);
-                    store1(z + ((size_t)h * FL_TT + l15) * FL_SQ + ch, acc[r] * dsilu_f(pre));
+                    const float v = acc[r] * dsilu_f(pre);
+                    dbs += v;
+                    store1(z + ((size_t)h * FL_TT + l15) * FL_SQ + ch, v);
                 }
             }
         }
+        dbs = wave_sum64(dbs);
+        if (lane == 0) atomicAdd(aff + 2 * FL_H + ch, dbs);
     }
     PHASE(7);
     lds_barrier();
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerP
     PHASE(9);
     lds_barrier();
     PHASE(10);
-    for (int i = tid; i < 2 * FL_H; i += nthr) part[(size_t)blockIdx.x * 2 * FL_H + i] = aff[i];
+    for (int i = tid; i < 2 * FL_H + FL_SQ; i += nthr) part[(size_t)blockIdx.x * (2 * FL_H + FL_SQ) + i] = aff[i];
     PHASE_END();
 }
 PHASE_READER(nbss_phase_read_full_bwd)
@@ -448,7 +455,7 @@ static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
                       float* stats, void* const* o, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + 2 * FL_H * sizeof(float) + PHASE_LDS_BYTES;
+    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + (2 * FL_H + FL_SQ) * sizeof(float) + PHASE_LDS_BYTES;
     const T* pk = (const T*)packed;
     if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (fp32 stream at F = 257: 213 KB of squeezed images)
     int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T, KSFM>), lds);
@@ -488,9 +495,10 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
                                  : full_bwd_t<float, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
     if (e) return e;
     AffSegs sg;
-    sg.n = 2;
+    sg.n = 3;
     sg.off[0] = param_off(c, layer, P_FULL_LN_W); sg.cnt[0] = FL_H;
     sg.off[1] = param_off(c, layer, P_FULL_LN_B); sg.cnt[1] = FL_H;
+    sg.off[2] = param_off(c, layer, P_SQ_B); sg.cnt[2] = FL_SQ;  // (summed in fp32 inside the kernel, not from the stream-precision operand)
     if ((e = affine_reduce_launch(part, c.B * cdiv(c.T, FL_TT), sg, G, st))) return e;
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));
@@ -511,7 +519,7 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.Ntok = (int)N; a.groups = 1; a.mvalid = 0; a.nvalid = 0;
     a.A = o[4]; a.lda = FL_SQ; a.MA = FL_SQ; a.B = x; a.ldb = FL_H; a.NB = FL_H;
     a.stats = stats; a.gamma = lp.p[P_FULL_LN_W]; a.beta = lp.p[P_FULL_LN_B];
-    a.dW = G + param_off(c, layer, P_SQ_W); a.dbias = G + param_off(c, layer, P_SQ_B);
+    a.dW = G + param_off(c, layer, P_SQ_W); a.dbias = nullptr;  // (bias: the kernel's own fp32 sums, folded above)
     return wgrad_launch(a, c.dtype, st);
 }
 

@@ -57,7 +57,72 @@ def large_16k():
     print("written: spatialnet_large_F17_T21_L1.npz, stft_norm_n3000_16k.npz")
 
 
+def bf16_reference_errors():
+    """What the REFERENCE's own bf16-mixed computation loses against fp64 (`python tests/golden/make_golden.py bf16ref`):
+    the reference's SpatialNet under torch.autocast('cpu', torch.bfloat16) — Lightning's `bf16-mixed`: fp32 parameters, bf16 convolutions /
+    linears / attention — forward + backward of sum(y * r), per-tensor rel-L2 error of the output and of every parameter gradient against
+    the same module in fp64.  Two cases: the F9 / T21 / L2 fixture (its stored x, r, parameters) and a 129-frequency, 64-frame, 8-layer
+    network whose parameters the oracle's seeded init_params generates (so that the test can regenerate them on the GPU box; a checksum
+    pins them).  Only the error figures are stored (bf16_reference_errors.json): the test asserts that the HIP bf16 stream is no worse
+    than 1.5x the reference's own bf16 deviation, tensor by tensor.  (CPU autocast; the CUDA autocast policy additionally keeps
+    layer_norm in fp32, so the reference's GPU figure can only be smaller in the norm-heavy tensors — the bar stays conservative.)"""
+    import json
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[m]
+    sys.path.insert(0, str(REF))
+    from models.arch.SpatialNet import SpatialNet  # noqa: E402  (reference)
+    assert "/root/reference" in sys.modules["models.arch.SpatialNet"].__file__
+    sys.path.insert(0, str(HERE.parent.parent))
+    from oracle import spatialnet_ref as oref  # (parameter generator only)
+
+    def rel(a, b):
+        a, b = a.double(), b.double()
+        return float((a - b).norm() / b.norm()) if float(b.norm()) > 0 else float(a.norm())
+
+    def run(F, T, L, sd, x, r):
+        kw = dict(dim_input=12, dim_output=4, num_layers=L, dim_hidden=96, dim_ffn=192, kernel_size=(5, 3), conv_groups=(8, 8),
+                  norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=8, num_freqs=F, num_heads=4, full_share=0)
+        res = {}
+        for mode in ("fp64", "bf16"):
+            net = SpatialNet(**kw).eval()
+            net.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+            if mode == "fp64":
+                net = net.double()
+                y = net(x.double())
+                (y * r.double()).sum().backward()
+            else:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    y = net(x.float())
+                (y.float() * r.float()).sum().backward()
+            res[mode] = (y.detach(), {n: p.grad.detach() for n, p in net.named_parameters()})
+        y64, g64 = res["fp64"]
+        ybf, gbf = res["bf16"]
+        return {"y": rel(ybf, y64), "grads": {n: rel(gbf[n], g64[n]) for n in g64}}
+
+    out = {"how": "tests/golden/make_golden.py bf16ref; rel-L2 of the reference SpatialNet under torch.autocast('cpu', bfloat16) vs the same module in fp64",
+           "torch": torch.__version__}
+    torch.set_num_threads(8)
+    z = np.load(HERE / "spatialnet_F9_T21_L2.npz")
+    sd = {k[len("param/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param/")}
+    out["F9_T21_L2"] = run(9, 21, 2, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["r"]))
+    p = oref.init_params(num_layers=8, num_freqs=129, seed=5)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 129, 64, 12, generator=g)
+    r = torch.randn(1, 129, 64, 4, generator=g)
+    c = run(129, 64, 8, p, x, r)
+    flat = torch.cat([v.double().reshape(-1) for v in p.values()])
+    c["seeds"] = {"init_params": 5, "x_r": 6}
+    c["checksum"] = [float(flat.sum()), float(flat.abs().sum()), float(x.double().sum()), float(r.double().sum())]
+    out["F129_T64_L8"] = c
+    (HERE / "bf16_reference_errors.json").write_text(json.dumps(out, indent=1))
+    worst = sorted(c["grads"].items(), key=lambda kv: -kv[1])[:6]
+    print("written: bf16_reference_errors.json; L8 case: y", c["y"], "worst grads", worst)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "bf16ref":
+        assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
+        return bf16_reference_errors()
     if len(sys.argv) > 1 and sys.argv[1] == "large16k":
         assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
         return large_16k()

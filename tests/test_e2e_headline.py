@@ -89,7 +89,7 @@ def test_bf16_stream_headline(hip_lib, oracle_run):
     assert err <= 3e-2
     assert rel_l2(yr_hat, wy) <= 5e-2
     assert abs(loss - float(wl)) <= 5e-2 * max(1.0, abs(float(wl)))
-    bad = {k: e for k, e in errs.items() if e > 0.15}
+    bad = {k: e for k, e in errs.items() if e > 0.08}  # (the reference's own bf16-autocast gradients deviate by up to 0.115 at this width: tests/golden/bf16_reference_errors.json)
     assert not bad, bad
     import statistics
     assert statistics.median(errs.values()) <= 5e-2

@@ -130,7 +130,7 @@ def test_fconv_bwd(backend, dtype, which):
     for (B, F, T) in shapes_for(backend) + big_f_shapes(backend, dtype):
         run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.fconv(x, p, pre),
                       lambda cs, G, x, dy, ws: ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, which, x, dy, ws), names, seed=40 + which,
-                      bf16_tol=8e-2)  # PReLU kink: bf16 rounding flips the sign of ~1% of the pre-activations
+                      bf16_tol=5e-2)  # PReLU kink: bf16 rounding flips the sign of ~1% of the pre-activations
 
 
 FULL_NAMES = ["layers.0.norm_full.weight", "layers.0.norm_full.bias", "layers.0.squeeze.0.weight", "layers.0.squeeze.0.bias",
