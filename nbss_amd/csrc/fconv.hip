@@ -57,6 +57,41 @@ NBSS_DEV void ln_row_inplace(T* row, const float* __restrict__ gamma, const floa
                (v[i + 2] - mean) * rstd * gamma[i + 2] + beta[i + 2], (v[i + 3] - mean) * rstd * gamma[i + 3] + beta[i + 3]);
 }
 
+// The same LayerNorm with TWO adjacent lanes per row (each HL / 2 channels; the partial sums are exchanged with a DPP quad swap): all 512
+// threads of a two-frame slab are busy (258 rows) and a lane's serial chain is half as long.  `row` points at the lane's own half.
+template <class T, int HL>
+NBSS_DEV void ln_halfrow_inplace(T* row, const float* __restrict__ gamma, const float* __restrict__ beta, bool active) {
+    constexpr int HP = HL / 2;
+    float v[HP], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HP; i += 8) load8(row + i, v + i);
+#pragma unroll
+    for (int i = 0; i < HP; ++i) s += v[i];
+#ifdef NBSS_EMU
+    s += __shfl_xor(s, 1);
+#else
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+#endif
+    const float mean = s * (1.0f / HL);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+        const float d = v[i] - mean;
+        q += d * d;
+    }
+#ifdef NBSS_EMU
+    q += __shfl_xor(q, 1);
+#else
+    q += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0xB1, 0xF, 0xF, true));
+#endif
+    const float rstd = rsqrtf(q * (1.0f / HL) + 1e-5f);
+    if (!active) return;  // (a lane beyond the last row read a clamped row so that whole waves take part in the exchange: no store)
+#pragma unroll
+    for (int i = 0; i < HP; i += 4)
+        store4(row + i, (v[i] - mean) * rstd * gamma[i] + beta[i], (v[i + 1] - mean) * rstd * gamma[i + 1] + beta[i + 1],
+               (v[i + 2] - mean) * rstd * gamma[i + 2] + beta[i + 2], (v[i + 3] - mean) * rstd * gamma[i + 3] + beta[i + 3]);
+}
+
 // GPW = conv groups per wave: 2 with 4 waves (fp32), 1 with 8 waves (bf16: two 8-wave workgroups per CU)
 // MTF = frequency tiles the accumulators are sized for: 10 (F <= 160, the 8-kHz geometry) or 17 (F <= 272: 16 kHz, n_fft 512 -> 257 bins)
 // HH = dim_hidden (geom.h): 96 (12 channels per conv group, one 16-row output tile) or 192 (24 channels, two tiles)
@@ -74,25 +109,27 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
     const int ntt = cdiv(T_, TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
     const int mtf = cdiv(F, 16), FP = mtf * 16 + 4;
-    constexpr int ROW = TT * HH;             // elements per frequency row in LDS
+    constexpr int HHP = HH + 8;              // padded (frequency, frame) row: 208 / 400 bytes — consecutive rows start on different LDS banks
+    constexpr int ROW = TT * HHP;            // elements per frequency row in LDS
     constexpr int VN = VecOf<T>::N;
-    constexpr int VPR = ROW / VN;            // vectors per frequency row
+    constexpr int VPR = TT * HH / VN;        // payload vectors per frequency row
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
 
     // ---- phase 1: stage x (raw) into LDS rows f+2, zero halo / tail rows -------------------
     for (int i = tid; i < FP * VPR; i += nthr) {
         const int rr = i / VPR, off = (i % VPR) * VN, f = rr - 2, tt = off / HH;
-        T* d = u + (size_t)rr * ROW + off;
+        T* d = u + (size_t)rr * ROW + tt * HHP + (off - tt * HH);
         if (f >= 0 && f < F && t0 + tt < T_)
             vec_copy(d, x + (((size_t)b * F + f) * T_ + t0) * HH + off);
         else
             vec_zero(d);
     }
     lds_barrier();
-    for (int r = tid; r < F * TT; r += nthr) {
-        const int f = r / TT, tt = r % TT;
-        if (t0 + tt < T_) ln_row_inplace<T, HH>(u + (size_t)(f + 2) * ROW + tt * HH, lnw, lnb);
+    for (int base = 0; base < 2 * F * TT; base += nthr) {  // two adjacent lanes per (frequency, frame) row; whole waves take part
+        const int r2 = base + tid, rc = (r2 < 2 * F * TT ? r2 : 2 * F * TT - 2 + (r2 & 1)) >> 1, hf = r2 & 1, f = rc / TT, tt = rc % TT;
+        // (rows beyond T hold zeros: normalising them is harmless and keeps both lanes of a pair on the same path)
+        ln_halfrow_inplace<T, HH>(u + (size_t)(f + 2) * ROW + tt * HHP + hf * (HH / 2), lnw + hf * (HH / 2), lnb + hf * (HH / 2), r2 < 2 * F * TT);
     }
     lds_barrier();
 
@@ -127,9 +164,9 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
                         Frag<T> bq;
                         const int p0 = ks * 8 + 2 * g4, p1 = p0 + 1;
                         // piece p -> tap p / (FG/4), channels (p % (FG/4))*4..+3 ; LDS row = f + tap
-                        if (p0 < NP) frag_load_lo(bq, u + (size_t)(f + p0 / (FG / 4)) * ROW + tt * HH + ch0 + (p0 % (FG / 4)) * 4);
+                        if (p0 < NP) frag_load_lo(bq, u + (size_t)(f + p0 / (FG / 4)) * ROW + tt * HHP + ch0 + (p0 % (FG / 4)) * 4);
                         else frag_zero_lo(bq);
-                        if (p1 < NP) frag_load_hi(bq, u + (size_t)(f + p1 / (FG / 4)) * ROW + tt * HH + ch0 + (p1 % (FG / 4)) * 4);
+                        if (p1 < NP) frag_load_hi(bq, u + (size_t)(f + p1 / (FG / 4)) * ROW + tt * HHP + ch0 + (p1 % (FG / 4)) * 4);
                         else frag_zero_hi(bq);
 #pragma unroll
                         for (int mt = 0; mt < MTG; ++mt) acc[gi][mt][tt][ft] = mma(a[gi][mt][ks], bq, acc[gi][mt][tt][ft]);
@@ -162,7 +199,7 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
                                 const float v = acc[gi][mt][tt][ft][r] + bb[r];
                                 o[r] = v > 0.f ? v : sl[r] * v;
                             }
-                            store4(u + (size_t)f * ROW + tt * HH + ch, o[0], o[1], o[2], o[3]);
+                            store4(u + (size_t)f * ROW + tt * HHP + ch, o[0], o[1], o[2], o[3]);
                         }
                     }
                 }
@@ -178,7 +215,7 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
         float xv[8], yv[8];
         if (VN == 8) {
             load8(x + go, xv);
-            load8(u + (size_t)f * ROW + off, yv);
+            load8(u + (size_t)f * ROW + tt * HHP + (off - tt * HH), yv);
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = xv[j] + yv[j];
@@ -186,7 +223,7 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
             store4(y + go + 4, o[4], o[5], o[6], o[7]);
         } else {
             load4(x + go, xv);
-            load4(u + (size_t)f * ROW + off, yv);
+            load4(u + (size_t)f * ROW + tt * HHP + (off - tt * HH), yv);
             store4(y + go, xv[0] + yv[0], xv[1] + yv[1], xv[2] + yv[2], xv[3] + yv[3]);
         }
     }
@@ -587,7 +624,7 @@ template <class T, int TT, int GPW, int MTF, int HH>
 static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > MTF) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)(mtf * 16 + 4) * TT * HH * sizeof(T);
+    const size_t lds = (size_t)(mtf * 16 + 4) * TT * (HH + 8) * sizeof(T);  // (rows padded by 8 elements: see HHP in the kernel)
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (fp32 stream, dim_hidden 192, F = 257: 212 KB)
     const float* lnw = P + param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W);
     const float* lnb = P + param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B);
