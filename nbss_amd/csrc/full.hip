@@ -27,7 +27,12 @@
 
 // KSFM: LinearGroup k-steps the fragment arrays are sized for; HH / NSQ = dim_hidden / dim_squeeze (geom.h)
 template <class T, int KSFM, int HH, int NSQ>
-__global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+#ifdef NBSS_FULLF_NOCAP
+__global__ __launch_bounds__(FL_THREADS)
+#else
+__global__ __launch_bounds__(FL_THREADS, HH == 96 ? 4 : 1)  // small geometry: <= 128 VGPRs, two workgroups per CU
+#endif
+void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bs, const float* __restrict__ bfull,
                                                        const float* __restrict__ bu, const T* __restrict__ Wsq,
                                                        const T* __restrict__ Wfull, const T* __restrict__ Wusq,
@@ -59,20 +64,38 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
                 gam[ks][j] = lnw[ks * 32 + 8 * g4 + j];
                 bet[ks][j] = lnb[ks * 32 + 8 * g4 + j];
             }
+        // software pipeline (the same as full_bwd's row loops): the x pieces of the wave's NEXT tile are requested before this tile's math —
+        // one workgroup of 8 waves per CU, and each wave walks 8 tiles load -> LayerNorm -> MFMA (SQ_WAIT_ANY was 77 % of the wave cycles)
+        const int tclf = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        auto row_of_f = [&](int nt) -> const T* {
+            const int f = 2 * nt + (l15 >> 3);
+            return x + (((size_t)b * F + (f < F ? f : F - 1)) * T_ + tclf) * HH;
+        };
+        Frag<T> xnext[(HH / 32)];
+        if (w < ntile) {
+#pragma unroll
+            for (int ks = 0; ks < (HH / 32); ++ks) frag_load(xnext[ks], row_of_f(w) + ks * 32 + 8 * g4);
+        }
         for (int nt = w; nt < ntile; nt += nw) {
             const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
             const bool valid = f < F && t0 + tt < T_;
-            const T* xr = x + (((size_t)b * F + f) * T_ + t0 + tt) * HH;
+            Frag<T> xcur[(HH / 32)];
+#pragma unroll
+            for (int ks = 0; ks < (HH / 32); ++ks) xcur[ks] = xnext[ks];
+            {
+                const T* nx = row_of_f(nt + nw < ntile ? nt + nw : nt);
+#pragma unroll
+                for (int ks = 0; ks < (HH / 32); ++ks) frag_load(xnext[ks], nx + ks * 32 + 8 * g4);
+            }
             float v[(HH / 32)][8];
             float sum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < (HH / 32); ++ks) {
-                if (valid) load8(xr + ks * 32 + 8 * g4, v[ks]);
-                else
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[ks][j] = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum += v[ks][j];
+                for (int j = 0; j < 8; ++j) {
+                    v[ks][j] = keep_if(valid, frag_get(xcur[ks], j));
+                    sum += v[ks][j];
+                }
             }
             const float mean = wave_sum16(sum) * (1.0f / HH);
             float q = 0.f;
@@ -135,9 +158,28 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
         Frag<T> a[(HH / 16)];
 #pragma unroll
         for (int mt = 0; mt < (HH / 16); ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
+        // the residual rows of the NEXT tile are requested before this tile's math (same pipeline as pass 1)
+        const int tcl3 = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        auto row_of_3 = [&](int nt) -> const T* {
+            const int f = 2 * nt + (l15 >> 3);
+            return x + (((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl3) * HH;
+        };
+        RawC4<T> rnext[(HH / 16)];
+        if (w < ntile) {
+#pragma unroll
+            for (int mt = 0; mt < (HH / 16); ++mt) rawc_load(rnext[mt], row_of_3(w) + 16 * mt + 4 * g4);
+        }
         for (int nt = w; nt < ntile; nt += nw) {
             const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
             const bool valid = f < F && t0 + tt < T_;
+            RawC4<T> rcur[(HH / 16)];
+#pragma unroll
+            for (int mt = 0; mt < (HH / 16); ++mt) rcur[mt] = rnext[mt];
+            {
+                const T* nx = row_of_3(nt + nw < ntile ? nt + nw : nt);
+#pragma unroll
+                for (int mt = 0; mt < (HH / 16); ++mt) rawc_load(rnext[mt], nx + 16 * mt + 4 * g4);
+            }
             Frag<T> bq;
             if (8 * g4 < NSQ && f < F) frag_load(bq, z + ((size_t)f * FL_TT + tt) * NSQ + 8 * g4);
             else frag_zero(bq);
@@ -148,7 +190,7 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
                 if (valid) {
                     const int ch = 16 * mt + 4 * g4;
                     float xv[4];
-                    load4(x + go + ch, xv);
+                    rawc_get(rcur[mt], xv);
                     float o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = xv[r] + round_to(silu_f(acc[r] + bu[ch + r]), x);
@@ -168,10 +210,13 @@ __global__ __launch_bounds__(FL_THREADS) void full_fwd_kernel(nbss_cfg c, const 
 //   p4  ds = Wf^T dz ; ds_pre = ds SiLU'(s_pre)                     -> LDS, global ds_pre
 //   p5  du = Ws^T ds_pre ; LayerNorm backward + residual in registers -> dx, (mean, rstd)
 // The three weight gradients (squeeze, LinearGroup, unsqueeze) are contracted by wgrad.hip.
+#ifndef FULLB_WAVES
+#define FULLB_WAVES 2
+#endif
 #define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
 
 template <class T, int KSFM>
-__global__ __launch_bounds__(FL_THREADS) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
+__global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
