@@ -107,7 +107,7 @@ class TrainModule(nn.Module):
         return (self.stft.istft(Yr_hat, length) if istft else torch.view_as_real(Yr_hat)), loss_paras
 
     @torch.no_grad()
-    def forward_streaming(self, x: Tensor, chunk: int = 8, use_graph: Optional[bool] = None):
+    def forward_streaming(self, x: Tensor, chunk: int = 8, use_graph: Optional[bool] = None, native: Optional[bool] = None):
         """causal chunked inference of an OnlineSpatialNet: x [B,C,N] -> (yr_hat [B,Spk,N], stats).  STFT and the (online) normalisation
         are frame-local, so the network is fed `chunk` frames at a time through OnlineStreamer (fixed-shape state; one HIP graph replay
         per chunk on a HIP device) and the result equals forward() on the whole signal (reference OnlineSpatialNet.py:333-354)."""
@@ -122,7 +122,15 @@ class TrainModule(nn.Module):
             feats = torch.nn.functional.pad(feats, (0, 0, 0, Tp - T))
         key = (B, chunk, str(x.device))
         if getattr(self, "_streamer_key", None) != key:
-            self._streamer, self._streamer_key = OnlineStreamer(self.arch, B, chunk, device=x.device, use_graph=use_graph), key
+            # on a HIP device the native step (nbss_amd/online.py: HIP kernels for the causal encoder, the recurrent retention and the causal
+            # T-ConvFFN + the cross-band kernels, one HIP graph per chunk) serves the geometry it is built for; everything else — other
+            # attention types / widths, host tensors — takes the torch.nn step (OnlineStreamer)
+            from nbss_amd.online import NativeOnlineStreamer, supported
+            if x.is_cuda and supported(self.arch) is None and chunk <= 32 and native is not False:
+                self._streamer = NativeOnlineStreamer(self.arch, B, chunk, device=x.device, use_graph=use_graph)
+            else:
+                self._streamer = OnlineStreamer(self.arch, B, chunk, device=x.device, use_graph=use_graph)
+            self._streamer_key = key
         s = self._streamer
         s.reset()
         if x.is_cuda:
@@ -134,7 +142,8 @@ class TrainModule(nn.Module):
         dt = time.time() - t0
         out = torch.view_as_complex(out.float().reshape(B, F, T, -1, 2).contiguous()).permute(0, 3, 1, 2)
         Yr_hat = self.norm.inorm(out, (Xr, XrMM))
-        stats = {"chunks": Tp // chunk, "graph_replays": Tp // chunk if s.graph is not None else 0, "frames_per_s": B * Tp / max(dt, 1e-9)}
+        stats = {"chunks": Tp // chunk, "graph_replays": Tp // chunk if s.graph is not None else 0, "frames_per_s": B * Tp / max(dt, 1e-9),
+                 "native": type(s).__name__ == "NativeOnlineStreamer"}
         return self.stft.istft(Yr_hat, length), stats
 
     def training_step(self, batch, batch_idx=0):
@@ -470,7 +479,7 @@ def _predict_generic(cfg: dict) -> Dict[str, Any]:
             if isinstance(module.arch, OnlineSpatialNet) and chunk > 0:
                 yr_hat, st = module.forward_streaming(x, chunk)
                 info["streamed"], info["graph_replays"] = True, info["graph_replays"] + st["graph_replays"]
-                info["frames_per_s"] = st["frames_per_s"]
+                info["frames_per_s"], info["native"] = st["frames_per_s"], st["native"]
             else:
                 yr_hat, _ = module.forward(x)
             outs.append(yr_hat.cpu())

@@ -175,6 +175,25 @@ int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, 
                         float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int flags,
                         void* stream);
 
+/* ---- OnlineSpatialNet: native streaming step (models/arch/OnlineSpatialNet.py:22-60,171-200,333-354; base/retention.py:194-253) -------
+ * One call advances a chunk of C <= 32 frames of every (batch, frequency) sequence; all state lives in caller-owned fp32 device
+ * buffers updated in place, so a whole step is a fixed launch sequence (capturable in a HIP graph).  fp32; geometry: dim_hidden 96,
+ * dim_ffn 192, 8 conv groups of 24, 4 retention heads (key 24, value 48).  The cross-band blocks of a layer are per-frame operations:
+ * nbss_fconv_fwd / nbss_full_fwd on the [B,F,C,H] chunk (cfg->T = C); the decoder: nbss_decoder_fwd.
+ * encoder: causal Conv1d(C_in -> 96, k = 5): x [BF][C][C_in], state [BF][4][C_in] (the last four input frames), y [BF][C][96]. */
+int nbss_online_encoder_step(int BF, int C, int C_in, const float* weight, const float* bias, const float* x, float* state, float* y, void* stream);
+/* x += out_proj(SiLU(g) * RMSNorm_head(retention(q, k, v))) with LayerNorm(x) as input, recurrent form: kv [BF][4][24][48] and
+ * scale [BF][4] (running decay sum, one copy per sequence) carry over; w*_t are the projection weights TRANSPOSED ([in][out]);
+ * wk_t = NULL shares k with q ('ret(2,share_qk)'); decay [4] = the per-head gamma.  x [BF][C][96] in place. */
+int nbss_online_ret_step(int BF, int C, const float* ln_w, const float* ln_b, const float* wq_t, const float* wk_t, const float* wv_t, const float* wg_t,
+                         const float* wo_t, const float* decay, float* kv, float* scale, float* x, void* stream);
+/* x += causal T-ConvFFN(x): LayerNorm -> 1x1 -> SiLU -> causal gconv -> SiLU -> causal gconv -> GroupNorm of each FRAME over (24 channels
+ * x all F frequencies) -> SiLU -> causal gconv -> SiLU -> 1x1.  w1_t [96][192], w2_t [192][96] transposed; conv weights [192][24][3];
+ * s1 s2 s3 [BF][2][192] = the last two input frames of the three convs; a3 [BF][C][192] and gn_sums [B][C][8][2] are scratch. */
+int nbss_online_tconvffn_step(int B, int F, int C, const float* ln_w, const float* ln_b, const float* w1_t, const float* b1, const float* c1w,
+                              const float* c1b, const float* c2w, const float* c2b, const float* gn_w, const float* gn_b, const float* c3w, const float* c3b,
+                              const float* w2_t, const float* b2, float* s1, float* s2, float* s3, float* a3, float* gn_sums, float* x, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */

@@ -73,6 +73,9 @@ SIGNATURES = {
     "nbss_inorm_istft_bwd": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "nbss_pit_ws_bytes": (C.c_int64, [_I, _I]),
     "nbss_pit_neg_sisdr": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_online_encoder_step": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "nbss_online_ret_step": (_I, [_I, _I] + [_P] * 12),
+    "nbss_online_tconvffn_step": (_I, [_I, _I, _I] + [_P] * 21),
     "nbss_clip_adam_step": (_I, [C.c_int64, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),
     "nbss_build_info": (C.c_char_p, []),

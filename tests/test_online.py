@@ -111,3 +111,53 @@ def test_hipgraph_streaming_step(name):
     ys = torch.cat([s.step(x[:, :, c:c + 8]) for c in range(0, 64, 8)], 2)
     assert s.graph is not None
     assert rel_l2(ys, y) < (1e-4 if name == "mhsa7" else 3e-3)
+
+
+# ---- native streaming step (csrc/online.hip + the cross-band kernels): emulator on CPU, libnbss_hip.so + HIP graph with -m gpu -----------
+NATIVE_KW = dict(dim_input=4, dim_output=4, num_layers=2, dim_squeeze=8, num_freqs=9, encoder_kernel_size=5, dim_hidden=96, dim_ffn=192, num_heads=4,
+                 dropout=(0, 0, 0), kernel_size=(5, 3), conv_groups=(8, 8), norms=["LN", "LN", "GN", "LN", "LN", "LN"], full_share=0, attention="ret(2)",
+                 decay=[4, 5, 9, 10], rope=False)
+
+
+def _native_net(seed=5, **over):
+    from models.arch.OnlineSpatialNet import OnlineSpatialNet
+    torch.manual_seed(seed)
+    net = OnlineSpatialNet(**{**NATIVE_KW, **over}).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    return net
+
+
+@pytest.mark.parametrize("chunk,over", [(8, {}), (5, {}), (16, {"attention": "ret(2,not_share_qk)"})])
+def test_native_streaming_step_matches_module(backend, chunk, over):
+    """the HIP streaming step (encoder / retention / T-ConvFFN kernels of csrc/online.hip + the cross-band kernels), chunk by chunk, against the
+    module's own whole-utterance forward (parallel retention) and its torch streaming step (the module itself is pinned to the reference by
+    tests/golden/online_tiny.npz above); fp32: <= 2e-3 against the parallel form (the orders differ by the per-head RMS eps), <= 2e-4 against
+    the torch recurrent step"""
+    from nbss_amd.online import NativeOnlineStreamer
+    net = _native_net(**over).to(backend.device)
+    T = 3 * chunk
+    x = torch.randn(2, 9, T, 4, device=backend.device)
+    with torch.no_grad():
+        y = net(x)
+        st = net.init_stream(2, device=backend.device)
+        ys = torch.cat([net.forward_stream(x[:, :, c:c + chunk], st) for c in range(0, T, chunk)], 2)
+    s = NativeOnlineStreamer(net, 2, chunk, device=backend.device, lib=backend.lib, use_graph=backend.name == "hip")
+    yn = torch.cat([s.step(x[:, :, c:c + chunk]) for c in range(0, T, chunk)], 2)
+    assert rel_l2(yn, ys) < 2e-4 and rel_l2(yn, y) < 2e-3, (rel_l2(yn, ys), rel_l2(yn, y))
+    assert (s.graph is not None) == (backend.name == "hip")
+    s.reset()  # a new utterance through the same (captured) step
+    yn2 = torch.cat([s.step(x[:, :, c:c + chunk]) for c in range(0, T, chunk)], 2)
+    assert torch.equal(yn, yn2) or rel_l2(yn2, yn) < 1e-6  # (GroupNorm sums are float atomics over the frequencies)
+
+
+def test_native_streaming_refuses_other_geometries():
+    from nbss_amd.online import NativeOnlineStreamer, supported
+    assert supported(_native_net()) is None
+    for over in ({"attention": "mhsa(7)"}, {"dim_hidden": 32, "dim_ffn": 64}, {"rope": True}):
+        net = _native_net(**over)
+        assert supported(net) is not None
+        with pytest.raises(NotImplementedError):
+            NativeOnlineStreamer(net, 1, 8, device="cpu", lib=object())

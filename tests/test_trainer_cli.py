@@ -242,6 +242,7 @@ def test_online_spatialnet_fit_and_streamed_predict_on_gpu(tmp_path):
     ck = str(tmp_path / "checkpoints" / "last.ckpt")
     res = TrainCLI(argv=["predict"] + args + ["--ckpt_path", ck, "--stream_chunk=16"]).result
     assert res["streamed"] and res["graph_replays"] >= 32 * 8000 // 128 // 16 and res["yr_hat"][0].shape == (1, 2, 256000)
+    assert res["native"]  # the shipped ret(2) geometry runs the HIP streaming kernels (csrc/online.hip), one HIP graph replay per chunk
     whole = TrainCLI(argv=["predict"] + args + ["--ckpt_path", ck, "--stream_chunk=0"]).result
     a, b = res["yr_hat"][0], whole["yr_hat"][0]
     assert torch.isfinite(a).all() and float((a - b).norm() / b.norm()) < 1e-2
