@@ -246,6 +246,64 @@ NBSS_DEV void ln_bwd_row96_raw_na(f32x4 (&du)[BK_MT], const RawC4<T> (&xr)[BK_MT
     }
 }
 
+// the same, also writing the row's (mean, rstd)
+template <class T>
+NBSS_DEV void ln_bwd_row96_raw_nas(f32x4 (&du)[BK_MT], const RawC4<T> (&xr)[BK_MT], const RawC4<T> (&dyr)[BK_MT], T* __restrict__ dxr, float* __restrict__ stat, bool valid,
+                                  const float* __restrict__ lnw) {
+    const int g4 = lane_id() >> 4;
+    float xv[BK_MT][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt) {
+        rawc_get(xr[mt], xv[mt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xv[mt][r] = keep_if(valid, xv[mt][r]);
+            sum += xv[mt][r];
+        }
+    }
+    const float mean = wave_sum16(sum) * (1.0f / BK_H);
+    float q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xv[mt][r] -= mean;
+            q += xv[mt][r] * xv[mt][r];
+        }
+    const float rstd = rsqrtf(wave_sum16(q) * (1.0f / BK_H) + 1e-5f);
+    if (valid && g4 == 0) {  // row statistics for the weight-gradient kernel's LayerNorm-on-the-fly
+        stat[0] = mean;
+        stat[1] = rstd;
+    }
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < BK_MT; ++mt) {
+        float gq[4];
+        load4(lnw + 16 * mt + 4 * g4, gq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xv[mt][r] *= rstd;  // xhat
+            du[mt][r] = keep_if(valid, du[mt][r]) * gq[r];
+            m1 += du[mt][r];
+            m2 += du[mt][r] * xv[mt][r];
+        }
+    }
+    m1 = wave_sum16(m1) * (1.0f / BK_H);
+    m2 = wave_sum16(m2) * (1.0f / BK_H);
+    if (valid) {
+#pragma unroll
+        for (int mt = 0; mt < BK_MT; ++mt) {
+            const int ch = 16 * mt + 4 * g4;
+            float dv[4], o[4];
+            rawc_get(dyr[mt], dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = dv[r] + rstd * (du[mt][r] - m1 - xv[mt][r] * m2);
+            store4(dxr + ch, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // Small per-channel parameter gradients (LN / GN affine, PReLU slope) are summed per workgroup in LDS
 // (ds_add_f32) and written as ONE partial row per workgroup; util.hip's affine_reduce folds the rows
 // into the gradient buffer.  (Same-address global atomics from every wave serialise in the memory

@@ -210,13 +210,14 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
 //   p4  ds = Wf^T dz ; ds_pre = ds SiLU'(s_pre)                     -> LDS, global ds_pre
 //   p5  du = Ws^T ds_pre ; LayerNorm backward + residual in registers -> dx, (mean, rstd)
 // The three weight gradients (squeeze, LinearGroup, unsqueeze) are contracted by wgrad.hip.
-#ifndef FULLB_WAVES
-#define FULLB_WAVES 2
-#endif
 #define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
+#define FL_WFR 15  // weight fragments staged in LDS by the backward kernel: Wusq 6 | WusqT 3 | WsqT 6
 
 template <class T, int KSFM>
-__global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
+// bf16 stream: <= 128 VGPRs (a few spilled registers) so that two workgroups share a CU: 4.72 -> 4.17 ms per step together with the LDS-resident
+// weight fragments and the LayerNorm affine sums moved out of the row loop; the software prefetch of the row loops (round 2: worth 10 % at one
+// workgroup per CU) costs more registers than it hides latency at two (4.57 with, 4.17 without)
+__global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
@@ -228,7 +229,10 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]   s, later dz
     T* sp = s + FL_SQ * FL_TT * FK;                // [FM][TT][SQ]   s_pre
     T* z = sp + FM * FL_TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
-    float* aff = reinterpret_cast<float*>(z + FM * FL_TT * FL_SQ);  // [2H + SQ] LN weight | LN bias | squeeze bias gradient sums
+    float* aff = reinterpret_cast<float*>(z + FM * FL_TT * FL_SQ);  // [SQ] squeeze bias gradient sums (fp32)
+    // the unsqueeze / squeeze weight fragments of the two row loops live in LDS, not in 60 registers per lane: with the LayerNorm affine
+    // sums gone as well (below) the kernel fits 128 VGPRs and TWO workgroups share a CU — its row loops are bound by exposed latency
+    T* wl = reinterpret_cast<T*>(aff + FL_SQ);                         // [FL_WFR][512]
     const int ntt = cdiv(T_, FL_TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -241,8 +245,16 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
     const float* bu = lp.p[P_USQ_B];
 
     for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
-    for (int i = tid; i < 2 * FL_H + FL_SQ; i += nthr) aff[i] = 0.f;
-    PHASE_BEGIN(aff + 2 * FL_H + FL_SQ);
+    for (int i = tid; i < FL_SQ; i += nthr) aff[i] = 0.f;
+    {
+        constexpr int VPF = 512 * (int)sizeof(T) / 16;  // 16-byte pieces per fragment (64 bf16, 128 fp32)
+        for (int v = tid; v < FL_WFR * VPF; v += nthr) {
+            const int fr = v / VPF, pc = v % VPF;
+            const T* src = fr < 6 ? Wusq + (size_t)fr * 512 : fr < 9 ? WusqT + (size_t)(fr - 6) * 512 : WsqT + (size_t)(fr - 9) * 512;
+            reinterpret_cast<u32x4*>(wl)[v] = reinterpret_cast<const u32x4*>(src)[pc];
+        }
+    }
+    PHASE_BEGIN(wl + FL_WFR * 512);
     lds_barrier();
     PHASE(0);
 
@@ -325,18 +337,14 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
 
     // ---- p3: recompute y_pre, dy_pre, dz = Wu^T dy_pre (dz overwrites s) ----
     {
-        Frag<T> a[FL_MT], at[FL_KS];
-#pragma unroll
-        for (int mt = 0; mt < FL_MT; ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
-#pragma unroll
-        for (int ks = 0; ks < FL_KS; ++ks) wfrag_load(at[ks], WusqT, 0, FL_KS, ks);
+        const T* wa = wl + (size_t)lane * 8;  // fragment fr of the window: wa + fr * 512
         // software pipeline: the dy pieces of the wave's NEXT row tile are requested before this tile's math (clamped addresses)
         const int tcl = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
         auto row_of = [&](int nt) -> size_t {
             const int f = 2 * nt + (l15 >> 3);
             return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
         };
-        constexpr bool PF = sizeof(T) == 2;  // (fp32 stream: the extra 24-48 registers spill; it keeps the plain loop)
+        constexpr bool PF = false;  // (see the note at the kernel's launch bounds)
         RawC4<T> dnext[BK_MT];
         if (PF && w < ntile) rawc_load_row<T>(dnext, dy + row_of(w) * FL_H);
         for (int nt = w; nt < ntile; nt += nw) {
@@ -366,7 +374,9 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
             f32x4 dyp[FL_MT];
 #pragma unroll
             for (int mt = 0; mt < FL_MT; ++mt) {
-                const f32x4 acc = mma(a[mt], bq, F32X4_ZERO);
+                Frag<T> am;
+                frag_load(am, wa + mt * 512);
+                const f32x4 acc = mma(am, bq, F32X4_ZERO);
                 const int ch = 16 * mt + 4 * g4;
                 float dv[4];
                 rawc_get(dcur[mt], dv);
@@ -377,9 +387,10 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
             f32x4 dzt = F32X4_ZERO;
 #pragma unroll
             for (int ks = 0; ks < FL_KS; ++ks) {
-                Frag<T> df;
+                Frag<T> df, atk;
                 frag_from_c2(df, dyp[2 * ks], dyp[2 * ks + 1]);
-                dzt = mma(at[ks], df, dzt);
+                frag_load(atk, wa + (6 + ks) * 512);
+                dzt = mma(atk, df, dzt);
             }
             if (valid && g4 < 2) {
 #pragma unroll
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
             }
         }
         dbs = wave_sum64(dbs);
-        if (lane == 0) atomicAdd(aff + 2 * FL_H + ch, dbs);
+        if (lane == 0) atomicAdd(aff + ch, dbs);
     }
     PHASE(7);
     lds_barrier();
@@ -436,20 +447,15 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
 
     // ---- p5: du = Ws^T ds_pre, LayerNorm backward + residual ----
     {
-        Frag<T> a[FL_MT];
-#pragma unroll
-        for (int mt = 0; mt < FL_MT; ++mt) wfrag_load(a[mt], WsqT, mt, 1, 0);
-        float dlw[BK_MT][4], dlb[BK_MT][4];
-#pragma unroll
-        for (int mt = 0; mt < BK_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dlw[mt][r] = dlb[mt][r] = 0.f;
+        const T* wa = wl + (size_t)(9 * 512) + (size_t)lane * 8;  // the six Ws^T fragments
+        // (no LayerNorm affine sums here: dgamma / dbeta follow from the squeeze weight gradient itself, D = ds_pre^T xhat —
+        //  dgamma[i] = sum_o Ws[o][i] D[o][i], dbeta[i] = sum_o Ws[o][i] dbs[o] — in full_sq_finalize_kernel; 48 accumulators per lane gone)
         const int tcl = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
         auto row_of = [&](int nt) -> size_t {
             const int f = 2 * nt + (l15 >> 3);
             return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
         };
-        constexpr bool PF = sizeof(T) == 2;
+        constexpr bool PF = false;
         RawC4<T> xnext[BK_MT], dnext[BK_MT];
         if (PF && w < ntile) {
             rawc_load_row<T>(xnext, x + row_of(w) * FL_H);
@@ -482,25 +488,51 @@ __global__ __launch_bounds__(FL_THREADS, FULLB_WAVES) void full_bwd_kernel(nbss_
             }
             f32x4 du[BK_MT];
 #pragma unroll
-            for (int mt = 0; mt < FL_MT; ++mt) du[mt] = mma(a[mt], bq, F32X4_ZERO);
-            ln_bwd_row96_raw<T>(du, xcur, dcur, dx + n * FL_H, stats + n * 2, valid, lnw, dlw, dlb);
+            for (int mt = 0; mt < FL_MT; ++mt) {
+                Frag<T> am;
+                frag_load(am, wa + mt * 512);
+                du[mt] = mma(am, bq, F32X4_ZERO);
+            }
+            ln_bwd_row96_raw_nas<T>(du, xcur, dcur, dx + n * FL_H, stats + n * 2, valid, lnw);
         }
-        ln_affine_flush(dlw, dlb, aff, aff + FL_H);
     }
     PHASE(9);
     lds_barrier();
     PHASE(10);
-    for (int i = tid; i < 2 * FL_H + FL_SQ; i += nthr) part[(size_t)blockIdx.x * (2 * FL_H + FL_SQ) + i] = aff[i];
+    for (int i = tid; i < FL_SQ; i += nthr) part[(size_t)blockIdx.x * FL_SQ + i] = aff[i];
     PHASE_END();
 }
 PHASE_READER(nbss_phase_read_full_bwd)
+
+// tmp = D [SQ][H] | dbs [SQ] | ones [H] | zeros [H]: cleared / initialised before the backward kernel
+__global__ void full_sq_prep_kernel(float* __restrict__ tmp) {
+    for (int i = threadIdx.x; i < FL_SQ * FL_H + FL_SQ + 2 * FL_H; i += blockDim.x) tmp[i] = (i >= FL_SQ * FL_H + FL_SQ && i < FL_SQ * FL_H + FL_SQ + FL_H) ? 1.0f : 0.f;
+}
+// dWs[o][i] += D[o][i] gamma[i] + dbs[o] beta[i];  dbs[o] += dbs;  dgamma[i] += sum_o Ws[o][i] D[o][i];  dbeta[i] += sum_o Ws[o][i] dbs[o]
+// (du = Ws^T ds_pre contracted with xhat resp. 1 over all tokens, reordered: the LayerNorm affine gradients cost no per-token work)
+__global__ void full_sq_finalize_kernel(const float* __restrict__ tmp, const float* __restrict__ Ws, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        float* __restrict__ dWs, float* __restrict__ dbs, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = threadIdx.x;
+    if (i >= FL_H) return;
+    float dg = 0.f, db = 0.f;
+#pragma unroll
+    for (int o = 0; o < FL_SQ; ++o) {
+        const float D = tmp[o * FL_H + i], b = tmp[FL_SQ * FL_H + o], w = Ws[o * FL_H + i];
+        dWs[o * FL_H + i] += D * gamma[i] + b * beta[i];
+        dg += w * D;
+        db += w * b;
+    }
+    dgamma[i] += dg;
+    dbeta[i] += db;
+    if (i < FL_SQ) dbs[i] += tmp[FL_SQ * FL_H + i];
+}
 
 template <class T, int KSFM>
 static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
                       float* stats, void* const* o, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ) * sizeof(T) + (2 * FL_H + FL_SQ) * sizeof(float) + PHASE_LDS_BYTES;
+    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ + (size_t)FL_WFR * 512) * sizeof(T) + FL_SQ * sizeof(float) + PHASE_LDS_BYTES;
     const T* pk = (const T*)packed;
     if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (fp32 stream at F = 257: 213 KB of squeezed images)
     int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T, KSFM>), lds);
@@ -532,6 +564,10 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     // (the F..FKP padding columns of s / dz, read by the wgrad staging, are written as zeros by the kernel's row copies)
     int e;
     float* part = (float*)((char*)ws + ws_part_offset(c));
+    // tmp (behind the per-workgroup partial rows): D [SQ][H] = ds_pre^T xhat | dbs [SQ] | ones [H] | zeros [H]
+    float* sqtmp = part + (size_t)c.B * cdiv(c.T, FL_TT) * FL_SQ + 64;
+    NBSS_LAUNCH(full_sq_prep_kernel, dim3(1), dim3(256), 0, st, sqtmp);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
     if (c.F > 32 * FL_KSF_MAX)
         e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
                                  : full_bwd_t<float, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
@@ -539,12 +575,11 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
         e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
                                  : full_bwd_t<float, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
     if (e) return e;
+    // squeeze bias gradient (fp32 sums of the kernel) -> tmp.dbs
     AffSegs sg;
-    sg.n = 3;
-    sg.off[0] = param_off(c, layer, P_FULL_LN_W); sg.cnt[0] = FL_H;
-    sg.off[1] = param_off(c, layer, P_FULL_LN_B); sg.cnt[1] = FL_H;
-    sg.off[2] = param_off(c, layer, P_SQ_B); sg.cnt[2] = FL_SQ;  // (summed in fp32 inside the kernel, not from the stream-precision operand)
-    if ((e = affine_reduce_launch(part, c.B * cdiv(c.T, FL_TT), sg, G, st))) return e;
+    sg.n = 1;
+    sg.off[0] = FL_SQ * FL_H; sg.cnt[0] = FL_SQ;
+    if ((e = affine_reduce_launch(part, c.B * cdiv(c.T, FL_TT), sg, sqtmp, st))) return e;
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
@@ -564,8 +599,14 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.Ntok = (int)N; a.groups = 1; a.mvalid = 0; a.nvalid = 0;
     a.A = o[4]; a.lda = FL_SQ; a.MA = FL_SQ; a.B = x; a.ldb = FL_H; a.NB = FL_H;
     a.stats = stats; a.gamma = lp.p[P_FULL_LN_W]; a.beta = lp.p[P_FULL_LN_B];
-    a.dW = G + param_off(c, layer, P_SQ_W); a.dbias = nullptr;  // (bias: the kernel's own fp32 sums, folded above)
-    return wgrad_launch(a, c.dtype, st);
+    // squeeze: D = ds_pre^T xhat (LayerNorm on the fly with gamma = 1, beta = 0) into tmp; the finalize kernel turns it into
+    // dWs = D gamma + dbs (x) beta, dbs, and the LayerNorm affine gradients
+    a.gamma = sqtmp + FL_SQ * FL_H + FL_SQ; a.beta = sqtmp + FL_SQ * FL_H + FL_SQ + FL_H;
+    a.dW = sqtmp; a.dbias = nullptr;
+    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    NBSS_LAUNCH(full_sq_finalize_kernel, dim3(1), dim3(FL_H), 0, st, (const float*)sqtmp, lp.p[P_SQ_W], lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+                G + param_off(c, layer, P_SQ_W), G + param_off(c, layer, P_SQ_B), G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B));
+    return NBSS_CHECK_LAUNCH();
 }
 
 template <class T, int KSFM, class G>

@@ -22,7 +22,10 @@
 #define MB_HEADS 4
 #define MB_DH 24
 #define MB_NT 16
-#define MB_NSW 2
+#ifndef MB_NSW
+#define MB_NSW 2   // strips per wave: 2 (8 waves per sequence) or 1 (16 waves, <= 128 VGPRs: four waves per SIMD)
+#endif
+#define MB_NTHR (64 * 16 / MB_NSW)
 #define MB_KS 3
 
 template <class T>
@@ -126,7 +129,7 @@ template <> struct RawRow4<float> {
 // XT (bf16): the tail — du = Win^T dqkv, LayerNorm backward, dx, LN-affine sums — runs in tailw.hip's fused tail / in_proj weight-gradient
 // kernel instead; this kernel then ends with the dqkv operand and writes the LayerNorm row statistics for it.
 template <class T, bool FULL, bool XT>
-__global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
+__global__ __launch_bounds__(MB_NTHR) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Win, const T* __restrict__ WinT, const T* __restrict__ WoutT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ osave,
                                                        const float* __restrict__ lse, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dqkv) {
@@ -205,20 +208,20 @@ __global__ __launch_bounds__(512) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs lp,
                 frag_load(dr[si][ks], dyb + (size_t)tc * MB_H + ks * 32 + 8 * g4);
             }
         }
-        constexpr int NWV = 96 * 64 / 512;  // 16-byte pieces per thread (blockDim.x == 512)
+        constexpr int NWV = 96 * 64 / MB_NTHR;  // 16-byte pieces per thread
         u32x4 wreg[NWV];
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
-            const int v = threadIdx.x + i * 512;
+            const int v = threadIdx.x + i * MB_NTHR;
             wreg[i] = v < 72 * 64 ? reinterpret_cast<const u32x4*>(Win)[v] : reinterpret_cast<const u32x4*>(WoutT)[v - 72 * 64];
         }
         request_o(0);
-        for (int i = threadIdx.x; i < 2 * MB_H; i += 512) {
+        for (int i = threadIdx.x; i < 2 * MB_H; i += MB_NTHR) {
             aff[i] = 0.f;
             lnp[i] = i < MB_H ? lp.p[P_MH_LN_W][i] : lp.p[P_MH_LN_B][i - MB_H];
         }
 #pragma unroll
-        for (int i = 0; i < NWV; ++i) reinterpret_cast<u32x4*>(wl)[threadIdx.x + i * 512] = wreg[i];
+        for (int i = 0; i < NWV; ++i) reinterpret_cast<u32x4*>(wl)[threadIdx.x + i * MB_NTHR] = wreg[i];
         // LayerNorm statistics from the fragments already in registers, then LN(x) in place
 #pragma unroll
         for (int si = 0; si < MB_NSW; ++si) {
@@ -618,7 +621,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_bwd_kernel<T, FULL, XT>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.F), block(512);  // (timed by the caller's ProfScope, together with the fused tail kernel when there is one)
+    dim3 grid(c.B * c.F), block(MB_NTHR);  // (timed by the caller's ProfScope, together with the fused tail kernel when there is one)
     NBSS_LAUNCH((mhsa_bwd_kernel<T, FULL, XT>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_INP_TN),
                 pk + pack_off(c, layer, K_OUTP_T), (const T*)x, (const T*)dy, (const T*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)),
                 (T*)dx, stats, (T*)dqkv);
