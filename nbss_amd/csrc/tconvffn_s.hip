@@ -155,12 +155,13 @@ struct TsFwdW {  // packed fragment bases of one layer
 
 #define TS_SB 2  // strips per block of a group phase (independent MFMA chains in flight)
 
-// What a training-mode forward keeps for the backward pass (tconvffn_bwd_v_kernel below): the four pre-activations a1 (W1 output), a2, a3
-// (conv1 / conv2 outputs; a3 = GroupNorm input) and a5 (conv3 output) as group-major [G][N][24] bf16 tensors — what the reference's
-// autocast graph holds as bf16 conv outputs —, the LayerNorm (mean, rstd) of every token and the GroupNorm (mean, rstd) of every
-// (sequence, group).  With them the backward pass evaluates each SiLU / SiLU' pair from ONE sigmoid and recomputes no convolution.
+// What a training-mode forward keeps for the backward pass (tconvffn_bwd_v_kernel below): the pre-activations a1 (W1 output), a2, a3
+// (conv1 / conv2 outputs; a3 = GroupNorm input) as group-major [G][N][24] bf16 tensors — what the reference's autocast graph holds as
+// bf16 conv outputs —, the LayerNorm (mean, rstd) of every token and the GroupNorm (mean, rstd) of every (sequence, group).  With them
+// the backward pass evaluates each SiLU / SiLU' pair from ONE sigmoid and recomputes one convolution only: a5 = conv3(h4), whose input
+// it has in LDS anyway (saving a5 as well cost 2 S.B of stores here and 2 S.B of loads there for 5 MFMAs per strip).
 struct TsSave {
-    bf16_t *a1, *a2, *a3, *a5;
+    bf16_t *a1, *a2, *a3;
     float *ln, *gn;  // [N][2], [B*F][G][2]
 };
 
@@ -397,12 +398,6 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                 P6 h5;
                 silu_pack(a5, lane_mask(32 * (s0 + k) + L.n < T_), h5);
                 p6_store(col + (size_t)(32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, h5);
-                if (SAVE) {
-                    P6 pa;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a5[2 * i], a5[2 * i + 1]);
-                    p6_gstore(sv.a5 + gsave + (size_t)(32 * (s0 + k) + L.n) * TS_CG, pa, 32 * (s0 + k) + L.n < T_, true);
-                }
             }
     }
     PHASE(5);
@@ -473,20 +468,20 @@ size_t tconvffn_s_fwd_lds(int T) {
     return (NT + TS_PAD) * TS_RS * sizeof(bf16_t) + (size_t)TS_WL_FR * 512 * sizeof(bf16_t) + PHASE_LDS_BYTES;
 }
 
-// layout of one layer's saved state (tconvffn_save_bytes(c) bytes): a1 | a2 | a3 | a5 ([G][N][24] bf16 each) | LayerNorm stats [N][2] f32 |
+// layout of one layer's saved state (tconvffn_save_bytes(c) bytes): a1 | a2 | a3 ([G][N][24] bf16 each) | LayerNorm stats [N][2] f32 |
 // GroupNorm stats [B*F][G][2] f32
 size_t tconvffn_save_bytes(const nbss_cfg& c) {
     if (c.dtype != NBSS_BF16 || c.H != TS_H || c.T > 256) return 0;
     const size_t N = (size_t)c.B * c.F * c.T;
-    return 4 * ws_align(N * TS_FFN * sizeof(bf16_t)) + ws_align(N * 2 * sizeof(float)) + ws_align((size_t)c.B * c.F * TS_G * 2 * sizeof(float));
+    return 3 * ws_align(N * TS_FFN * sizeof(bf16_t)) + ws_align(N * 2 * sizeof(float)) + ws_align((size_t)c.B * c.F * TS_G * 2 * sizeof(float));
 }
 TsSave ts_save_ptrs(const nbss_cfg& c, void* tsave) {
     const size_t N = (size_t)c.B * c.F * c.T, tb = ws_align(N * TS_FFN * sizeof(bf16_t));
     char* b = (char*)tsave;
     TsSave sv;
-    sv.a1 = (bf16_t*)b; sv.a2 = (bf16_t*)(b + tb); sv.a3 = (bf16_t*)(b + 2 * tb); sv.a5 = (bf16_t*)(b + 3 * tb);
-    sv.ln = (float*)(b + 4 * tb);
-    sv.gn = (float*)(b + 4 * tb + ws_align(N * 2 * sizeof(float)));
+    sv.a1 = (bf16_t*)b; sv.a2 = (bf16_t*)(b + tb); sv.a3 = (bf16_t*)(b + 2 * tb);
+    sv.ln = (float*)(b + 3 * tb);
+    sv.gn = (float*)(b + 3 * tb + ws_align(N * 2 * sizeof(float)));
     return sv;
 }
 
@@ -506,7 +501,7 @@ int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, i
         if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<true>, lds))) return e;
         NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave));
     } else {
-        TsSave none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        TsSave none = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<false>, lds))) return e;
         NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none);
     }
@@ -1161,11 +1156,11 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
 // by the forward and read here, 170 KB of partial row per sequence.  Still emitted: h5 (W2 weight gradient) and da1 (tail + W1 weight
 // gradient, tailw.hip).
 struct TvIn {
-    const bf16_t *a1, *a2, *a3, *a5;
+    const bf16_t *a1, *a2, *a3;
     const float* gn;
 };
 struct TvW {
-    const bf16_t *W2T, *C1T, *C2T, *C3T;
+    const bf16_t *W2T, *C1T, *C2T, *C3T, *C3;
 };
 #define TV_CONVW (TS_FFN * TS_CG * 3)                 // one conv weight [192][24][3]
 #define TV_PSTRIDE (2 * TS_FFN + 3 * (TV_CONVW + TS_FFN))  // floats per `part` row: GN w | GN b | (conv W | conv b) x 3
@@ -1254,18 +1249,15 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
             for (int i_ = 0; i_ < 6; ++i_) dst.d[i_] = 0u;                           \
     }
 #define TV_LOADA4(src) TV_LOADA(0, src, ra0) TV_LOADA(1, src, ra1) TV_LOADA(2, src, ra2) TV_LOADA(3, src, ra3)
-    // ---- strip phase: dh5 = W2^T dy, (h5, SiLU'(a5)) from the saved a5: da5 -> S at bases (1,7), h5 -> operand --------------------------------
+    // ---- strip phase: dh5 = W2^T dy -> S at bases (1,7) (it becomes da5 in place once a5 has been rebuilt from h4, stage 1b) --------------------
     {
         u32x4 wr[3];  // 24 W2^T fragments of this workgroup's four groups
 #pragma unroll
         for (int i = 0; i < 3; ++i) wr[i] = reinterpret_cast<const u32x4*>(W.W2T + (size_t)gh * 24 * 512)[tid + i * 512];
         u32x4 rawd[6];
-        P6 a5r[4];
         const int t = 32 * w + L.n, tc = t < T_ ? t : T_ - 1;
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) rawd[ks] = *reinterpret_cast<const u32x4*>(dyb + (size_t)tc * TS_H + 16 * ks + 8 * L.h);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) p6_gload(sv.a5 + ((size_t)(4 * gh + q) * ntok + n0 + tc) * TS_CG + 4 * L.h, a5r[q]);
         TV_LOADA4(sv.a3)
         for (int i = tid; i < 4 * TB_RS / 2; i += 512) reinterpret_cast<uint32_t*>(S)[i] = 0u;
         for (int i = tid; i < 5 * TB_RS / 2; i += 512) reinterpret_cast<uint32_t*>(S + (size_t)(NT + 4) * TB_RS)[i] = 0u;
@@ -1275,8 +1267,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
         lds_barrier();
         PHASE(1);
         if (w < NS) {
-            const bool tv = t < T_;
-            const uint32_t vm = lane_mask(tv);
+            const uint32_t vm = lane_mask(t < T_);
             FragH dq[6];
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) dq[ks].v = __builtin_bit_cast(s16x8, rawd[ks]);
@@ -1288,18 +1279,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
                 f32x16 d5 = mma32(w2t[0], dq[0], f32x16_zero());
 #pragma unroll
                 for (int ks = 1; ks < 6; ++ks) d5 = mma32(w2t[ks], dq[ks], d5);
-                float a5[12], hv[12], dv[12];
-                p6_unpack(a5r[q], a5);
+                float dv[12];
 #pragma unroll
-                for (int r = 0; r < 12; ++r) {
-                    silu_dsilu(a5[r], hv[r], dv[r]);
-                    dv[r] *= d5[r];
-                }
-                P6 ph, pd;
-                p6_pack(hv, vm, ph);
+                for (int r = 0; r < 12; ++r) dv[r] = d5[r];
+                P6 pd;
                 p6_pack(dv, vm, pd);
                 p6_store(srow + q * TS_CG, pd);
-                p6_gstore(op_h5 + ((size_t)(4 * gh + q) * ntok + n0 + t) * TS_CG + 4 * L.h, ph, tv, true);
             }
         }
     }
@@ -1369,6 +1354,45 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
 #undef TV_STAGE1
     TV_LOADA4(sv.a2)  // needed in B3b: requested now, AHEAD of the contraction's partial-row stores (loads and stores share vmcnt)
     PHASE(4);
+    lds_barrier();
+    // stage 1b: a5 = conv3(h4) rebuilt from H (own strips; neighbours' rows are complete), (h5, SiLU'(a5)) from one sigmoid: h5 -> operand,
+    // da5 = dh5 * SiLU'(a5) in place in S (this lane's own piece)
+    {
+        FragH wf[5];
+        load_wfrags<5>(wf, W.C3, g, L.lane);
+#pragma unroll 1
+        for (int s0 = s_beg; s0 < s_end; s0 += TB_SB) {
+            FragH b[TB_SB][5];
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const bf16_t* r1 = Hc + (size_t)(1 + 32 * (s0 + k) + L.n) * TB_RS;
+                    conv_bfrags3(L, r1 - TB_RS, r1, r1 + TB_RS, b[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    const bool tv = t < T_;
+                    const uint32_t vm = lane_mask(tv);
+                    const f32x16 a5 = conv_mma(wf, b[k]);
+                    bf16_t* r = orow(t, 1, 7);
+                    P6 p5, ph, pd;
+                    p6_load(r, p5);
+                    float hv[12], dv[12], d5[12];
+                    p6_unpack(p5, d5);
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {
+                        silu_dsilu(a5[q], hv[q], dv[q]);
+                        dv[q] *= d5[q];
+                    }
+                    p6_pack(hv, vm, ph);
+                    p6_pack(dv, vm, pd);
+                    p6_store(r, pd);
+                    p6_gstore(op_h5 + gsv + (size_t)t * TS_CG, ph, tv, true);
+                }
+        }
+    }
     lds_barrier();
     PHASE(5);
     // stage 2: conv3 weight gradient: da5 (1,7) x h4
@@ -1596,9 +1620,10 @@ int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     const size_t h_el = (NT + 2) * TB_RS > (size_t)24 * 512 ? (NT + 2) * TB_RS : (size_t)24 * 512;
     const size_t lds = ((NT + TB_PAD) * TB_RS + h_el) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + 8 * TS_CG * sizeof(bf16_t) + PHASE_LDS_BYTES;
     const bf16_t* pk = (const bf16_t*)packed;
-    TvW W = {pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1_T), pk + pack_off(c, layer, K_TS_C2_T), pk + pack_off(c, layer, K_TS_C3_T)};
+    TvW W = {pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1_T), pk + pack_off(c, layer, K_TS_C2_T), pk + pack_off(c, layer, K_TS_C3_T),
+             pk + pack_off(c, layer, K_TS_C3)};
     const TsSave s = ts_save_ptrs(c, tsave);
-    TvIn in = {s.a1, s.a2, s.a3, s.a5, s.gn};
+    TvIn in = {s.a1, s.a2, s.a3, s.gn};
     int e = NBSS_SET_MAX_LDS(tconvffn_bwd_v_kernel, lds);
     if (e) return e;
     NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, (bf16_t*)op_h5, (bf16_t*)op_da1);
