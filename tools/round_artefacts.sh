@@ -18,6 +18,9 @@ import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['batch_per_gp
 python tools/rocprof_summary.py gpurun_out/${TAG}_prof gpurun_out/${TAG}_rocprof.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline (batch 32; 7 steps + one-time table/pack kernels)"
 python tools/gpu_idle.py gpurun_out/${TAG}_prof | tee gpurun_out/${TAG}_gpu_idle.txt
 python tools/wgrad_breakdown.py gpurun_out/${TAG}_prof > gpurun_out/${TAG}_wgrad_breakdown.txt
+# the rows around the hot path: on-device simulator throughput (f4) and the OnlineSpatialNet streaming step, native vs torch.nn (f2)
+python tools/sim_throughput.py 32 12 2>/dev/null | tail -1 > gpurun_out/${TAG}_sim_throughput.json; cat gpurun_out/${TAG}_sim_throughput.json
+python tools/online_throughput.py 16 32 2>/dev/null | tail -1 > gpurun_out/${TAG}_online_throughput.json; cut -c1-400 gpurun_out/${TAG}_online_throughput.json
 find gpurun_out/${TAG}_prof -name "*.db" -delete
 # PMC passes LAST: on this pool a bench run that follows rocprofv3 --pmc passes was measured 12 % slower (mhsa_fwd 2x), so the
 # timed runs above must not come after them.  bench.py reads roofline.traffic from profiles/pmc_traffic.json (the previous
@@ -32,6 +35,7 @@ k = b["roofline"]["kernel"]
 if t.get("batch") == b["config"]["batch_per_gpu"] and k in t["kernels"]:
     b["roofline"]["traffic"] = t["kernels"][k]["hbm_bytes"]
     b["roofline"]["traffic_commit"] = t.get("commit")
+    b["roofline"]["traffic_stale"] = t.get("csrc_hash") != b["roofline"].get("csrc_hash")
     b["roofline"]["traffic_source"] = "tools/pmc_traffic.sh passes of the same round_artefacts.sh call"
 m = json.load(open("gpurun_out/pmc_mfma.json"))
 if k in m["kernels"]:
