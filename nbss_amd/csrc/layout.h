@@ -215,11 +215,12 @@ NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // whole conv weight gradient [H][H / groups][ks] + its bias [H] as this workgroup's two frames see it; affine_reduce folds the rows
 #define NBSS_FC_PROW(c) (3 * (c).H + (c).H * ((c).H / (c).f_groups) * (c).f_ks + (c).H)
 NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * ((c.T + 1) / 2) * NBSS_FC_PROW(c) * sizeof(float); }
-// T-ConvFFN backward from saved pre-activations (tconvffn_s.hip: tconvffn_bwd_v_kernel; bf16 stream, small geometry): one partial row per
-// sequence = the GroupNorm affine sums (2 FFN) + the three conv weight gradients [FFN][FFN / groups][ks] with their biases [FFN]
-#define NBSS_TC_PROW(c) (2 * (c).FFN + 3 * ((c).FFN * ((c).FFN / (c).t_groups) * (c).t_ks + (c).FFN))
+// T-ConvFFN backward from saved pre-activations (tconvffn_s.hip: tconvffn_bwd_v_kernel; bf16 stream, small geometry): per sequence one fp32
+// partial row (GroupNorm affine sums 2 FFN + the three conv bias sums 3 FFN) and one bf16 row (the three conv weight gradients)
 NBSS_HD size_t tc_part_bytes(const nbss_cfg& c) {
-    return c.dtype == NBSS_BF16 && c.H == 96 && c.T <= 256 ? (size_t)c.B * c.F * NBSS_TC_PROW(c) * sizeof(float) : 0;
+    return c.dtype == NBSS_BF16 && c.H == 96 && c.T <= 256
+               ? (size_t)c.B * c.F * (5 * c.FFN * sizeof(float) + (size_t)3 * c.FFN * (c.FFN / c.t_groups) * c.t_ks * 2)
+               : 0;
 }
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;

@@ -1163,7 +1163,8 @@ struct TvW {
     const bf16_t *W2T, *C1T, *C2T, *C3T, *C3;
 };
 #define TV_CONVW (TS_FFN * TS_CG * 3)                 // one conv weight [192][24][3]
-#define TV_PSTRIDE (2 * TS_FFN + 3 * (TV_CONVW + TS_FFN))  // floats per `part` row: GN w | GN b | (conv W | conv b) x 3
+#define TV_PSTRIDE (2 * TS_FFN + 3 * TS_FFN)           // floats per fp32 `part` row: GN w | GN b | conv1 b | conv2 b | conv3 b
+#define TV_P16 (3 * TV_CONVW)                          // bf16 per `part16` row: the three conv weight gradients, each as [tap][in][out]
 
 // dW tile accumulation of one conv group over the whole sequence.  Sg = &S[0][24 gl], Hg = &H[0][24 gl]; bases (bl, bu) as in the stage that
 // wrote S; H holds token t at row t + 1 (rows 0 and NT + 1 are zero).
@@ -1196,29 +1197,59 @@ NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, in
         for (int j = 0; j < 5; ++j) acc[j] = mma(fa, fb[j], acc[j]);
     }
 }
-// prow = the sequence's partial row at the conv's weight block ([192][24][3] in the parameter's own order, then its [192] bias)
-NBSS_DEV void tv_flush(float* __restrict__ prow, int g, int mt, const f32x4 (&acc)[5], const f32x4& bsum) {
+// The per-sequence partial of a conv weight gradient leaves in bf16, as [tap][input channel][output channel] (a lane's four output channels are one
+// 8-byte store); tconv_part_reduce_kernel sums the rows in fp32 and writes the parameter's own [out][in][tap] order.  (Under the reference's
+// autocast the weight gradient of a bf16 convolution IS a bf16 tensor before it is cast up for the fp32 parameter; here only the per-sequence
+// partial sums are rounded, the sum over the 4 128 sequences is fp32.  Half the partial-row traffic of the fp32 rows: 0.35 instead of 0.7 GB each way.)
+// w16 = the row's block of this conv; brow = the fp32 row's bias block of this conv.
+NBSS_DEV void tv_flush(bf16_t* __restrict__ w16, float* __restrict__ brow, int g, int mt, const f32x4 (&acc)[5], const f32x4& bsum) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int oc0 = 16 * mt + 4 * g4;
+    if (oc0 < TS_CG) {
+        const int o0 = g * TS_CG + oc0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oc = 16 * mt + 4 * g4 + r;
-        if (oc < TS_CG) {
-            const int o = g * TS_CG + oc;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int pc = 4 * j + (l15 >> 2);
-                if (pc < 18) {
-                    const int tap = pc / 6, i = (pc - 6 * tap) * 4 + (l15 & 3);
-                    prow[((size_t)o * TS_CG + i) * 3 + tap] = acc[j][r];
-                }
+        for (int j = 0; j < 5; ++j) {
+            const int pc = 4 * j + (l15 >> 2);
+            if (pc < 18) {
+                const int tap = pc / 6, i = (pc - 6 * tap) * 4 + (l15 & 3);
+                const u32x2 v = {pack2bf(acc[j][0], acc[j][1]), pack2bf(acc[j][2], acc[j][3])};
+                *reinterpret_cast<u32x2*>(w16 + ((size_t)tap * TS_CG + i) * TS_FFN + o0) = v;
             }
-            if (l15 == 0) prow[TV_CONVW + o] = bsum[r];
+        }
+        if (l15 == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) brow[o0 + r] = bsum[r];
         }
     }
 }
 
+// G[conv k weight][(o * 24 + i) * 3 + tap] += sum over rows of part16[row][k][tap][i][o]; block (x, y): 256 threads x 2 outputs, slice y of the rows
+#define TV_RSL 32
+__global__ __launch_bounds__(256) void tconv_part_reduce_kernel(const bf16_t* __restrict__ part16, int nrows, float* __restrict__ G, long long off0, long long off1,
+                                                                long long off2) {
+    const int e2 = blockIdx.x * 256 + threadIdx.x;  // pair index
+    if (e2 >= TV_P16 / 2) return;
+    const int r0 = (int)((long)nrows * blockIdx.y / gridDim.y), r1 = (int)((long)nrows * (blockIdx.y + 1) / gridDim.y);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(part16) + e2;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    int r = r0;
+    for (; r + 2 <= r1; r += 2) {
+        const uint32_t u = p[(size_t)r * (TV_P16 / 2)], v = p[(size_t)(r + 1) * (TV_P16 / 2)];
+        a0 += __builtin_bit_cast(float, u << 16); a1 += __builtin_bit_cast(float, u & 0xFFFF0000u);
+        b0 += __builtin_bit_cast(float, v << 16); b1 += __builtin_bit_cast(float, v & 0xFFFF0000u);
+    }
+    for (; r < r1; ++r) {
+        const uint32_t u = p[(size_t)r * (TV_P16 / 2)];
+        a0 += __builtin_bit_cast(float, u << 16); a1 += __builtin_bit_cast(float, u & 0xFFFF0000u);
+    }
+    const int e = 2 * e2, k = e / TV_CONVW, q = e - k * TV_CONVW, tap = q / (TS_CG * TS_FFN), i = (q / TS_FFN) % TS_CG, o = q % TS_FFN;
+    float* g = G + (k == 0 ? off0 : k == 1 ? off1 : off2);
+    atomicAdd(g + ((size_t)o * TS_CG + i) * 3 + tap, a0 + b0);
+    atomicAdd(g + ((size_t)(o + 1) * TS_CG + i) * 3 + tap, a1 + b1);
+}
+
 __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPtrs lp, TvW W, TvIn sv, const bf16_t* __restrict__ dy, float* __restrict__ part,
-                                                             bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1) {
+                                                             bf16_t* __restrict__ part16, bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);         // [NT + TB_PAD][TB_RS]  the gradient chain, in place
@@ -1312,7 +1343,8 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     chan_vec12(lp.p[P_TF_GN_B] + g * TS_CG, L.h, gb);
     const float cnt = (float)(TS_CG * T_);
     const float gmean = sv.gn[((size_t)row * TS_G + g) * 2], grstd = sv.gn[((size_t)row * TS_G + g) * 2 + 1];
-    float* prow = part + (size_t)row * TV_PSTRIDE + 2 * TS_FFN;
+    float* prow = part + (size_t)row * TV_PSTRIDE + 2 * TS_FFN;   // conv bias blocks of the fp32 row
+    bf16_t* prow16 = part16 + (size_t)row * TV_P16;
 
     FragH wt[5];
     load_wfrags<5>(wt, W.C3T, g, L.lane);
@@ -1399,7 +1431,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     {
         f32x4 acc[5], bsum;
         tv_contract(Sc, Hc, 1, 7, NS, NSL, th, acc, bsum);
-        tv_flush(prow + 2 * (TV_CONVW + TS_FFN), g, th, acc, bsum);
+        tv_flush(prow16 + 2 * TV_CONVW, prow + 2 * TS_FFN, g, th, acc, bsum);
     }
     PHASE(6);
     // B3: conv3^T: da5 (1,7) -> dh4; dn3 = dh4 * SiLU'(n3) -> S (2,6); GroupNorm backward sums and affine gradients
@@ -1503,7 +1535,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     {
         f32x4 acc[5], bsum;
         tv_contract(Sc, Hc, 2, 6, NS, NSL, th, acc, bsum);
-        tv_flush(prow + 1 * (TV_CONVW + TS_FFN), g, th, acc, bsum);
+        tv_flush(prow16 + 1 * TV_CONVW, prow + 1 * TS_FFN, g, th, acc, bsum);
     }
     PHASE(12);
     // B2: conv2^T: da3 (2,6) -> dh2; da2 = dh2 * SiLU'(a2) (parked) -> S (3,5)
@@ -1562,7 +1594,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     {
         f32x4 acc[5], bsum;
         tv_contract(Sc, Hc, 3, 5, NS, NSL, th, acc, bsum);
-        tv_flush(prow, g, th, acc, bsum);
+        tv_flush(prow16, prow, g, th, acc, bsum);
     }
     PHASE(16);
     // B1: conv1^T: da2 (3,5) -> dh1; da1 = dh1 * SiLU'(a1) (parked) -> S (4,4) -> operand (whole rows, this wave's own run)
@@ -1610,11 +1642,18 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
 }
 PHASE_READER(nbss_phase_read_tconvffn_bwd_v)
 
-size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * TV_PSTRIDE * sizeof(float); }
+size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV_PSTRIDE * sizeof(float) + TV_P16 * sizeof(bf16_t)); }
+// fold of the bf16 conv-weight partial rows into G (fp32); offs = flat-gradient offsets of the three conv weights
+int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* G, const long long* offs, hipStream_t st) {
+    NBSS_LAUNCH(tconv_part_reduce_kernel, dim3((TV_P16 / 2 + 255) / 256, c.B * c.F < TV_RSL ? c.B * c.F : TV_RSL), dim3(256), 0, st, (const bf16_t*)part16, c.B * c.F, G,
+                offs[0], offs[1], offs[2]);
+    return NBSS_CHECK_LAUNCH();
+}
 
-// data-gradient + T-conv weight-gradient kernel from saved pre-activations; `part`: [B*F][TV_PSTRIDE] floats
+// data-gradient + T-conv weight-gradient kernel from saved pre-activations; `part`: [B*F][TV_PSTRIDE] floats, then [B*F][TV_P16] bf16
 int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5,
                           void* op_da1, hipStream_t st) {
+    bf16_t* part16 = reinterpret_cast<bf16_t*>(part + (size_t)c.B * c.F * TV_PSTRIDE);
     if (c.dtype != NBSS_BF16 || c.T > 256 || !tsave) return NBSS_EUNSUPPORTED;
     const size_t NT = (size_t)((c.T + 31) / 32) * 32;
     const size_t h_el = (NT + 2) * TB_RS > (size_t)24 * 512 ? (NT + 2) * TB_RS : (size_t)24 * 512;
@@ -1626,7 +1665,7 @@ int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     TvIn in = {s.a1, s.a2, s.a3, s.gn};
     int e = NBSS_SET_MAX_LDS(tconvffn_bwd_v_kernel, lds);
     if (e) return e;
-    NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, (bf16_t*)op_h5, (bf16_t*)op_da1);
+    NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_h5, (bf16_t*)op_da1);
     return NBSS_CHECK_LAUNCH();
 }
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave) { return ts_save_ptrs(c, tsave).ln; }
