@@ -261,7 +261,7 @@ def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, g
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
         ck["optimizer_states"] = [{"state": state, "param_groups": [group]}]
         # a complete torch.optim.lr_scheduler.ExponentialLR.state_dict() (what Lightning stores and restores)
-        gamma = float((module.lr_scheduler or (None, {}))[1].get("gamma", 1.0)) if module.lr_scheduler else 1.0
+        gamma = float((module.lr_scheduler or (None, {}))[1].get("gamma", 1.0)) if module.lr_scheduler and module.lr_scheduler[0] == "ExponentialLR" else 1.0
         base_lr = float(module.optimizer[1].get("lr", 1e-3))
         ck["lr_schedulers"] = [{"gamma": gamma, "base_lrs": [base_lr], "last_epoch": epoch + 1, "verbose": False, "_step_count": epoch + 2,
                                 "_get_lr_called_within_step": False, "_last_lr": [float(ts.lr)]}]
@@ -317,14 +317,38 @@ def _fused_step_for(module: "TrainModule", cfg: dict, dev):
     gamma = 1.0
     if module.lr_scheduler:
         sname, skw = module.lr_scheduler
-        if sname != "ExponentialLR":
-            raise NotImplementedError(f"lr_scheduler {sname}: only ExponentialLR (configs/SpatialNet.yaml) is implemented")
-        gamma = float(skw.get("gamma", 1.0))
+        if sname == "ExponentialLR":
+            gamma = float(skw.get("gamma", 1.0))
+        elif sname == "ReduceLROnPlateau":  # on the monitored validation metric (general_steps.py:259-271): handled by fit()'s _Plateau
+            gamma = _Plateau(**{k: v for k, v in skw.items() if k in ("mode", "factor", "patience", "threshold", "min_lr", "cooldown")})
+        else:
+            raise NotImplementedError(f"lr_scheduler {sname}: ExponentialLR (configs/SpatialNet.yaml) and ReduceLROnPlateau are implemented")
     ts = TrainStep(eng, n_fft=module.stft.n_fft, ref_channel=module.channels.index(module.ref_channel), lr=okw.get("lr", 1e-3),
                    betas=tuple(okw.get("betas", (0.9, 0.999))), eps=okw.get("eps", 1e-8), weight_decay=wd,
                    decoupled_weight_decay=oname == "AdamW", clip=float(tr.get("gradient_clip_val") or 0.0),
                    window=0 if module.stft.win == "hann_window" else 1)
     return eng, ts, gamma
+
+
+class _Plateau:
+    """torch.optim.lr_scheduler.ReduceLROnPlateau's rule (mode / factor / patience / rel. threshold / cooldown / min_lr) on a plain float lr"""
+
+    def __init__(self, mode: str = "min", factor: float = 0.1, patience: int = 10, threshold: float = 1e-4, min_lr: float = 0.0, cooldown: int = 0):
+        self.mode, self.factor, self.patience, self.threshold, self.min_lr, self.cooldown = mode, factor, patience, threshold, min_lr, cooldown
+        self.best, self.bad, self.cool = None, 0, 0
+
+    def step(self, metric: float, lr: float) -> float:
+        better = self.best is None or (metric < self.best * (1 - self.threshold) if self.mode == "min" else metric > self.best * (1 + self.threshold))
+        if better:
+            self.best, self.bad = metric, 0
+        else:
+            self.bad += 1
+        if self.cool > 0:
+            self.cool, self.bad = self.cool - 1, 0
+        if self.bad > self.patience:
+            self.cool, self.bad = self.cooldown, 0
+            return max(lr * self.factor, self.min_lr)
+        return lr
 
 
 def _check_train_geometry(module: "TrainModule", data=None) -> None:
@@ -393,9 +417,20 @@ def fit(cfg: dict) -> Dict[str, Any]:
             loss = ts.step(x[:, module.channels].to(dev).contiguous(), ys[:, :, module.ref_channel].to(dev).contiguous())
             tot += float(loss)
             n += 1
-        ts.lr *= gamma
+        # validation pass of the epoch (forward-only path, every rank the same unsharded split): `val/neg_si_sdr` is what `val_metric: loss`
+        # monitors in the reference (SharedTrainer.py:151-205) and what a ReduceLROnPlateau scheduler steps on
+        vtot, vn = 0.0, 0
+        for x, ys, _ in data.batches(1, 0, 1, 0):
+            vl, _, _, _, _ = ts.forward_loss(x[:, module.channels].to(dev).contiguous(), ys[:, :, module.ref_channel].to(dev).contiguous(), need_grad=False)
+            vtot, vn = vtot + float(vl), vn + 1
+        val = vtot / vn if vn else float("nan")
+        if isinstance(gamma, _Plateau):
+            if vn:
+                ts.lr = gamma.step(val, ts.lr)
+        else:
+            ts.lr *= gamma
         ts.check_replicas()  # every N steps (here: once per epoch): all ranks must still hold bitwise the same parameters and moments
-        rec = {"epoch": epoch, "train/neg_si_sdr": tot / max(n, 1), "steps": n, "sec": time.time() - t0}
+        rec = {"epoch": epoch, "train/neg_si_sdr": tot / max(n, 1), "val/neg_si_sdr": val, "lr": ts.lr, "steps": n, "sec": time.time() - t0}
         log.append(rec)
         if rank == 0:
             print(json.dumps(rec), flush=True)

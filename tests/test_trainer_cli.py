@@ -40,6 +40,23 @@ def test_fit_one_epoch_on_gpu():
     log = cli.result["log"]
     assert len(log) == 2 and all(torch.isfinite(torch.tensor(r["train/neg_si_sdr"])) for r in log)
     assert log[1]["train/neg_si_sdr"] < log[0]["train/neg_si_sdr"]
+    assert all(torch.isfinite(torch.tensor(r["val/neg_si_sdr"])) for r in log)  # the epoch's validation pass (val_metric: loss)
+    # a scheduler on the validation metric: ReduceLROnPlateau with patience 0 and an unreachable threshold halves the rate every epoch after the first
+    cli = TrainCLI(argv=argv + ["--model.lr_scheduler=[ReduceLROnPlateau, {factor: 0.5, patience: 0, threshold: 0.9}]"])
+    lrs = [r["lr"] for r in cli.result["log"]]
+    assert lrs[0] == 1e-3 and abs(lrs[1] - 5e-4) < 1e-12, lrs
+
+
+def test_plateau_rule_matches_torch():
+    from SharedTrainer import _Plateau
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=1, threshold=1e-2, cooldown=1, min_lr=0.05)
+    mine, lr = _Plateau(mode="min", factor=0.5, patience=1, threshold=1e-2, cooldown=1, min_lr=0.05), 1.0
+    for m in [5.0, 4.0, 4.0, 4.0, 3.99, 4.1, 4.2, 4.3, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]:
+        ref.step(m)
+        lr = mine.step(m, lr)
+        assert abs(lr - opt.param_groups[0]["lr"]) < 1e-12, (m, lr, opt.param_groups[0]["lr"])
 
 
 @pytest.mark.gpu
