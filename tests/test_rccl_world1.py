@@ -56,3 +56,42 @@ def test_bucketed_equals_single_collective_on_rccl(hip_lib):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replica_sync_checksum_and_comm_timing_on_rccl(hip_lib):
+    """what bench.py / fit do around the steps when WORLD_SIZE > 1, on a 1-rank RCCL group: broadcast of parameters and Adam state (fp32 buffers
+    + an fp64 scalar pair), the fp64 MIN / MAX all-reduces of the replica checksum, all_gather_object of the world size, and the event-timed
+    bucket waits — every collective flavour and dtype the multi-GPU path uses has to exist in RCCL"""
+    import torch.distributed as dist
+    from nbss_amd.engine import SpatialNetEngine, TrainStep
+    from oracle import spatialnet_ref as ref
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        eng = SpatialNetEngine(hip_lib, dev, dim_input=12, dim_output=4, num_freqs=129, num_layers=2, dtype=NBSS_BF16)
+        eng.load_params(ref.init_params(num_layers=2, num_freqs=129, dim_input=12, dim_output=4, seed=0))
+        ts = TrainStep(eng, bucketed=True, force_collectives=True)
+        before = eng.params.clone()
+        ts.sync_replicas()
+        assert torch.equal(eng.params, before) and ts.step_count == 0 and ts.lr == 1e-3
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(2, 6, 8000, generator=g).to(dev)
+        yr = torch.randn(2, 2, 8000, generator=g).to(dev)
+        ts.comm_wait_ms = 0.0
+        for _ in range(3):
+            ts.step(x, yr)
+        ms = ts.comm_wait_read()
+        assert ms >= 0.0 and ts.comm_wait_read() == 0.0
+        assert ts.check_replicas() == 0.0
+        worlds = [None]
+        dist.all_gather_object(worlds, dist.get_world_size())
+        assert worlds == [1]
+    finally:
+        if own:
+            dist.destroy_process_group()
