@@ -187,6 +187,12 @@ int nbss_online_encoder_step(int BF, int C, int C_in, const float* weight, const
  * wk_t = NULL shares k with q ('ret(2,share_qk)'); decay [4] = the per-head gamma.  x [BF][C][96] in place. */
 int nbss_online_ret_step(int BF, int C, const float* ln_w, const float* ln_b, const float* wq_t, const float* wk_t, const float* wv_t, const float* wg_t,
                          const float* wo_t, const float* decay, float* kv, float* scale, float* x, void* stream);
+/* 'mhsa(N)': x += out_proj(causal windowed attention over the last `scope` frames) with LayerNorm(x) as input.  kring / vring [BF][ring][96]: the projected
+ * keys / values of the last frames at slot (frame index mod ring), ring >= scope - 1 + C; pos[0] (device int32): frames seen before this chunk — every layer's
+ * call of a step reads it, nbss_online_advance adds C once at the end of the step.  win_t [96][288] / wo_t [96][96]: in_proj / out_proj weights transposed. */
+int nbss_online_mhsa_step(int BF, int C, int scope, int ring, const float* ln_w, const float* ln_b, const float* win_t, const float* bin, const float* wo_t,
+                          const float* bo, float* kring, float* vring, const int32_t* pos, float* x, void* stream);
+int nbss_online_advance(int32_t* pos, int C, void* stream);
 /* x += causal T-ConvFFN(x): LayerNorm -> 1x1 -> SiLU -> causal gconv -> SiLU -> causal gconv -> GroupNorm of each FRAME over (24 channels
  * x all F frequencies) -> SiLU -> causal gconv -> SiLU -> 1x1.  w1_t [96][192], w2_t [192][96] transposed; conv weights [192][24][3];
  * s1 s2 s3 [BF][2][192] = the last two input frames of the three convs; a3 [BF][C][192] and gn_sums [B][C][8][2] are scratch. */

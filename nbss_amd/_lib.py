@@ -75,6 +75,8 @@ SIGNATURES = {
     "nbss_pit_neg_sisdr": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "nbss_online_encoder_step": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "nbss_online_ret_step": (_I, [_I, _I] + [_P] * 12),
+    "nbss_online_mhsa_step": (_I, [_I, _I, _I, _I] + [_P] * 11),
+    "nbss_online_advance": (_I, [_P, _I, _P]),
     "nbss_online_tconvffn_step": (_I, [_I, _I, _I] + [_P] * 21),
     "nbss_clip_adam_step": (_I, [C.c_int64, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),

@@ -260,6 +260,105 @@ __global__ __launch_bounds__(ON_FFN) void online_tconv_b_kernel(int F, int C, co
     }
 }
 
+
+// Causal windowed multi-head self-attention over a K/V ring ('mhsa(N)', OnlineSpatialNet.py:356-385 + nn.MultiheadAttention): frame i of the chunk
+// attends to the last `scope` frames up to and including itself.  The ring holds the projected keys / values of the last R >= scope - 1 + C frames
+// of the sequence at slot (frame index mod R); `pos` (device-side, one int per launch grid: frames seen so far) advances by C per call, so the
+// step stays a fixed launch sequence.  grid = B*F, block = 256.  win_t [96][288] = in_proj_weight^T, wo_t [96][96] = out_proj.weight^T.
+#define ON_AT 256
+__global__ __launch_bounds__(ON_AT) void online_mhsa_kernel(int C, int scope, int R, const float* __restrict__ lw, const float* __restrict__ lb,
+                                                           const float* __restrict__ win_t, const float* __restrict__ bin, const float* __restrict__ wo_t,
+                                                           const float* __restrict__ bo, float* __restrict__ kring, float* __restrict__ vring,
+                                                           const int* __restrict__ pos, float* __restrict__ x) {
+    NBSS_LDS(smem);
+    float* u = reinterpret_cast<float*>(smem);  // [C][96]   LN(x), later the attention output of the chunk
+    float* q = u + C * ON_H;                    // [C][96]
+    float* sc = q + C * ON_H;                   // [4][R]    scores / probabilities of one frame
+    float* red = sc + ON_HEADS * R;             // [2][4]    per-head max / sum
+    const int bf = blockIdx.x, j = threadIdx.x, t0 = pos[0];
+    float* xr = x + (size_t)bf * C * ON_H;
+    float* kr = kring + (size_t)bf * R * ON_H;
+    float* vr = vring + (size_t)bf * R * ON_H;
+    on_layernorm(xr, C, lw, lb, u);
+    __syncthreads();
+    // in_proj: 288 outputs over 256 threads (thread j and, for j < 32, j + 256); q is scaled by 1 / sqrt(dh); k, v go to their ring slots
+    for (int o = j; o < 3 * ON_H; o += ON_AT) {
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) acc[cc] = bin[o];
+            for (int i = 0; i < ON_H; ++i) {
+                const float w = win_t[i * 3 * ON_H + o];
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) acc[cc] += w * u[(c0 + cc < C ? c0 + cc : C - 1) * ON_H + i];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (c0 + cc < C) {
+                    const int c = c0 + cc, slot = (t0 + c) % R;
+                    if (o < ON_H) q[c * ON_H + o] = acc[cc] * 0.20412414523193154f;  // 1 / sqrt(24)
+                    else if (o < 2 * ON_H) kr[(size_t)slot * ON_H + o - ON_H] = acc[cc];
+                    else vr[(size_t)slot * ON_H + o - 2 * ON_H] = acc[cc];
+                }
+        }
+    }
+    __syncthreads();  // (the ring rows written above are read below by other threads of this workgroup; these lines were not read earlier in this launch)
+    for (int c = 0; c < C; ++c) {
+        const int tcur = t0 + c, nk = tcur + 1 < scope ? tcur + 1 : scope;  // keys: frames tcur - nk + 1 .. tcur
+        for (int e = j; e < ON_HEADS * nk; e += ON_AT) {
+            const int hd = e / nk, kk = e - hd * nk, slot = (tcur - nk + 1 + kk) % R;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < ON_DK; ++d) s += q[c * ON_H + hd * ON_DK + d] * kr[(size_t)slot * ON_H + hd * ON_DK + d];
+            sc[hd * R + kk] = s;
+        }
+        __syncthreads();
+        if (j < ON_HEADS) {
+            float mx = -1e30f;
+            for (int kk = 0; kk < nk; ++kk) mx = fmaxf(mx, sc[j * R + kk]);
+            red[j] = mx;
+        }
+        __syncthreads();
+        for (int e = j; e < ON_HEADS * nk; e += ON_AT) {
+            const int hd = e / nk, kk = e - hd * nk;
+            sc[hd * R + kk] = __expf(sc[hd * R + kk] - red[hd]);
+        }
+        __syncthreads();
+        if (j < ON_HEADS) {
+            float sum = 0.f;
+            for (int kk = 0; kk < nk; ++kk) sum += sc[j * R + kk];
+            red[ON_HEADS + j] = 1.0f / sum;
+        }
+        __syncthreads();
+        if (j < ON_H) {  // output channel j = (head, d): sum over the keys
+            const int hd = j / ON_DK;
+            float o = 0.f;
+            for (int kk = 0; kk < nk; ++kk) o += sc[hd * R + kk] * vr[(size_t)((tcur - nk + 1 + kk) % R) * ON_H + j];
+            u[c * ON_H + j] = o * red[ON_HEADS + hd];
+        }
+        __syncthreads();
+    }
+    if (j < ON_H) {
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) acc[cc] = bo[j];
+            for (int i = 0; i < ON_H; ++i) {
+                const float w = wo_t[i * ON_H + j];
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) acc[cc] += w * u[(c0 + cc < C ? c0 + cc : C - 1) * ON_H + i];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (c0 + cc < C) xr[(c0 + cc) * ON_H + j] += acc[cc];
+        }
+    }
+}
+// advances the frame counter of a stream by C (after every layer's attention of the step has read it)
+__global__ void online_pos_advance_kernel(int* pos, int C) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) pos[0] += C;
+}
+
 int memset_async_impl(void* p, size_t bytes, hipStream_t st);
 
 static bool on_ok(int BF, int C) { return BF > 0 && C > 0 && C <= ON_CMAX; }
@@ -299,6 +398,23 @@ int nbss_online_tconvffn_step(int B, int F, int C, const float* ln_w, const floa
     const size_t lds_b = ((size_t)(C + 2) * ON_FFN + (size_t)C * ON_FFN) * sizeof(float);
     if ((e = NBSS_SET_MAX_LDS(online_tconv_b_kernel, lds_b))) return e;
     NBSS_LAUNCH(online_tconv_b_kernel, dim3(B * F), dim3(ON_FFN), lds_b, st, F, C, gn_w, gn_b, c3w, c3b, w2_t, b2, s3, (const float*)a3, (const float*)gn_sums, x);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int nbss_online_mhsa_step(int BF, int C, int scope, int ring, const float* ln_w, const float* ln_b, const float* win_t, const float* bin, const float* wo_t,
+                          const float* bo, float* kring, float* vring, const int32_t* pos, float* x, void* stream) {
+    if (!on_ok(BF, C) || scope <= 0 || ring < scope - 1 + C || !ln_w || !ln_b || !win_t || !bin || !wo_t || !bo || !kring || !vring || !pos || !x) return NBSS_EINVAL;
+    const size_t lds = ((size_t)2 * C * ON_H + (size_t)ON_HEADS * ring + 2 * ON_HEADS) * sizeof(float);
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e = NBSS_SET_MAX_LDS(online_mhsa_kernel, lds);
+    if (e) return e;
+    NBSS_LAUNCH(online_mhsa_kernel, dim3(BF), dim3(ON_AT), lds, (hipStream_t)stream, C, scope, ring, ln_w, ln_b, win_t, bin, wo_t, bo, kring, vring, (const int*)pos, x);
+    return NBSS_CHECK_LAUNCH();
+}
+
+int nbss_online_advance(int32_t* pos, int C, void* stream) {
+    if (!pos || C <= 0) return NBSS_EINVAL;
+    NBSS_LAUNCH(online_pos_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)pos, C);
     return NBSS_CHECK_LAUNCH();
 }
 

@@ -130,7 +130,7 @@ def _native_net(seed=5, **over):
     return net
 
 
-@pytest.mark.parametrize("chunk,over", [(8, {}), (5, {}), (16, {"attention": "ret(2,not_share_qk)"})])
+@pytest.mark.parametrize("chunk,over", [(8, {}), (5, {}), (16, {"attention": "ret(2,not_share_qk)"}), (8, {"attention": "mhsa(11)"}), (4, {"attention": "mhsa(40)"})])
 def test_native_streaming_step_matches_module(backend, chunk, over):
     """the HIP streaming step (encoder / retention / T-ConvFFN kernels of csrc/online.hip + the cross-band kernels), chunk by chunk, against the
     module's own whole-utterance forward (parallel retention) and its torch streaming step (the module itself is pinned to the reference by
@@ -156,7 +156,8 @@ def test_native_streaming_step_matches_module(backend, chunk, over):
 def test_native_streaming_refuses_other_geometries():
     from nbss_amd.online import NativeOnlineStreamer, supported
     assert supported(_native_net()) is None
-    for over in ({"attention": "mhsa(7)"}, {"dim_hidden": 32, "dim_ffn": 64}, {"rope": True}):
+    assert supported(_native_net(attention="mhsa(7)")) is None
+    for over in ({"attention": "mhsa(inf)"}, {"dim_hidden": 32, "dim_ffn": 64}, {"rope": True}, {"attention": "mhsa(7)", "rope": "ALiBi"}):
         net = _native_net(**over)
         assert supported(net) is not None
         with pytest.raises(NotImplementedError):
