@@ -1114,7 +1114,7 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
 int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5,
                           void* op_da1, hipStream_t st);
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave);
-int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* G, const long long* offs, hipStream_t st);
+int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, hipStream_t st);
 
 // bf16 stream, from the pre-activations a training-mode forward saved (tconvffn_s.hip): data gradient + the three T-conv weight gradients in
 // one kernel, the tail + W1 weight gradient in tailw.hip, one fold of the per-sequence partial rows, the W2 weight gradient through wgrad.hip
@@ -1141,7 +1141,8 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     for (int k = 0; k < 3; ++k) { sg.off[2 + k] = param_off(c, layer, convBias[k]); sg.cnt[2 + k] = TF_FFN; }
     if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
     const long long woffs[3] = {param_off(c, layer, convW[0]), param_off(c, layer, convW[1]), param_off(c, layer, convW[2])};
-    if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN), G, woffs, st))) return e;
+    // (the slice sums of the fold live in the wgrad partial-tile region, idle between this sub-block's wgrad launches: 64 x 41 472 floats = 10.6 MB)
+    if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN), wgpart, G, woffs, st))) return e;
     // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
     WgradArgs a;
     a.part = wgpart;
