@@ -2,6 +2,8 @@
 // and dtype dispatch only; kernels live in the sibling .hip files.
 #include "launch.h"
 #include "layout.h"
+#include "side.h"
+#include <stdlib.h>
 
 int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipStream_t stream);
 int selftest_mma_impl(int dtype, int kperm, const float* A, const float* B, float* D, hipStream_t stream);
@@ -9,19 +11,19 @@ int encoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, cons
 int decoder_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, const void* x, float* out, hipStream_t st);
 int fconv_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, int which, const void* x, void* y, hipStream_t st);
 int full_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
-int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st);
+int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st, const SeqTail* tl);
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
-                  void* dx, void* ws, hipStream_t st);
-int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st);
+                  void* dx, void* ws, hipStream_t st, const Side* sd);
+int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st, const SeqTail* tl);
 size_t tconvffn_save_bytes(const nbss_cfg& c);
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,
-                      void* dx, void* ws, hipStream_t st);
+                      void* dx, void* ws, hipStream_t st, const Side* sd);
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
-                   void* ws, hipStream_t st);
+                   void* ws, hipStream_t st, const Side* sd);
 int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx, void* ws,
-                  hipStream_t st);
+                  hipStream_t st, const Side* sd);
 int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, const void* x, const float* dout, void* dx, void* ws,
                      hipStream_t st);
 int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, void* ws, hipStream_t st);
@@ -122,7 +124,7 @@ int nbss_mhsa_fwd(const nbss_cfg* cfg, const float* params, const void* packed, 
     CHECK_CFG(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !packed || !x || !y || x == y) return NBSS_EINVAL;
-    return mhsa_fwd_impl(*cfg, params, packed, layer, x, y, o_save, (hipStream_t)stream);
+    return mhsa_fwd_impl(*cfg, params, packed, layer, x, y, o_save, (hipStream_t)stream, nullptr);
 }
 
 int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
@@ -130,7 +132,7 @@ int nbss_mhsa_bwd(const nbss_cfg* cfg, const float* params, float* grads, const 
     CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !o_save || !dx || !ws) return NBSS_EINVAL;
-    return mhsa_bwd_impl(*cfg, params, grads, packed, layer, x, dy, o_save, dx, ws, (hipStream_t)stream);
+    return mhsa_bwd_impl(*cfg, params, grads, packed, layer, x, dy, o_save, dx, ws, (hipStream_t)stream, nullptr);
 }
 
 int64_t nbss_tconvffn_save_bytes(const nbss_cfg* cfg) {
@@ -143,7 +145,7 @@ int nbss_tconvffn_fwd(const nbss_cfg* cfg, const float* params, const void* pack
     CHECK_LAYER(cfg, layer);
     if (!params || !packed || !x || !y || x == y) return NBSS_EINVAL;
     if (t_save && tconvffn_save_bytes(*cfg) == 0) return NBSS_EUNSUPPORTED;
-    return tconvffn_fwd_impl(*cfg, params, packed, layer, x, y, t_save, (hipStream_t)stream);
+    return tconvffn_fwd_impl(*cfg, params, packed, layer, x, y, t_save, (hipStream_t)stream, nullptr);
 }
 
 int64_t nbss_workspace_bytes(const nbss_cfg* cfg) {
@@ -157,7 +159,7 @@ int nbss_tconvffn_bwd(const nbss_cfg* cfg, const float* params, float* grads, co
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
     if (t_save && tconvffn_save_bytes(*cfg) == 0) return NBSS_EUNSUPPORTED;
-    return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, t_save, dx, ws, (hipStream_t)stream);
+    return tconvffn_bwd_impl(*cfg, params, grads, packed, layer, x, dy, t_save, dx, ws, (hipStream_t)stream, nullptr);
 }
 
 int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, int which, const void* x,
@@ -165,7 +167,7 @@ int nbss_fconv_bwd(const nbss_cfg* cfg, const float* params, float* grads, const
     CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws || (which != 0 && which != 1)) return NBSS_EINVAL;
-    return fconv_bwd_impl(*cfg, params, grads, packed, layer, which, x, dy, dx, ws, (hipStream_t)stream);
+    return fconv_bwd_impl(*cfg, params, grads, packed, layer, which, x, dy, dx, ws, (hipStream_t)stream, nullptr);
 }
 
 int nbss_full_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, int layer, const void* x, const void* dy,
@@ -173,7 +175,7 @@ int nbss_full_bwd(const nbss_cfg* cfg, const float* params, float* grads, const 
     CHECK_CFG_TRAIN(cfg);
     CHECK_LAYER(cfg, layer);
     if (!params || !grads || !packed || !x || !dy || !dx || !ws) return NBSS_EINVAL;
-    return full_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream);
+    return full_bwd_impl(*cfg, params, grads, packed, layer, x, dy, dx, ws, (hipStream_t)stream, nullptr);
 }
 
 int nbss_decoder_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* x, const float* dout, void* dx,
@@ -190,6 +192,7 @@ int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const v
 }
 
 // ---- whole network: native sequencing of the sub-block kernels (one C call per direction) --------
+#define BWD_KINDS 5  // sub-blocks of a layer in backward order: T-ConvFFN, attention, F-conv 2, full, F-conv 1
 static size_t stream_bytes(const nbss_cfg& c) {
     return ws_align((size_t)c.B * c.F * c.T * c.H * (c.dtype == NBSS_BF16 ? 2 : 4));
 }
@@ -211,8 +214,44 @@ int64_t nbss_acts_bytes(const nbss_cfg* cfg) {
 
 int64_t nbss_train_ws_bytes(const nbss_cfg* cfg) {
     if (!cfg || check_cfg(*cfg) != NBSS_OK) return -1;
-    return (int64_t)(workspace_bytes(*cfg) + 2 * stream_bytes(*cfg));
+    // the backward walk: one workspace copy per sub-block kind + three rotating gradient buffers (see nbss_spatialnet_bwd_range);
+    // the forward walk uses the first copy and the two buffers behind it
+    return (int64_t)(BWD_KINDS * workspace_bytes(*cfg) + 3 * stream_bytes(*cfg));
 }
+
+// ---- the second stream of the walks (side.h): parameter-gradient launches in backward, the row kernels' tail launches in forward ------------
+// Owned by the library, created at the first backward walk.  done[k]: recorded on the gradient stream behind sub-block kind k's parameter-gradient
+// launches; the main stream waits for it before kind k's workspace copy (next layer) or a gradient buffer those launches read is written again.
+#ifndef NBSS_EMU
+struct SideState {
+    int state = 0;  // 0 = not tried, 1 = ready, -1 = unavailable / switched off (NBSS_SIDE_STREAM=0): in order
+    int device = -1;
+    Side sd;
+    hipEvent_t done[BWD_KINDS], join;
+    int ncu = 256;
+};
+static SideState g_side;
+static SideState* side_state() {
+    SideState& s = g_side;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (s.state == 1 && s.device != dev) s.state = 0;  // (one process per GPU: does not happen; a second device gets its own objects)
+    if (s.state == 0) {
+        s.state = -1;
+        s.device = dev;
+        const char* env = getenv("NBSS_SIDE_STREAM");
+        if (env && env[0] == '0') return nullptr;
+        bool ok = hipStreamCreateWithFlags(&s.sd.gs, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.sd.ready, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; ok && k < BWD_KINDS; ++k) ok = hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming) == hipSuccess;
+        hipDeviceProp_t prop;
+        if (ok && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) s.ncu = prop.multiProcessorCount;
+        if (ok) s.state = 1;
+    }
+    return s.state == 1 ? &s : nullptr;
+}
+#endif
 
 int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* xin, void* acts, void* ws, float* out,
                         void* stream) {
@@ -229,15 +268,35 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     auto buf = [&](int i) -> void* { return acts ? (void*)((char*)acts + (size_t)i * sb) : (void*)(pp + (size_t)(i & 1) * sb); };
     int e = encoder_fwd_impl(c, params, packed, xin, buf(0), st);
     if (e) return e;
+    // tail launches of the bf16 row kernels (side.h: SeqTail): when the last round of sequences is at most half full
+    SeqTail tl = {0, st};
+#ifndef NBSS_EMU
+    SideState* ss = side_state();
+    const int ncu = ss ? ss->ncu : 0;
+    if (ss) tl.ts = ss->sd.gs;
+#else
+    const int ncu = 4;  // (the emulator walks tiny grids through the same offset logic, in order)
+#endif
+    {
+        const int nseq = c.B * c.F, rem = ncu > 0 ? nseq % ncu : 0;
+        if (c.dtype == NBSS_BF16 && c.H == 96 && c.T <= NBSS_T_TRAIN_MAX && nseq > ncu && rem > 0 && 2 * rem <= ncu) tl.n = rem;
+    }
+    const SeqTail* tlp = tl.n > 0 ? &tl : nullptr;
     for (int l = 0; l < c.L; ++l) {
         // (inference beyond 256 frames: the head of ws, idle without a backward pass, is the attention's K | V scratch)
         void* osave = acts ? (void*)((char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c)) : (c.T > NBSS_T_TRAIN_MAX || c.H != 96) ? ws : nullptr;
         if ((e = fconv_fwd_impl(c, params, packed, l, 0, buf(k), buf(k + 1), st))) return e;
         if ((e = full_fwd_impl(c, params, packed, l, buf(k + 1), buf(k + 2), st))) return e;
         if ((e = fconv_fwd_impl(c, params, packed, l, 1, buf(k + 2), buf(k + 3), st))) return e;
-        if ((e = mhsa_fwd_impl(c, params, packed, l, buf(k + 3), buf(k + 4), osave, st))) return e;
+#ifndef NBSS_EMU
+        if (tlp && (hipEventRecord(ss->sd.ready, st) != hipSuccess || hipStreamWaitEvent(tl.ts, ss->sd.ready, 0) != hipSuccess)) return NBSS_ELAUNCH;
+#endif
+        if ((e = mhsa_fwd_impl(c, params, packed, l, buf(k + 3), buf(k + 4), osave, st, tlp))) return e;
         void* tsave = acts && tcf_save_bytes(c) ? (void*)((char*)acts + acts_tcf_offset(c) + (size_t)l * tcf_save_bytes(c)) : nullptr;
-        if ((e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), tsave, st))) return e;
+        if ((e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), tsave, st, tlp))) return e;
+#ifndef NBSS_EMU
+        if (tlp && (hipEventRecord(ss->join, tl.ts) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess)) return NBSS_ELAUNCH;
+#endif
         k += 5;
     }
     return decoder_fwd_impl(c, params, packed, buf(k), out, st);
@@ -251,29 +310,67 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
     if (layer_lo < 0 || layer_hi > c.L || layer_lo >= layer_hi) return NBSS_EINVAL;
     if (layer_hi == c.L && !dout) return NBSS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const size_t sb = stream_bytes(c);
+    const size_t sb = stream_bytes(c), wb = workspace_bytes(c);
     auto act = [&](int i) -> const void* { return (const char*)acts + (size_t)i * sb; };
-    char* gb = (char*)ws + workspace_bytes(c);
-    // the gradient stream ping-pongs between two buffers and swaps once per layer: which one is current follows from
-    // the number of layers already walked
-    void* dA = gb;
-    void* dB = gb + sb;
-    if ((c.L - layer_hi) & 1) { void* t = dA; dA = dB; dB = t; }
+    // ws = [BWD_KINDS workspace copies | 3 gradient buffers].  The gradient stream walks from buffer to buffer (sub-block j of the walk reads
+    // buffer j % 3 and writes (j + 1) % 3; the decoder wrote buffer 0), so that a sub-block's upstream gradient — an operand of its out_proj / W2
+    // weight-gradient problem on the gradient stream — is not overwritten by the NEXT sub-block (two buffers) but by the one after it
+    char* gb = (char*)ws + BWD_KINDS * wb;
+    auto gbuf = [&](int j) -> void* { return gb + (size_t)(j % 3) * sb; };
+    auto wsk = [&](int kind) -> void* { return (char*)ws + (size_t)kind * wb; };
+    int j = BWD_KINDS * (c.L - layer_hi);  // sub-blocks already walked
     int k = 5 * layer_hi;
     int e;
-    if (layer_hi == c.L && (e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, dA, ws, st))) return e;
+#ifndef NBSS_EMU
+    SideState* ss = side_state();
+    const Side* sd = ss ? &ss->sd : nullptr;
+    bool rec[BWD_KINDS] = {false, false, false, false, false};
+    int reader[3] = {-1, -1, -1};  // kind whose gradient-stream launches read buffer b (as their dy)
+    // before sub-block `kind` writes buffer `out`: its own workspace copy and that buffer must be free of gradient-stream readers
+    auto before = [&](int kind, int out) {
+        if (!ss) return;
+        if (rec[kind]) hipStreamWaitEvent(st, ss->done[kind], 0);
+        if (reader[out] >= 0 && reader[out] != kind) hipStreamWaitEvent(st, ss->done[reader[out]], 0);
+        reader[out] = -1;
+    };
+    auto after = [&](int kind, int in) {
+        if (!ss) return;
+        hipEventRecord(ss->done[kind], ss->sd.gs);
+        rec[kind] = true;
+        if (in >= 0) reader[in] = kind;  // (only the T-ConvFFN's W2 and the attention's out_proj problems contract against the upstream gradient)
+    };
+#else
+    const Side* sd = nullptr;
+    auto before = [&](int, int) {};
+    auto after = [&](int, int) {};
+#endif
+    if (layer_hi == c.L && (e = decoder_bwd_impl(c, params, grads, packed, act(k), dout, gbuf(0), wsk(0), st))) return e;
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         const void* osave = (const char*)acts + (size_t)(5 * c.L + 1) * sb + (size_t)l * mhsa_save_bytes(c);
         const void* tsave = tcf_save_bytes(c) ? (const void*)((const char*)acts + acts_tcf_offset(c) + (size_t)l * tcf_save_bytes(c)) : nullptr;
-        if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), dA, tsave, dB, ws, st))) return e;
-        if ((e = mhsa_bwd_impl(c, params, grads, packed, l, act(k - 2), dB, osave, dA, ws, st))) return e;
-        if ((e = fconv_bwd_impl(c, params, grads, packed, l, 1, act(k - 3), dA, dB, ws, st))) return e;
-        if ((e = full_bwd_impl(c, params, grads, packed, l, act(k - 4), dB, dA, ws, st))) return e;
-        if ((e = fconv_bwd_impl(c, params, grads, packed, l, 0, act(k - 5), dA, dB, ws, st))) return e;
-        void* t = dA; dA = dB; dB = t;
+        before(0, (j + 1) % 3);
+        if ((e = tconvffn_bwd_impl(c, params, grads, packed, l, act(k - 1), gbuf(j), tsave, gbuf(j + 1), wsk(0), st, sd))) return e;
+        after(0, j % 3);
+        before(1, (j + 2) % 3);
+        if ((e = mhsa_bwd_impl(c, params, grads, packed, l, act(k - 2), gbuf(j + 1), osave, gbuf(j + 2), wsk(1), st, sd))) return e;
+        after(1, (j + 1) % 3);
+        before(2, (j + 3) % 3);
+        if ((e = fconv_bwd_impl(c, params, grads, packed, l, 1, act(k - 3), gbuf(j + 2), gbuf(j + 3), wsk(2), st, sd))) return e;
+        after(2, -1);
+        before(3, (j + 4) % 3);
+        if ((e = full_bwd_impl(c, params, grads, packed, l, act(k - 4), gbuf(j + 3), gbuf(j + 4), wsk(3), st, sd))) return e;
+        after(3, -1);
+        before(4, (j + 5) % 3);
+        if ((e = fconv_bwd_impl(c, params, grads, packed, l, 0, act(k - 5), gbuf(j + 4), gbuf(j + 5), wsk(4), st, sd))) return e;
+        after(4, -1);
+        j += BWD_KINDS;
         k -= 5;
     }
-    return layer_lo == 0 ? encoder_bwd_impl(c, grads, xin, dA, ws, st) : NBSS_OK;
+#ifndef NBSS_EMU
+    // join: the caller's next work on `st` (the gradient all-reduce of this range, the optimizer) sees every parameter gradient
+    if (ss && (hipEventRecord(ss->join, ss->sd.gs) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess)) return NBSS_ELAUNCH;
+#endif
+    return layer_lo == 0 ? encoder_bwd_impl(c, grads, xin, gbuf(j), wsk(0), st) : NBSS_OK;
 }
 
 int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,

@@ -16,6 +16,7 @@
 #include "blocks.h"
 #include "wgrad.h"
 #include "geom.h"
+#include "side.h"
 #include <cstdlib>
 
 #define FC_H 96
@@ -573,7 +574,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
 #define FC_BWD_TT 2  // frames per workgroup of the bf16 backward (measured: 2 frames, one workgroup per CU beats 1 frame, two per CU by 2.2x in wave time)
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
-                   void* ws, hipStream_t st) {
+                   void* ws, hipStream_t st, const Side* sd) {
     const size_t N = (size_t)c.B * c.F * c.T;
     float* stats = (float*)ws;
     void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));
@@ -607,7 +608,8 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     sg.off[2] = param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU); sg.cnt[2] = FC_H;
     sg.off[3] = param_off(c, layer, which ? P_FC2_W : P_FC1_W); sg.cnt[3] = FC_H * FC_CG * 5;  // partial rows carry dW / db in their own order
     sg.off[4] = param_off(c, layer, which ? P_FC2_B : P_FC1_B); sg.cnt[4] = FC_H;
-    if ((e = affine_reduce_launch(part, nwg, sg, G, st))) return e;
+    const hipStream_t gs = side_fork(sd, st);  // the folds and the weight-gradient problem only produce parameter gradients (side.h)
+    if ((e = affine_reduce_launch(part, nwg, sg, G, gs))) return e;
     if (fused) return NBSS_OK;
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
     WgradArgs a;
@@ -617,7 +619,7 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     a.A = dv; a.lda = FC_H; a.MA = FC_H; a.B = x; a.ldb = FC_H; a.NB = FC_H;
     a.stats = stats; a.gamma = P + param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); a.beta = P + param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B);
     a.dW = G + param_off(c, layer, which ? P_FC2_W : P_FC1_W); a.dbias = G + param_off(c, layer, which ? P_FC2_B : P_FC1_B);
-    return wgrad_launch(a, c.dtype, st);
+    return wgrad_launch(a, c.dtype, gs);
 }
 
 template <class T, int TT, int GPW, int MTF, int HH>

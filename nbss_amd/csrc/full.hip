@@ -9,16 +9,18 @@
 //   pass 1  rows (f,tt) as MFMA N dim: LN in registers -> s = SiLU(Ws u + bs)
 //   pass 2  per squeeze channel c: z[:,tt] = Wf[c] (F x F) * s[c][tt][:]   (N = 8 frames)
 //   pass 3  y = x + SiLU(Wu z + bu)
+#include <stdlib.h>
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
 #include "geom.h"
+#include "side.h"
 
 #define FL_H 96
 #define FL_SQ 8
-#define FL_TT 8
+#define FL_TT_MAX 8  // frames per slab: 8, or 4 / 2 when 8 would leave most of the 256 CUs without a workgroup (full_tt)
 #define FL_KS (FL_H / 32)
 #define FL_MT (FL_H / 16)
 #define FL_KSF_MAX 5  // ceil(160 / 32): the 8-kHz geometry (F <= 160)
@@ -26,7 +28,7 @@
 #define FL_THREADS 512  // 8 waves: one workgroup per CU (256 slabs), so the waves of a workgroup are all the latency hiding there is
 
 // KSFM: LinearGroup k-steps the fragment arrays are sized for; HH / NSQ = dim_hidden / dim_squeeze (geom.h)
-template <class T, int KSFM, int HH, int NSQ>
+template <class T, int KSFM, int HH, int NSQ, int TT>
 #ifdef NBSS_FULLF_NOCAP
 __global__ __launch_bounds__(FL_THREADS)
 #else
@@ -41,14 +43,14 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
     const int F = c.F, T_ = c.T;
     const int mtf = cdiv(F, 16), ksf = cdiv(F, 32), FK = ksf * 32, FM = mtf * 16;
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]
-    T* z = s + NSQ * FL_TT * FK;                 // [FM][TT][SQ]
-    const int ntt = cdiv(T_, FL_TT);
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
+    T* z = s + NSQ * TT * FK;                 // [FM][TT][SQ]
+    const int ntt = cdiv(T_, TT);
+    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
-    const int ntile = cdiv(F, 2);  // n-tiles of (2 freqs x 8 frames)
+    const int ntile = cdiv(F, 16 / TT);  // n-tiles of (16 / TT freqs x TT frames)
 
-    for (int i = tid; i < NSQ * FL_TT * FK + FM * FL_TT * NSQ; i += nthr) store1(s + i, 0.f);
+    for (int i = tid; i < NSQ * TT * FK + FM * TT * NSQ; i += nthr) store1(s + i, 0.f);
     lds_barrier();
 
     // ---- pass 1: LN + squeeze + SiLU ---------------------------------------------------------
@@ -66,9 +68,9 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
             }
         // software pipeline (the same as full_bwd's row loops): the x pieces of the wave's NEXT tile are requested before this tile's math —
         // one workgroup of 8 waves per CU, and each wave walks 8 tiles load -> LayerNorm -> MFMA (SQ_WAIT_ANY was 77 % of the wave cycles)
-        const int tclf = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        const int tclf = t0 + (l15 % TT) < T_ ? t0 + (l15 % TT) : T_ - 1;
         auto row_of_f = [&](int nt) -> const T* {
-            const int f = 2 * nt + (l15 >> 3);
+            const int f = (16 / TT) * nt + (l15 / TT);
             return x + (((size_t)b * F + (f < F ? f : F - 1)) * T_ + tclf) * HH;
         };
         Frag<T> xnext[(HH / 32)];
@@ -77,7 +79,7 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
             for (int ks = 0; ks < (HH / 32); ++ks) frag_load(xnext[ks], row_of_f(w) + ks * 32 + 8 * g4);
         }
         for (int nt = w; nt < ntile; nt += nw) {
-            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const int f = (16 / TT) * nt + (l15 / TT), tt = l15 % TT;
             const bool valid = f < F && t0 + tt < T_;
             Frag<T> xcur[(HH / 32)];
 #pragma unroll
@@ -119,7 +121,7 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ch = 4 * g4 + r;
-                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, silu_f(acc[r] + bs[ch]));
+                    store1(s + ((size_t)ch * TT + tt) * FK + f, silu_f(acc[r] + bs[ch]));
                 }
             }
         }
@@ -138,16 +140,16 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
         for (int ks = 0; ks < KSFM; ++ks) {
             if (ks < ksf) {
                 Frag<T> bq;
-                if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);
                 else frag_zero(bq);
                 acc = mma(a[ks], bq, acc);
             }
         }
-        if (l15 < FL_TT) {
+        if (l15 < TT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = mt * 16 + 4 * g4 + r;
-                if (k < F) store1(z + ((size_t)k * FL_TT + l15) * NSQ + ch, acc[r] + bfull[ch * F + k]);
+                if (k < F) store1(z + ((size_t)k * TT + l15) * NSQ + ch, acc[r] + bfull[ch * F + k]);
             }
         }
     }
@@ -159,9 +161,9 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
 #pragma unroll
         for (int mt = 0; mt < (HH / 16); ++mt) wfrag_load(a[mt], Wusq, mt, 1, 0);
         // the residual rows of the NEXT tile are requested before this tile's math (same pipeline as pass 1)
-        const int tcl3 = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        const int tcl3 = t0 + (l15 % TT) < T_ ? t0 + (l15 % TT) : T_ - 1;
         auto row_of_3 = [&](int nt) -> const T* {
-            const int f = 2 * nt + (l15 >> 3);
+            const int f = (16 / TT) * nt + (l15 / TT);
             return x + (((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl3) * HH;
         };
         RawC4<T> rnext[(HH / 16)];
@@ -170,7 +172,7 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
             for (int mt = 0; mt < (HH / 16); ++mt) rawc_load(rnext[mt], row_of_3(w) + 16 * mt + 4 * g4);
         }
         for (int nt = w; nt < ntile; nt += nw) {
-            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const int f = (16 / TT) * nt + (l15 / TT), tt = l15 % TT;
             const bool valid = f < F && t0 + tt < T_;
             RawC4<T> rcur[(HH / 16)];
 #pragma unroll
@@ -181,7 +183,7 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
                 for (int mt = 0; mt < (HH / 16); ++mt) rawc_load(rnext[mt], nx + 16 * mt + 4 * g4);
             }
             Frag<T> bq;
-            if (8 * g4 < NSQ && f < F) frag_load(bq, z + ((size_t)f * FL_TT + tt) * NSQ + 8 * g4);
+            if (8 * g4 < NSQ && f < F) frag_load(bq, z + ((size_t)f * TT + tt) * NSQ + 8 * g4);
             else frag_zero(bq);
             const size_t go = (((size_t)b * F + f) * T_ + t0 + tt) * HH;
 #pragma unroll
@@ -213,7 +215,7 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
 #define FL_FKP(F) (((F) + 3) & ~3)   // padded F stride of the global s / dz operands
 #define FL_WFR 15  // weight fragments staged in LDS by the backward kernel: Wusq 6 | WusqT 3 | WsqT 6
 
-template <class T, int KSFM>
+template <class T, int KSFM, int TT>
 // bf16 stream: <= 128 VGPRs (a few spilled registers) so that two workgroups share a CU: 4.72 -> 4.17 ms per step together with the LDS-resident
 // weight fragments and the LayerNorm affine sums moved out of the row loop; the software prefetch of the row loops (round 2: worth 10 % at one
 // workgroup per CU) costs more registers than it hides latency at two (4.57 with, 4.17 without)
@@ -227,24 +229,24 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
     const int F = c.F, T_ = c.T;
     const int mtf = cdiv(F, 16), ksf = cdiv(F, 32), FK = ksf * 32, FM = mtf * 16, FKP = FL_FKP(F);
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]   s, later dz
-    T* sp = s + FL_SQ * FL_TT * FK;                // [FM][TT][SQ]   s_pre
-    T* z = sp + FM * FL_TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
-    float* aff = reinterpret_cast<float*>(z + FM * FL_TT * FL_SQ);  // [SQ] squeeze bias gradient sums (fp32)
+    T* sp = s + FL_SQ * TT * FK;                // [FM][TT][SQ]   s_pre
+    T* z = sp + FM * TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
+    float* aff = reinterpret_cast<float*>(z + FM * TT * FL_SQ);  // [SQ] squeeze bias gradient sums (fp32)
     // the unsqueeze / squeeze weight fragments of the two row loops live in LDS, not in 60 registers per lane: with the LayerNorm affine
     // sums gone as well (below) the kernel fits 128 VGPRs and TWO workgroups share a CU — its row loops are bound by exposed latency
     T* wl = reinterpret_cast<T*>(aff + FL_SQ);                         // [FL_WFR][512]
-    const int ntt = cdiv(T_, FL_TT);
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * FL_TT;
+    const int ntt = cdiv(T_, TT);
+    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
-    const int ntile = cdiv(F, 2);
+    const int ntile = cdiv(F, 16 / TT);
     const float* lnw = lp.p[P_FULL_LN_W];
     const float* lnb = lp.p[P_FULL_LN_B];
     const float* bs = lp.p[P_SQ_B];
     const float* bfull = lp.p[P_FULL_B];
     const float* bu = lp.p[P_USQ_B];
 
-    for (int i = tid; i < FL_SQ * FL_TT * FK + 2 * FM * FL_TT * FL_SQ; i += nthr) store1(s + i, 0.f);
+    for (int i = tid; i < FL_SQ * TT * FK + 2 * FM * TT * FL_SQ; i += nthr) store1(s + i, 0.f);
     for (int i = tid; i < FL_SQ; i += nthr) aff[i] = 0.f;
     {
         constexpr int VPF = 512 * (int)sizeof(T) / 16;  // 16-byte pieces per fragment (64 bf16, 128 fp32)
@@ -264,11 +266,11 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
     auto copy_sq_image = [&](T* __restrict__ dst) {
         constexpr int VE = 8 / sizeof(T);  // elements per 8-byte piece
         const int vpr = FKP / VE;          // FKP is a multiple of 4
-        for (int i = tid; i < FL_SQ * FL_TT * vpr; i += nthr) {
-            const int rowi = i / vpr, v = i % vpr, ch = rowi / FL_TT, tt = rowi % FL_TT;
+        for (int i = tid; i < FL_SQ * TT * vpr; i += nthr) {
+            const int rowi = i / vpr, v = i % vpr, ch = rowi / TT, tt = rowi % TT;
             if (t0 + tt >= T_) continue;
             // (image columns F..FK are never written and hold the zero fill: the operand's padding columns F..FKP come out zero)
-            const u32x2 val = *reinterpret_cast<const u32x2*>(s + ((size_t)ch * FL_TT + tt) * FK + v * VE);
+            const u32x2 val = *reinterpret_cast<const u32x2*>(s + ((size_t)ch * TT + tt) * FK + v * VE);
             *reinterpret_cast<u32x2*>(dst + (((size_t)b * T_ + t0 + tt) * FL_SQ + ch) * FKP + v * VE) = val;
         }
     };
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
         float gam[BK_KS][8], bet[BK_KS][8];
         load_ln_affine(lnw, lnb, gam, bet);
         for (int nt = w; nt < ntile; nt += nw) {
-            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const int f = (16 / TT) * nt + (l15 / TT), tt = l15 % TT;
             const bool valid = f < F && t0 + tt < T_;
             Frag<T> u[BK_KS];
             ln_strip96<T>(x + (((size_t)b * F + f) * T_ + t0 + tt) * FL_H, valid, gam, bet, u);
@@ -295,9 +297,9 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
                     const int ch = 4 * g4 + r;
                     pre[r] = acc[r] + bs[ch];
                     const float sv = silu_f(pre[r]);
-                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, sv);  // (the global copy for wgrad leaves from this image: copy_sq_image)
+                    store1(s + ((size_t)ch * TT + tt) * FK + f, sv);  // (the global copy for wgrad leaves from this image: copy_sq_image)
                 }
-                store4(sp + ((size_t)f * FL_TT + tt) * FL_SQ + 4 * g4, pre[0], pre[1], pre[2], pre[3]);
+                store4(sp + ((size_t)f * TT + tt) * FL_SQ + 4 * g4, pre[0], pre[1], pre[2], pre[3]);
             }
         }
     }
@@ -318,16 +320,16 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
         for (int ks = 0; ks < KSFM; ++ks) {
             if (ks < ksf) {
                 Frag<T> bq;
-                if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);
                 else frag_zero(bq);
                 acc = mma(a[ks], bq, acc);
             }
         }
-        if (l15 < FL_TT) {
+        if (l15 < TT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = mt * 16 + 4 * g4 + r;
-                if (k < F) store1(z + ((size_t)k * FL_TT + l15) * FL_SQ + ch, acc[r] + bfull[ch * F + k]);
+                if (k < F) store1(z + ((size_t)k * TT + l15) * FL_SQ + ch, acc[r] + bfull[ch * F + k]);
             }
         }
     }
@@ -339,16 +341,16 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
     {
         const T* wa = wl + (size_t)lane * 8;  // fragment fr of the window: wa + fr * 512
         // software pipeline: the dy pieces of the wave's NEXT row tile are requested before this tile's math (clamped addresses)
-        const int tcl = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        const int tcl = t0 + (l15 % TT) < T_ ? t0 + (l15 % TT) : T_ - 1;
         auto row_of = [&](int nt) -> size_t {
-            const int f = 2 * nt + (l15 >> 3);
+            const int f = (16 / TT) * nt + (l15 / TT);
             return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
         };
         constexpr bool PF = false;  // (see the note at the kernel's launch bounds)
         RawC4<T> dnext[BK_MT];
         if (PF && w < ntile) rawc_load_row<T>(dnext, dy + row_of(w) * FL_H);
         for (int nt = w; nt < ntile; nt += nw) {
-            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const int f = (16 / TT) * nt + (l15 / TT), tt = l15 % TT;
             const bool valid = f < F && t0 + tt < T_;
             const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
             RawC4<T> dcur[BK_MT];
@@ -361,10 +363,10 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
             }
             Frag<T> bq;
             if (g4 == 0 && f < F) {
-                frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
+                frag_load(bq, z + ((size_t)f * TT + tt) * FL_SQ);
                 if (valid) {
                     float zv[8];
-                    load8(z + ((size_t)f * FL_TT + tt) * FL_SQ, zv);
+                    load8(z + ((size_t)f * TT + tt) * FL_SQ, zv);
                     store4(z_out + n * FL_SQ, zv[0], zv[1], zv[2], zv[3]);
                     store4(z_out + n * FL_SQ + 4, zv[4], zv[5], zv[6], zv[7]);
                 }
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ch = 4 * g4 + r;
-                    store1(s + ((size_t)ch * FL_TT + tt) * FK + f, dzt[r]);
+                    store1(s + ((size_t)ch * TT + tt) * FK + f, dzt[r]);
                 }
             }
         }
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
         for (int ks = 0; ks < KSFM; ++ks) {
             if (ks < ksf) {
                 Frag<T> bq;
-                if (l15 < FL_TT) frag_load(bq, s + ((size_t)ch * FL_TT + l15) * FK + ks * 32 + 8 * g4);
+                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);
                 else frag_zero(bq);
                 acc = mma(a[ks], bq, acc);
             }
@@ -426,15 +428,15 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
         // the squeeze BIAS gradient is summed here from the fp32 values: as a column sum of the bf16 ds_pre operand over all ~10^6 tokens
         // (wgrad.hip) its rounding noise was the worst parameter-gradient error of the whole network (9.6e-2 on layers.0.squeeze.0.bias)
         float dbs = 0.f;
-        if (l15 < FL_TT) {
+        if (l15 < TT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = mt * 16 + 4 * g4 + r;
                 if (h < F) {
-                    const float pre = load1(sp + ((size_t)h * FL_TT + l15) * FL_SQ + ch);
+                    const float pre = load1(sp + ((size_t)h * TT + l15) * FL_SQ + ch);
                     const float v = acc[r] * dsilu_f(pre);
                     dbs += v;
-                    store1(z + ((size_t)h * FL_TT + l15) * FL_SQ + ch, v);
+                    store1(z + ((size_t)h * TT + l15) * FL_SQ + ch, v);
                 }
             }
         }
@@ -450,9 +452,9 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
         const T* wa = wl + (size_t)(9 * 512) + (size_t)lane * 8;  // the six Ws^T fragments
         // (no LayerNorm affine sums here: dgamma / dbeta follow from the squeeze weight gradient itself, D = ds_pre^T xhat —
         //  dgamma[i] = sum_o Ws[o][i] D[o][i], dbeta[i] = sum_o Ws[o][i] dbs[o] — in full_sq_finalize_kernel; 48 accumulators per lane gone)
-        const int tcl = t0 + (l15 & 7) < T_ ? t0 + (l15 & 7) : T_ - 1;
+        const int tcl = t0 + (l15 % TT) < T_ ? t0 + (l15 % TT) : T_ - 1;
         auto row_of = [&](int nt) -> size_t {
-            const int f = 2 * nt + (l15 >> 3);
+            const int f = (16 / TT) * nt + (l15 / TT);
             return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
         };
         constexpr bool PF = false;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
             rawc_load_row<T>(dnext, dy + row_of(w) * FL_H);
         }
         for (int nt = w; nt < ntile; nt += nw) {
-            const int f = 2 * nt + (l15 >> 3), tt = l15 & 7;
+            const int f = (16 / TT) * nt + (l15 / TT), tt = l15 % TT;
             const bool valid = f < F && t0 + tt < T_;
             const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
             RawC4<T> xcur[BK_MT], dcur[BK_MT];
@@ -478,9 +480,9 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
             }
             Frag<T> bq;
             if (g4 == 0 && valid) {
-                frag_load(bq, z + ((size_t)f * FL_TT + tt) * FL_SQ);
+                frag_load(bq, z + ((size_t)f * TT + tt) * FL_SQ);
                 float dv[8];
-                load8(z + ((size_t)f * FL_TT + tt) * FL_SQ, dv);
+                load8(z + ((size_t)f * TT + tt) * FL_SQ, dv);
                 store4(dsp_out + n * FL_SQ, dv[0], dv[1], dv[2], dv[3]);
                 store4(dsp_out + n * FL_SQ + 4, dv[4], dv[5], dv[6], dv[7]);
             } else {
@@ -527,28 +529,62 @@ __global__ void full_sq_finalize_kernel(const float* __restrict__ tmp, const flo
     if (i < FL_SQ) dbs[i] += tmp[FL_SQ * FL_H + i];
 }
 
-template <class T, int KSFM>
-static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
-                      float* stats, void* const* o, hipStream_t st) {
+// frames per slab: the largest of 8 / 4 / 2 that still gives every CU a workgroup.  The LinearGroup passes cost the same per slab whatever its
+// width (their MFMA N dimension is 16 frames wide either way), the row passes scale with it: at batch 2 (64 slabs of 8 frames on 256 CUs) the
+// backward kernel took 158 us per launch, 4.8 x its share of the batch-32 launch
+static int full_tt(const nbss_cfg& c) {
+    static const int forced = [] { const char* e = getenv("NBSS_FULL_TT"); return e ? atoi(e) : 0; }();  // tuning / test knob: 8, 4 or 2
+    if (forced == 8 || forced == 4 || forced == 2) return forced;
+    for (int tt = FL_TT_MAX; tt > 2; tt >>= 1)
+        if (c.B * cdiv(c.T, tt) >= 256) return tt;
+    return 2;
+}
+
+// LDS of the backward kernel at slab width tt (PHASE_LDS_BYTES: the phase-timer build's counters)
+static size_t full_bwd_lds(const nbss_cfg& c, int tt) {
+    const size_t esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
+    return ((size_t)FL_SQ * tt * ksf * 32 + (size_t)2 * mtf * 16 * tt * FL_SQ + (size_t)FL_WFR * 512) * esz + FL_SQ * sizeof(float) + PHASE_LDS_BYTES;
+}
+// ... and the width the backward pass runs at: full_tt(), narrowed until the squeezed images fit (fp32 stream at F = 257: 213 KB at 8 frames, 136 KB at 4)
+static int full_bwd_width(const nbss_cfg& c) {
+    int tt = full_tt(c);
+    while (tt > 2 && full_bwd_lds(c, tt) > 160 * 1024) tt >>= 1;
+    return tt;
+}
+
+template <class T, int KSFM, int TT>
+static int full_bwd_tt(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                       float* stats, void* const* o, hipStream_t st) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)FL_SQ * FL_TT * ksf * 32 + (size_t)2 * mtf * 16 * FL_TT * FL_SQ + (size_t)FL_WFR * 512) * sizeof(T) + FL_SQ * sizeof(float) + PHASE_LDS_BYTES;
+    const size_t lds = full_bwd_lds(c, TT);
     const T* pk = (const T*)packed;
-    if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (fp32 stream at F = 257: 213 KB of squeezed images)
-    int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T, KSFM>), lds);
+    if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e = NBSS_SET_MAX_LDS((full_bwd_kernel<T, KSFM, TT>), lds);
     if (e) return e;
-    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
+    dim3 grid(c.B * cdiv(c.T, TT)), block(FL_THREADS);
     ProfScope ps(PK_FULL_B, st);
-    NBSS_LAUNCH((full_bwd_kernel<T, KSFM>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
+    NBSS_LAUNCH((full_bwd_kernel<T, KSFM, TT>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
                 pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
                 (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4]);
     return NBSS_CHECK_LAUNCH();
 }
 
+template <class T, int KSFM>
+static int full_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
+                      float* stats, void* const* o, hipStream_t st) {
+    switch (full_bwd_width(c)) {
+        case 8: return full_bwd_tt<T, KSFM, 8>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
+        case 4: return full_bwd_tt<T, KSFM, 4>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
+        default: return full_bwd_tt<T, KSFM, 2>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
+    }
+}
+
 int memset_async_impl(void* p, size_t bytes, hipStream_t st);
 
 int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx, void* ws,
-                  hipStream_t st) {
+                  hipStream_t st, const Side* sd) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats | s [B*T][SQ][FKP] | dz [B*T][SQ][FKP] | z [N][SQ] | dy_pre [N][H] | ds_pre [N][SQ]
     const size_t N = (size_t)c.B * c.F * c.T, BT = (size_t)c.B * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
@@ -565,9 +601,8 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     int e;
     float* part = (float*)((char*)ws + ws_part_offset(c));
     // tmp (behind the per-workgroup partial rows): D [SQ][H] = ds_pre^T xhat | dbs [SQ] | ones [H] | zeros [H]
-    float* sqtmp = part + (size_t)c.B * cdiv(c.T, FL_TT) * FL_SQ + 64;
-    NBSS_LAUNCH(full_sq_prep_kernel, dim3(1), dim3(256), 0, st, sqtmp);
-    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    const int nslab = c.B * cdiv(c.T, full_bwd_width(c));
+    float* sqtmp = part + (size_t)nslab * FL_SQ + 64;
     if (c.F > 32 * FL_KSF_MAX)
         e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
                                  : full_bwd_t<float, FL_KSF_BIG>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
@@ -575,11 +610,15 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
         e = c.dtype == NBSS_BF16 ? full_bwd_t<bf16_t, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st)
                                  : full_bwd_t<float, FL_KSF_MAX>(c, P, part, packed, layer, x, dy, dx, stats, o, st);
     if (e) return e;
+    // everything below only produces parameter gradients: gradient stream (side.h)
+    const hipStream_t gs = side_fork(sd, st);
+    NBSS_LAUNCH(full_sq_prep_kernel, dim3(1), dim3(256), 0, gs, sqtmp);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
     // squeeze bias gradient (fp32 sums of the kernel) -> tmp.dbs
     AffSegs sg;
     sg.n = 1;
     sg.off[0] = FL_SQ * FL_H; sg.cnt[0] = FL_SQ;
-    if ((e = affine_reduce_launch(part, c.B * cdiv(c.T, FL_TT), sg, sqtmp, st))) return e;
+    if ((e = affine_reduce_launch(part, nslab, sg, sqtmp, gs))) return e;
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
@@ -589,12 +628,12 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.Ntok = (int)N; a.groups = 1;
     a.A = o[3]; a.lda = FL_H; a.MA = FL_H; a.B = o[2]; a.ldb = FL_SQ; a.NB = FL_SQ;
     a.dW = G + param_off(c, layer, P_USQ_W); a.dbias = G + param_off(c, layer, P_USQ_B);
-    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
     // LinearGroup: dWf[c][k][h] = sum_{b,t} dz[b,t,c,k] s[b,t,c,h] ; dbf = colsum(dz)   (rows = (b,t))
     a.Ntok = (int)BT; a.groups = FL_SQ; a.mvalid = c.F; a.nvalid = c.F;
     a.A = o[1]; a.lda = FL_SQ * FKP; a.MA = FL_SQ * FKP; a.B = o[0]; a.ldb = FL_SQ * FKP; a.NB = FL_SQ * FKP;
     a.dW = G + param_off(c, layer, P_FULL_W); a.dbias = G + param_off(c, layer, P_FULL_B);
-    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
     // squeeze: dWs[SQ][H] = ds_pre^T LN(x) ; dbs = colsum(ds_pre)
     a.Ntok = (int)N; a.groups = 1; a.mvalid = 0; a.nvalid = 0;
     a.A = o[4]; a.lda = FL_SQ; a.MA = FL_SQ; a.B = x; a.ldb = FL_H; a.NB = FL_H;
@@ -603,27 +642,36 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     // dWs = D gamma + dbs (x) beta, dbs, and the LayerNorm affine gradients
     a.gamma = sqtmp + FL_SQ * FL_H + FL_SQ; a.beta = sqtmp + FL_SQ * FL_H + FL_SQ + FL_H;
     a.dW = sqtmp; a.dbias = nullptr;
-    if ((e = wgrad_launch(a, c.dtype, st))) return e;
-    NBSS_LAUNCH(full_sq_finalize_kernel, dim3(1), dim3(FL_H), 0, st, (const float*)sqtmp, lp.p[P_SQ_W], lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
+    NBSS_LAUNCH(full_sq_finalize_kernel, dim3(1), dim3(FL_H), 0, gs, (const float*)sqtmp, lp.p[P_SQ_W], lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 G + param_off(c, layer, P_SQ_W), G + param_off(c, layer, P_SQ_B), G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B));
+    return NBSS_CHECK_LAUNCH();
+}
+
+template <class T, int KSFM, class G, int TT>
+static int full_fwd_tt(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
+    const size_t lds = ((size_t)G::SQ * TT * ksf * 32 + (size_t)mtf * 16 * TT * G::SQ) * sizeof(T);
+    const T* pk = (const T*)packed;
+    if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T, KSFM, G::H, G::SQ, TT>), lds);
+    if (e) return e;
+    dim3 grid(c.B * cdiv(c.T, TT)), block(FL_THREADS);
+    ProfScope ps(PK_FULL_F, st);
+    NBSS_LAUNCH((full_fwd_kernel<T, KSFM, G::H, G::SQ, TT>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+                lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
+                pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);
     return NBSS_CHECK_LAUNCH();
 }
 
 template <class T, int KSFM, class G>
 static int full_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st) {
-    const LayerPtrs lp = layer_ptrs(c, P, layer);
-    const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    const size_t lds = ((size_t)G::SQ * FL_TT * ksf * 32 + (size_t)mtf * 16 * FL_TT * G::SQ) * sizeof(T);
-    const T* pk = (const T*)packed;
-    if (ksf > KSFM || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
-    int e = NBSS_SET_MAX_LDS((full_fwd_kernel<T, KSFM, G::H, G::SQ>), lds);
-    if (e) return e;
-    dim3 grid(c.B * cdiv(c.T, FL_TT)), block(FL_THREADS);
-    ProfScope ps(PK_FULL_F, st);
-    NBSS_LAUNCH((full_fwd_kernel<T, KSFM, G::H, G::SQ>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
-                lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
-                pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);
-    return NBSS_CHECK_LAUNCH();
+    switch (full_tt(c)) {
+        case 8: return full_fwd_tt<T, KSFM, G, 8>(c, P, packed, layer, x, y, st);
+        case 4: return full_fwd_tt<T, KSFM, G, 4>(c, P, packed, layer, x, y, st);
+        default: return full_fwd_tt<T, KSFM, G, 2>(c, P, packed, layer, x, y, st);
+    }
 }
 
 template <class G>

@@ -19,6 +19,7 @@
 #include "layout.h"
 #include "prof.h"
 #include "geom.h"
+#include "side.h"
 
 #define MH_H 96
 #define MH_HEADS 4
@@ -74,7 +75,7 @@ template <class T, int HPP, bool FULL, int NSW>
 __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
-                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave, float* __restrict__ lse) {
+                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave, float* __restrict__ lse, int bf0) {
     NBSS_LDS(smem);
     T* Ks = reinterpret_cast<T*>(smem);              // [HPP][TP][DH]
     T* Vt = Ks + HPP * MH_TP * MH_DH;                // [HPP][DH][TP]
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
     T* wl = Vt + HPP * MH_TP * MH_DH + 32;           // [48][512]
     float* prm = reinterpret_cast<float*>(wl + (WLDS ? 48 * 512 : 0));  // [3H in_proj bias | H out_proj bias | 2H LN gamma, beta]
     const int T_ = c.T, nst = FULL ? MH_NT : cdiv(T_, 16);
-    const int bf = blockIdx.x;
+    const int bf = blockIdx.x + bf0;  // (bf0: first sequence of this launch — the walk's tail launch, side.h: SeqTail)
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const T* xb = x + (size_t)bf * T_ * MH_H;
     T* yb = y + (size_t)bf * T_ * MH_H;
@@ -336,18 +337,25 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
 }
 
 template <class T, int HPP, bool FULL, int NSW>
-static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
+static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st, const SeqTail* tl) {
     if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
     // +64: the last transposing read overreaches its row by 16 B; bf16: 48-fragment weight window + biases
     const size_t lds = (size_t)2 * HPP * MH_TP * MH_DH * sizeof(T) + 64 + (sizeof(T) == 2 && HPP == MH_HEADS ? (size_t)48 * 512 * sizeof(T) + 4 * MH_H * sizeof(float) : 0);
     const T* pk = (const T*)packed;
     int e = NBSS_SET_MAX_LDS((mhsa_fwd_kernel<T, HPP, FULL, NSW>), lds);
     if (e) return e;
-    dim3 grid(c.B * c.F), block(64 * 16 / NSW);
+    const int nseq = c.B * c.F, ntail = tl ? tl->n : 0;
+    dim3 grid(nseq - ntail), block(64 * 16 / NSW);
     ProfScope ps(PK_MHSA_F, st);
+    float* lse = osave ? (float*)((char*)osave + mhsa_lse_offset(c)) : nullptr;
     NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL, NSW>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
-                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, osave ? (float*)((char*)osave + mhsa_lse_offset(c)) : nullptr);
+                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, lse, 0);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if (ntail > 0)  // the last, nearly empty round of sequences: on the walk's second stream, overlapping the next row kernel's full rounds
+        NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL, NSW>), dim3(ntail), block, lds, tl->ts, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
+                    P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
+                    pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, lse, nseq - ntail);
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -667,11 +675,11 @@ static int mhsa_fwd_long_t(const nbss_cfg& c, const float* P, const void* packed
     return NBSS_CHECK_LAUNCH();
 }
 
-int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st) {
+int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* osave, hipStream_t st, const SeqTail* tl) {
     // SpatialNet-large (forward only): always the two-launch path; `osave` is its K | V scratch
     if (c.H == GeoL::H) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t, GeoL, 128>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float, GeoL, 64>(c, P, packed, layer, x, y, osave, st);
     // T > 256: `osave` is the K | V scratch of the two-launch long-sequence path (nothing is saved for backward)
     if (c.T > MH_TP) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t, GeoS, 128>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float, GeoS, 128>(c, P, packed, layer, x, y, osave, st);
-    if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false, 2>(c, P, packed, layer, x, y, osave, st);
-    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_t<bf16_t, 4, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st);
+    if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false, 2>(c, P, packed, layer, x, y, osave, st, nullptr);
+    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st, tl) : mhsa_fwd_t<bf16_t, 4, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st, tl);
 }

@@ -16,6 +16,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "side.h"
 #include <cstdlib>
 
 #define MB_H 96
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(MB_NTHR) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs
 PHASE_READER(nbss_phase_read_mhsa_bwd)
 
 int tailw_mhsa(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
-               const void* dqkv, float* wgpart, float* G, hipStream_t st);
+               const void* dqkv, float* wgpart, float* G, hipStream_t st, const Side* sd, hipStream_t* gs);
 
 template <class T, bool FULL, bool XT>
 static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void* packed, int layer, const void* x, const void* dy, const void* osave,
@@ -629,7 +630,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
 }
 
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
-                  void* dx, void* ws, hipStream_t st) {
+                  void* dx, void* ws, hipStream_t st, const Side* sd) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const size_t N = (size_t)c.B * c.F * c.T;
     float* stats = (float*)ws;
@@ -642,6 +643,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     const bool xt = c.dtype == NBSS_BF16;  // tail + in_proj weight gradient in tailw.hip
 #endif
     int e;
+    hipStream_t gs = st;  // parameter-gradient launches (side.h)
     {
     ProfScope ps(PK_MHSA_B, st);  // ONE profiler interval per nbss_mhsa_bwd call: data-gradient kernel (+ fused tail / in_proj wgrad kernel)
     e = c.dtype != NBSS_BF16 ? mhsa_bwd_t<float, false, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
@@ -650,14 +652,15 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
             : full ? mhsa_bwd_t<bf16_t, true, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
                    : mhsa_bwd_t<bf16_t, false, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st);
     if (e) return e;
-    if (xt && (e = tailw_mhsa(c, lp, packed, layer, x, dy, dx, stats, dqkv, (float*)((char*)ws + ws_wgpart_offset(c)), G, st))) return e;
+    if (xt && (e = tailw_mhsa(c, lp, packed, layer, x, dy, dx, stats, dqkv, (float*)((char*)ws + ws_wgpart_offset(c)), G, st, sd, &gs))) return e;
     }
+    if (!xt) gs = side_fork(sd, st);
     if (!xt) {
         AffSegs sg;
         sg.n = 2;
         sg.off[0] = param_off(c, layer, P_MH_LN_W); sg.cnt[0] = MB_H;
         sg.off[1] = param_off(c, layer, P_MH_LN_B); sg.cnt[1] = MB_H;
-        if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
+        if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, gs))) return e;
     }
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));
@@ -667,12 +670,12 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.A = dy; a.lda = MB_H; a.MA = MB_H; a.B = osave; a.ldb = MB_H; a.NB = MB_H;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     a.dW = G + param_off(c, layer, P_OUTP_W); a.dbias = G + param_off(c, layer, P_OUTP_B);
-    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
     if (xt) return NBSS_OK;
     // in_proj: dWin[3H][H] = dqkv^T LN(x) ; dbin = colsum(dqkv)
     a.A = dqkv; a.lda = 3 * MB_H; a.MA = 3 * MB_H; a.B = x; a.ldb = MB_H; a.NB = MB_H;
     if (c.dtype == NBSS_BF16) { a.a_gw = MB_DH; a.a_gs = (int)(N * MB_DH); }  // group-major dqkv
     a.stats = stats; a.gamma = lp.p[P_MH_LN_W]; a.beta = lp.p[P_MH_LN_B];
     a.dW = G + param_off(c, layer, P_INP_W); a.dbias = G + param_off(c, layer, P_INP_B);
-    return wgrad_launch(a, c.dtype, st);
+    return wgrad_launch(a, c.dtype, gs);
 }

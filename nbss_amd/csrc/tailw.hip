@@ -20,6 +20,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "side.h"
 
 #define TW_KC 64
 #define TW_H 96
@@ -264,8 +265,9 @@ static int tailw_go(const TailArgs& t, int grid, hipStream_t st) {
 }
 
 // MA = 192 (T-ConvFFN W1) or 288 (attention in_proj).  W: fp32 master weight [MA][96]; the gradients accumulate into dW / dbias / dgamma / dbeta
+// The finalize pass only produces parameter gradients: it goes to the gradient stream (side.h), which is handed back in *gs for the caller's own folds.
 int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes, const float* W, float* dW, float* dbias, float* dgamma, float* dbeta,
-                 hipStream_t st) {
+                 hipStream_t st, const Side* sd, hipStream_t* gs_out) {
     TailArgs t = t0;
     const int nchunks = cdiv(t.Ntok, TW_KC);
     const int grid = nchunks < 256 ? nchunks : 256;
@@ -280,14 +282,16 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
 #endif
             : NBSS_EUNSUPPORTED;
     if (e) return e;
-    NBSS_LAUNCH(tailw_finalize_kernel, dim3(ntot, grid < TW_RSL ? grid : TW_RSL), dim3(256), 2 * 4 * 16 * sizeof(float), st, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias,
+    const hipStream_t gs = side_fork(sd, st);
+    if (gs_out) *gs_out = gs;
+    NBSS_LAUNCH(tailw_finalize_kernel, dim3(ntot, grid < TW_RSL ? grid : TW_RSL), dim3(256), 2 * 4 * 16 * sizeof(float), gs, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias,
                 dgamma, dbeta);
     return NBSS_CHECK_LAUNCH();
 }
 
 // T-ConvFFN: da1 (FFN = 192), W1^T fragments K_TF_W1_TN, LayerNorm P_TF_LN_*; dW1 / db1 / LN-affine gradients into G
 int tailw_tconvffn(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
-                   const void* da1, float* wgpart, float* G, const float* P, hipStream_t st) {
+                   const void* da1, float* wgpart, float* G, const float* P, hipStream_t st, const Side* sd, hipStream_t* gs) {
     (void)P;
     TailArgs t;
     t.A = (const bf16_t*)da1; t.x = (const bf16_t*)x; t.dy = (const bf16_t*)dy; t.dx = (bf16_t*)dx; t.stats = stats;
@@ -296,12 +300,12 @@ int tailw_tconvffn(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, i
     t.part = nullptr;
     t.Ntok = c.B * c.F * c.T;
     return tailw_launch(192, t, wgpart, WGPART_BYTES, lp.p[P_TF_W1], G + param_off(c, layer, P_TF_W1), G + param_off(c, layer, P_TF_B1),
-                        G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), st);
+                        G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), st, sd, gs);
 }
 
 // attention: dqkv (3H = 288), in_proj^T fragments K_INP_TN, LayerNorm P_MH_LN_*
 int tailw_mhsa(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
-               const void* dqkv, float* wgpart, float* G, hipStream_t st) {
+               const void* dqkv, float* wgpart, float* G, hipStream_t st, const Side* sd, hipStream_t* gs) {
     TailArgs t;
     t.A = (const bf16_t*)dqkv; t.x = (const bf16_t*)x; t.dy = (const bf16_t*)dy; t.dx = (bf16_t*)dx; t.stats = stats;
     t.gamma = lp.p[P_MH_LN_W]; t.beta = lp.p[P_MH_LN_B];
@@ -309,5 +313,5 @@ int tailw_mhsa(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int l
     t.part = nullptr;
     t.Ntok = c.B * c.F * c.T;
     return tailw_launch(288, t, wgpart, WGPART_BYTES, lp.p[P_INP_W], G + param_off(c, layer, P_INP_W), G + param_off(c, layer, P_INP_B),
-                        G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B), st);
+                        G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B), st, sd, gs);
 }

@@ -15,6 +15,7 @@
 #include "prof.h"
 #include "wgrad.h"
 #include "blocks.h"
+#include "side.h"
 
 #define TF_H 96
 #define TF_FFN 192
@@ -1062,7 +1063,7 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
                           void* const* opsv, float* stats, int pstride, hipStream_t st);
 struct TailArgs;
 int tailw_tconvffn(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
-                   const void* da1, float* wgpart, float* G, const float* P, hipStream_t st);
+                   const void* da1, float* wgpart, float* G, const float* P, hipStream_t st, const Side* sd, hipStream_t* gs);
 
 // the tail (du, LayerNorm backward, dx) runs inside the W1 weight-gradient kernel (tailw.hip) unless built with -DNBSS_NO_TAILW (A/B flavour)
 #ifdef NBSS_NO_TAILW
@@ -1073,13 +1074,13 @@ int tailw_tconvffn(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, i
 
 // bf16 stream: data-gradient kernel of tconvffn_s.hip + the tail (same operand tensors, same `part` rows as the group-serial kernel)
 static int tconvffn_bwd_bf16(const nbss_cfg& c, const float* P, float* G, float* part, const void* packed, int layer, const void* x, const void* dy, void* dx,
-                             float* stats, void* const* opsv, float* wgpart, hipStream_t st) {
+                             float* stats, void* const* opsv, float* wgpart, hipStream_t st, const Side* sd, hipStream_t* gs) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
     if (TF_FUSED_TAIL) {
         int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, stats, 2 * TF_FFN, st);
         if (e) return e;
-        return tailw_tconvffn(c, lp, packed, layer, x, dy, dx, stats, opsv[4], wgpart, G, P, st);
+        return tailw_tconvffn(c, lp, packed, layer, x, dy, dx, stats, opsv[4], wgpart, G, P, st, sd, gs);
     }
     int e = tconvffn_bwd_s_launch(c, lp, part, packed, layer, x, dy, opsv, nullptr, TF_AFF, st);
     if (e) return e;
@@ -1119,7 +1120,7 @@ int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, fl
 // bf16 stream, from the pre-activations a training-mode forward saved (tconvffn_s.hip): data gradient + the three T-conv weight gradients in
 // one kernel, the tail + W1 weight gradient in tailw.hip, one fold of the per-sequence partial rows, the W2 weight gradient through wgrad.hip
 static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* tsave,
-                              void* dx, void* ws, hipStream_t st) {
+                              void* dx, void* ws, hipStream_t st, const Side* sd) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const size_t N = (size_t)c.B * c.F * c.T;
     char* base = (char*)ws + ws_align(N * 2 * sizeof(float));
@@ -1128,10 +1129,11 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     float* part = (float*)((char*)ws + ws_tcpart_offset(c));
     float* wgpart = (float*)((char*)ws + ws_wgpart_offset(c));
     int e;
+    hipStream_t gs = st;  // parameter-gradient launches (side.h): everything behind the tail kernel
     {
         ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
         if ((e = tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_h5, op_da1, st))) return e;
-        if ((e = tailw_tconvffn(c, lp, packed, layer, x, dy, dx, tconvffn_save_ln_stats(c, tsave), op_da1, wgpart, G, P, st))) return e;
+        if ((e = tailw_tconvffn(c, lp, packed, layer, x, dy, dx, tconvffn_save_ln_stats(c, tsave), op_da1, wgpart, G, P, st, sd, &gs))) return e;
     }
     const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convBias[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
     AffSegs sg;  // fp32 rows: GroupNorm affine sums + the three conv bias sums
@@ -1139,10 +1141,10 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
     sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
     for (int k = 0; k < 3; ++k) { sg.off[2 + k] = param_off(c, layer, convBias[k]); sg.cnt[2 + k] = TF_FFN; }
-    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
+    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, gs))) return e;
     const long long woffs[3] = {param_off(c, layer, convW[0]), param_off(c, layer, convW[1]), param_off(c, layer, convW[2])};
     // (the slice sums of the fold live in the wgrad partial-tile region, idle between this sub-block's wgrad launches: 64 x 41 472 floats = 10.6 MB)
-    if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN), wgpart, G, woffs, st))) return e;
+    if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN), wgpart, G, woffs, gs))) return e;
     // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
     WgradArgs a;
     a.part = wgpart;
@@ -1152,12 +1154,12 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = op_h5; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
     a.b_gw = TF_CG; a.b_gs = (int)(N * TF_CG);
     a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
-    return wgrad_launch(a, c.dtype, st);
+    return wgrad_launch(a, c.dtype, gs);
 }
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,
-                      void* dx, void* ws, hipStream_t st) {
-    if (tsave && c.dtype == NBSS_BF16) return tconvffn_bwd_saved(c, P, G, packed, layer, x, dy, const_cast<void*>(tsave), dx, ws, st);
+                      void* dx, void* ws, hipStream_t st, const Side* sd) {
+    if (tsave && c.dtype == NBSS_BF16) return tconvffn_bwd_saved(c, P, G, packed, layer, x, dy, const_cast<void*>(tsave), dx, ws, st, sd);
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats [N][2] f32 | h1 h2 h4 h5 da1 da2 da3 da5, each [N][FFN] of the stream dtype
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
@@ -1168,16 +1170,18 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     float* part = (float*)((char*)ws + ws_part_offset(c));
     float* wgpart = (float*)((char*)ws + ws_wgpart_offset(c));
     const bool fused = c.dtype == NBSS_BF16 && TF_FUSED_TAIL;  // the tail kernel contracted dW1 / db1 and reduced the LayerNorm affine sums
-    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_bf16(c, P, G, part, packed, layer, x, dy, dx, stats, ops, wgpart, st)
+    hipStream_t gs = st;  // parameter-gradient launches (side.h)
+    int e = c.dtype == NBSS_BF16 ? tconvffn_bwd_bf16(c, P, G, part, packed, layer, x, dy, dx, stats, ops, wgpart, st, sd, &gs)
                                  : tconvffn_bwd_t<float>(c, P, part, packed, layer, x, dy, dx, stats, ops, st);
     if (e) return e;
+    if (gs == st) gs = side_fork(sd, st);
     AffSegs sg;
     sg.n = fused ? 2 : 4;
     sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
     sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
     sg.off[2] = param_off(c, layer, P_TF_LN_W); sg.cnt[2] = TF_H;
     sg.off[3] = param_off(c, layer, P_TF_LN_B); sg.cnt[3] = TF_H;
-    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, st))) return e;
+    if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, gs))) return e;
     WgradArgs a;
     a.part = wgpart;
     a.mvalid = 0; a.nvalid = 0;
@@ -1189,7 +1193,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = ops[3]; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
     a.b_gw = ogw; a.b_gs = ogs;
     a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
-    if ((e = wgrad_launch(a, c.dtype, st))) return e;
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
     // the three grouped k=3 convs
     const int convA[3] = {5, 6, 7}, convB[3] = {0, 1, 2};
     const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convBias[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
@@ -1198,7 +1202,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
         a.groups = c.t_groups; a.taps = c.t_ks;
         a.a_gw = ogw; a.a_gs = ogs; a.b_gw = ogw; a.b_gs = ogs;
         a.dW = G + param_off(c, layer, convW[k]); a.dbias = G + param_off(c, layer, convBias[k]);
-        if ((e = wgrad_launch(a, c.dtype, st))) return e;
+        if ((e = wgrad_launch(a, c.dtype, gs))) return e;
     }
     if (fused) return NBSS_OK;
     // W1: dW1[FFN][H] = da1^T LN(x) ; db1 = colsum(da1)
@@ -1206,7 +1210,7 @@ int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* p
     a.a_gw = ogw; a.a_gs = ogs; a.b_gw = 0; a.b_gs = 0;
     a.stats = stats; a.gamma = lp.p[P_TF_LN_W]; a.beta = lp.p[P_TF_LN_B];
     a.dW = G + param_off(c, layer, P_TF_W1); a.dbias = G + param_off(c, layer, P_TF_B1);
-    return wgrad_launch(a, c.dtype, st);
+    return wgrad_launch(a, c.dtype, gs);
 }
 
 template <class T, int NSW, bool LONG>
@@ -1222,15 +1226,15 @@ static int tconvffn_fwd_t(const nbss_cfg& c, const float* P, const void* packed,
     return NBSS_CHECK_LAUNCH();
 }
 
-int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st);
+int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st, const SeqTail* tl);
 
 int tconvffn_fwd_large_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, hipStream_t st);
 
 // tsave (optional; bf16 stream, T <= 256, small geometry — tconvffn_save_bytes() > 0): the training-mode forward keeps its pre-activations there
-int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st) {
+int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st, const SeqTail* tl) {
     if (c.H != TF_H) return tconvffn_fwd_large_impl(c, P, packed, layer, x, y, st);  // SpatialNet-large, forward only (tconvffn_g.hip)
     // bf16 stream: the streaming wave-per-group kernel (tconvffn_s.hip); fp32 stream: the group-serial kernel above
     // sequences beyond 256 frames (forward only): the chunked two-pass variant of the group-serial kernel
     if (c.T > TF_TP) return c.dtype == NBSS_BF16 ? tconvffn_fwd_t<bf16_t, 1, true>(c, P, packed, layer, x, y, st) : tconvffn_fwd_t<float, 2, true>(c, P, packed, layer, x, y, st);
-    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, tsave, st) : tconvffn_fwd_t<float, 2, false>(c, P, packed, layer, x, y, st);
+    return c.dtype == NBSS_BF16 ? tconvffn_fwd_s_impl(c, P, packed, layer, x, y, tsave, st, tl) : tconvffn_fwd_t<float, 2, false>(c, P, packed, layer, x, y, st);
 }

@@ -14,6 +14,7 @@
 // (rows (r&3) + 8(r>>2) + 4(lane>>5), r < 12) of frame lane&31, i.e. three 8-byte pieces of an image row.  Biases ride in spare
 // K slots of the packed weights (layout.h: ts_conv_k) against a constant-1 slot of the B operand.
 // The fp32 stream keeps the group-serial kernels of tconvffn.hip.
+#include "side.h"
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"
@@ -168,7 +169,7 @@ struct TsSave {
 // SAVE: training-mode forward (sv is filled); inference launches the SAVE = false instance (no stores, no extra packing)
 template <bool SAVE>
 __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPtrs lp, TsFwdW W, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                             TsSave sv) {
+                                                             TsSave sv, int bf0) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32;
     bf16_t* img = reinterpret_cast<bf16_t*>(smem);  // [NT + TS_PAD][TS_RS]
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
     load_wfrags<5>(wc3, W.C3, w, L.lane);
     // One workgroup per sequence.  (A persistent grid of 256 workgroups looping over sequences was measured SLOWER, 675 vs 524 us
     // per launch at batch 31: all CUs then march through the HBM-latency and the VALU-bound phases in lock step.)
-    const int bf = blockIdx.x;
+    const int bf = blockIdx.x + bf0;  // (bf0: first sequence of this launch — side.h: SeqTail)
     const size_t n0 = (size_t)bf * T_, ntok = (size_t)c.B * c.F * T_;
     {
     const bf16_t* xb = x + (size_t)bf * T_ * TS_H;
@@ -486,7 +487,7 @@ TsSave ts_save_ptrs(const nbss_cfg& c, void* tsave) {
 }
 
 // bf16 stream only; returns NBSS_EUNSUPPORTED when the sequence does not fit the LDS image.  tsave != nullptr: training-mode forward
-int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st) {
+int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st, const SeqTail* tl) {
     if (c.dtype != NBSS_BF16) return NBSS_EUNSUPPORTED;
     const size_t lds = tconvffn_s_fwd_lds(c.T);
     if (lds > 160 * 1024 || c.T > 256) return NBSS_EUNSUPPORTED;
@@ -494,17 +495,23 @@ int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, i
     const bf16_t* pk = (const bf16_t*)packed;
     TsFwdW W = {pk + pack_off(c, layer, K_TS_W1), pk + pack_off(c, layer, K_TS_C1), pk + pack_off(c, layer, K_TS_C2), pk + pack_off(c, layer, K_TS_C3),
                 pk + pack_off(c, layer, K_TS_W2)};
-    dim3 grid(c.B * c.F), block(512);
+    const int nseq = c.B * c.F, ntail = tl ? tl->n : 0;  // (tail launch: see mhsa_fwd_t)
+    dim3 grid(nseq - ntail), block(512);
     ProfScope ps(PK_TCF_F, st);
     int e;
     if (tsave) {
         if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<true>, lds))) return e;
-        NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave));
+        NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave), 0);
+        if (ntail > 0 && !(e = NBSS_CHECK_LAUNCH()))
+            NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, dim3(ntail), block, lds, tl->ts, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave), nseq - ntail);
     } else {
         TsSave none = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<false>, lds))) return e;
-        NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none);
+        NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none, 0);
+        if (ntail > 0 && !(e = NBSS_CHECK_LAUNCH()))
+            NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, dim3(ntail), block, lds, tl->ts, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none, nseq - ntail);
     }
+    if (e) return e;
     return NBSS_CHECK_LAUNCH();
 }
 

@@ -74,7 +74,10 @@ class SpatialNetEngine:
                             "sequence per workgroup in LDS — cut training segments to <= 256 frames (the reference trains on 4 s = 251)")
         key = (B, T, dtype, train)
         if self._geom != key:
-            self.ws = ops.scratch(self.lib.nbss_train_ws_bytes(C.byref(cfg)), self.device)
+            # (inference: one workspace + the two ping-pong stream buffers behind it; training: the backward walk's per-sub-block copies)
+            esz = 2 if dtype == NBSS_BF16 else 4
+            infer = self.lib.nbss_workspace_bytes(C.byref(cfg)) + 2 * ((B * cfg.F * T * cfg.H * esz + 255) // 256 * 256)
+            self.ws = ops.scratch(self.lib.nbss_train_ws_bytes(C.byref(cfg)) if train else infer, self.device)
             self.acts = ops.scratch(self.lib.nbss_acts_bytes(C.byref(cfg)), self.device) if train else None
             self._geom = key
         return cfg
