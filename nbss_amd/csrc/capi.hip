@@ -279,7 +279,10 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
 #endif
     {
         const int nseq = c.B * c.F, rem = ncu > 0 ? nseq % ncu : 0;
-        if (c.dtype == NBSS_BF16 && c.H == 96 && c.T <= NBSS_T_TRAIN_MAX && nseq > ncu && rem > 0 && 2 * rem <= ncu) tl.n = rem;
+        // measured (same box, NBSS_SEQ_TAIL=0 / 1): batch 2 (1 round + 2 sequences) 297 -> 302 utt/s, batch 8 (4 + 8) 512 -> 516, batch 32 (16 + 32)
+        // 624 -> 623: the tail launch pays while the rounds are few
+        static const bool off = [] { const char* v = getenv("NBSS_SEQ_TAIL"); return v && v[0] == '0'; }();  // A/B knob
+        if (!off && c.dtype == NBSS_BF16 && c.H == 96 && c.T <= NBSS_T_TRAIN_MAX && nseq > ncu && nseq < 8 * ncu && rem > 0 && 2 * rem <= ncu) tl.n = rem;
     }
     const SeqTail* tlp = tl.n > 0 ? &tl : nullptr;
     for (int l = 0; l < c.L; ++l) {

@@ -27,12 +27,48 @@
 #define FL_KSF_BIG 9  // ceil(272 / 32): 16 kHz (n_fft 512 -> F = 257)
 #define FL_THREADS 512  // 8 waves: one workgroup per CU (256 slabs), so the waves of a workgroup are all the latency hiding there is
 
+
+// LinearGroup pass: task = (squeeze channel ch, 16-row tile mt of the F x F matrix), acc = W[ch] tile x s[ch][:, tt]; the body between BEGIN and
+// END is the task's epilogue.  Narrow slabs (TT < 8: small grids, one workgroup per CU, the passes are a chain of exposed fragment loads —
+// 70 of the backward kernel's 96 us per launch at batch 2) request the NEXT task's weight fragments before this task's MFMAs.
+#define FL_TASK_LOOP_BEGIN(NTASK, WMAT)                                                                                  \
+    constexpr bool TPF = TT < 8;                                                                                         \
+    Frag<T> anext[KSFM];                                                                                                 \
+    if (TPF && w < (NTASK)) {                                                                                            \
+        _Pragma("unroll") for (int ks = 0; ks < KSFM; ++ks)                                                              \
+            if (ks < ksf) wfrag_load(anext[ks], (WMAT) + (size_t)(w / mtf) * mtf * ksf * 512, w % mtf, ksf, ks);         \
+    }                                                                                                                    \
+    for (int task = w; task < (NTASK); task += nw) {                                                                     \
+        const int ch = task / mtf, mt = task % mtf;                                                                      \
+        f32x4 acc = F32X4_ZERO;                                                                                          \
+        Frag<T> a[KSFM]; /* all k-step fragments of the tile requested together (at most KSFM) */                        \
+        if (TPF) {                                                                                                       \
+            _Pragma("unroll") for (int ks = 0; ks < KSFM; ++ks) a[ks] = anext[ks];                                       \
+            const int nx = task + nw;                                                                                    \
+            if (nx < (NTASK)) {                                                                                          \
+                _Pragma("unroll") for (int ks = 0; ks < KSFM; ++ks)                                                      \
+                    if (ks < ksf) wfrag_load(anext[ks], (WMAT) + (size_t)(nx / mtf) * mtf * ksf * 512, nx % mtf, ksf, ks); \
+            }                                                                                                            \
+        } else {                                                                                                         \
+            _Pragma("unroll") for (int ks = 0; ks < KSFM; ++ks)                                                          \
+                if (ks < ksf) wfrag_load(a[ks], (WMAT) + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);                     \
+        }                                                                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < KSFM; ++ks) {                                                            \
+            if (ks < ksf) {                                                                                              \
+                Frag<T> bq;                                                                                              \
+                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);                        \
+                else frag_zero(bq);                                                                                      \
+                acc = mma(a[ks], bq, acc);                                                                               \
+            }                                                                                                            \
+        }
+#define FL_TASK_LOOP_END }
+
 // KSFM: LinearGroup k-steps the fragment arrays are sized for; HH / NSQ = dim_hidden / dim_squeeze (geom.h)
 template <class T, int KSFM, int HH, int NSQ, int TT>
 #ifdef NBSS_FULLF_NOCAP
 __global__ __launch_bounds__(FL_THREADS)
 #else
-__global__ __launch_bounds__(FL_THREADS, HH == 96 ? 4 : 1)  // small geometry: <= 128 VGPRs, two workgroups per CU
+__global__ __launch_bounds__(FL_THREADS, HH == 96 && TT == 8 ? 4 : 1)  // small geometry, full grids: <= 128 VGPRs, two workgroups per CU
 #endif
 void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bs, const float* __restrict__ bfull,
@@ -129,22 +165,8 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
     lds_barrier();
 
     // ---- pass 2: LinearGroup along F, one F x F matrix per squeeze channel -------------------
-    for (int task = w; task < NSQ * mtf; task += nw) {
-        const int ch = task / mtf, mt = task % mtf;
-        f32x4 acc = F32X4_ZERO;
-        Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
-#pragma unroll
-        for (int ks = 0; ks < KSFM; ++ks)
-            if (ks < ksf) wfrag_load(a[ks], Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
-#pragma unroll
-        for (int ks = 0; ks < KSFM; ++ks) {
-            if (ks < ksf) {
-                Frag<T> bq;
-                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);
-                else frag_zero(bq);
-                acc = mma(a[ks], bq, acc);
-            }
-        }
+    {
+        FL_TASK_LOOP_BEGIN(NSQ * mtf, Wfull)
         if (l15 < TT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -152,6 +174,7 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
                 if (k < F) store1(z + ((size_t)k * TT + l15) * NSQ + ch, acc[r] + bfull[ch * F + k]);
             }
         }
+        FL_TASK_LOOP_END
     }
     lds_barrier();
 
@@ -219,7 +242,7 @@ template <class T, int KSFM, int TT>
 // bf16 stream: <= 128 VGPRs (a few spilled registers) so that two workgroups share a CU: 4.72 -> 4.17 ms per step together with the LDS-resident
 // weight fragments and the LayerNorm affine sums moved out of the row loop; the software prefetch of the row loops (round 2: worth 10 % at one
 // workgroup per CU) costs more registers than it hides latency at two (4.57 with, 4.17 without)
-__global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
+__global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void full_bwd_kernel(nbss_cfg c, LayerPtrs lp, const float* __restrict__ P, float* __restrict__ part, int layer,
                                                        const T* __restrict__ Wsq, const T* __restrict__ Wfull, const T* __restrict__ Wusq,
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
@@ -309,22 +332,8 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
     copy_sq_image(s_out);
 
     // ---- p2: z = Wf s + bf ----
-    for (int task = w; task < FL_SQ * mtf; task += nw) {
-        const int ch = task / mtf, mt = task % mtf;
-        f32x4 acc = F32X4_ZERO;
-        Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
-#pragma unroll
-        for (int ks = 0; ks < KSFM; ++ks)
-            if (ks < ksf) wfrag_load(a[ks], Wfull + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
-#pragma unroll
-        for (int ks = 0; ks < KSFM; ++ks) {
-            if (ks < ksf) {
-                Frag<T> bq;
-                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);
-                else frag_zero(bq);
-                acc = mma(a[ks], bq, acc);
-            }
-        }
+    {
+        FL_TASK_LOOP_BEGIN(FL_SQ * mtf, Wfull)
         if (l15 < TT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
                 if (k < F) store1(z + ((size_t)k * TT + l15) * FL_SQ + ch, acc[r] + bfull[ch * F + k]);
             }
         }
+        FL_TASK_LOOP_END
     }
     PHASE(3);
     lds_barrier();
@@ -409,22 +419,8 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
     copy_sq_image(dz_out);
 
     // ---- p4: ds = Wf^T dz ; ds_pre = ds * SiLU'(s_pre)  (ds_pre overwrites z) ----
-    for (int task = w; task < FL_SQ * mtf; task += nw) {
-        const int ch = task / mtf, mt = task % mtf;
-        f32x4 acc = F32X4_ZERO;
-        Frag<T> a[KSFM];  // all k-step fragments of the tile requested together (at most KSFM)
-#pragma unroll
-        for (int ks = 0; ks < KSFM; ++ks)
-            if (ks < ksf) wfrag_load(a[ks], WfullT + (size_t)ch * mtf * ksf * 512, mt, ksf, ks);
-#pragma unroll
-        for (int ks = 0; ks < KSFM; ++ks) {
-            if (ks < ksf) {
-                Frag<T> bq;
-                if (l15 < TT) frag_load(bq, s + ((size_t)ch * TT + l15) * FK + ks * 32 + 8 * g4);
-                else frag_zero(bq);
-                acc = mma(a[ks], bq, acc);
-            }
-        }
+    {
+        FL_TASK_LOOP_BEGIN(FL_SQ * mtf, WfullT)
         // the squeeze BIAS gradient is summed here from the fp32 values: as a column sum of the bf16 ds_pre operand over all ~10^6 tokens
         // (wgrad.hip) its rounding noise was the worst parameter-gradient error of the whole network (9.6e-2 on layers.0.squeeze.0.bias)
         float dbs = 0.f;
@@ -442,6 +438,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 ? 4 : 2) void full_bwd_k
         }
         dbs = wave_sum64(dbs);
         if (lane == 0) atomicAdd(aff + ch, dbs);
+        FL_TASK_LOOP_END
     }
     PHASE(7);
     lds_barrier();

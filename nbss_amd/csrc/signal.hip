@@ -156,15 +156,17 @@ NBSS_DEV float ola_env(const float* __restrict__ win, int nfft, int hop, int Tn,
 // out[B,F,T,2Spk] (fp32) * XrMM -> frames -> overlap-add into ybuf[B,Spk,(T+1)*hop] (zeroed by the caller)
 template <int NFFT>
 __global__ __launch_bounds__(256) void inorm_istft_kernel(int B, int S, int Tn, const float* __restrict__ tab, const float* __restrict__ out,
-                                                          const float* __restrict__ xrmm, float* __restrict__ ybuf) {
+                                                          const float* __restrict__ xrmm, float* __restrict__ ybuf, int np) {
+    // np: the output-row tiles of a task are dealt to np waves (small batches: B S T/16 tasks alone are 64 waves at batch 2 on 1024 SIMDs)
     constexpr int HOP = NFFT / 2, F = NFFT / 2 + 1, MTm = NFFT / 16, KSq = (2 * F + 31) / 32;
     const StftGeom g = stft_geom(NFFT);
     const float* Ep = tab + NFFT + (size_t)2 * g.MTq * g.KSm * 512;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
-    const int nst = cdiv(Tn, 16), ntask = B * S * nst;
+    const int nst = cdiv(Tn, 16), ntask = B * S * nst * np;
     const int LP = (Tn + 1) * HOP;
     const int wpb = blockDim.x >> 6;
-    for (int task = blockIdx.x * wpb + wave_id(); task < ntask; task += gridDim.x * wpb) {
+    for (int task0 = blockIdx.x * wpb + wave_id(); task0 < ntask; task0 += gridDim.x * wpb) {
+        const int part = task0 % np, task = task0 / np;
         const int st = task % nst, s = (task / nst) % S, b = task / (nst * S);
         const int t = st * 16 + l15;
         Frag<float> bq[KSq];
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void inorm_istft_kernel(int B, int S, int Tn, 
             }
         }
         float* yb = ybuf + ((size_t)b * S + s) * LP;
-        for (int mt = 0; mt < MTm; ++mt) {
+        for (int mt = part; mt < MTm; mt += np) {
             f32x4 acc = F32X4_ZERO;
 #pragma unroll
             for (int ks = 0; ks < KSq; ++ks) {
@@ -224,14 +226,15 @@ __global__ void istft_finalize_kernel(int BS, int N, int Tn, int nfft, const flo
 template <int NFFT>
 __global__ __launch_bounds__(256) void inorm_istft_bwd_kernel(int B, int S, int N, int Tn, const float* __restrict__ tab,
                                                               const float* __restrict__ dy, const float* __restrict__ xrmm,
-                                                              float* __restrict__ dout) {
+                                                              float* __restrict__ dout, int np) {
     constexpr int HOP = NFFT / 2, F = NFFT / 2 + 1, KSm = NFFT / 32, MTq = (2 * F + 15) / 16;
     const float* ETp = tab + NFFT + (size_t)MTq * KSm * 512;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
-    const int nst = cdiv(Tn, 16), ntask = B * S * nst;
+    const int nst = cdiv(Tn, 16), ntask = B * S * nst * np;
     const int LP = (Tn + 1) * HOP;
     const int wpb = blockDim.x >> 6;
-    for (int task = blockIdx.x * wpb + wave_id(); task < ntask; task += gridDim.x * wpb) {
+    for (int task0 = blockIdx.x * wpb + wave_id(); task0 < ntask; task0 += gridDim.x * wpb) {
+        const int part = task0 % np, task = task0 / np;
         const int st = task % nst, s = (task / nst) % S, b = task / (nst * S);
         const int t = st * 16 + l15;
         const float* dyb = dy + ((size_t)b * S + s) * N;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void inorm_istft_bwd_kernel(int B, int S, int 
                 bq[ks].v[j] = v;
             }
         }
-        for (int mt = 0; mt < MTq; ++mt) {
+        for (int mt = part; mt < MTq; mt += np) {
             f32x4 acc = F32X4_ZERO;
 #pragma unroll
             for (int ks = 0; ks < KSm; ++ks) {
@@ -301,15 +304,23 @@ int stft_norm_impl(int nfft, int dtype, int B, int C, int N, int ref, const floa
     return NBSS_CHECK_LAUNCH();
 }
 
+// waves a (b, speaker, 16-frame tile) task of the iSTFT kernels is dealt to: 1 / 2 / 4 / 8, until the launch has a wave per SIMD
+static int istft_parts(int ntask) {
+    int np = 1;
+    while (np < 8 && ntask * np < 1024) np *= 2;
+    return np;
+}
+
 int inorm_istft_impl(int nfft, int B, int S, int N, const float* tab, const float* out, const float* xrmm, float* ybuf, float* y, hipStream_t st) {
     const int Tn = N / (nfft / 2) + 1;
     const size_t LP = (size_t)(Tn + 1) * (nfft / 2);
     ProfScope ps(PK_ISTFT, st);
     int e = memset_async_impl(ybuf, (size_t)B * S * LP * sizeof(float), st);
     if (e) return e;
-    dim3 grid(grid_for(B * S * cdiv(Tn, 16))), block(256);
-    if (nfft == 256) NBSS_LAUNCH((inorm_istft_kernel<256>), grid, block, 0, st, B, S, Tn, tab, out, xrmm, ybuf);
-    else if (nfft == 512) NBSS_LAUNCH((inorm_istft_kernel<512>), grid, block, 0, st, B, S, Tn, tab, out, xrmm, ybuf);
+    const int np = istft_parts(B * S * cdiv(Tn, 16));
+    dim3 grid(grid_for(B * S * cdiv(Tn, 16) * np)), block(256);
+    if (nfft == 256) NBSS_LAUNCH((inorm_istft_kernel<256>), grid, block, 0, st, B, S, Tn, tab, out, xrmm, ybuf, np);
+    else if (nfft == 512) NBSS_LAUNCH((inorm_istft_kernel<512>), grid, block, 0, st, B, S, Tn, tab, out, xrmm, ybuf, np);
     else return NBSS_EUNSUPPORTED;
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     const size_t total = (size_t)B * S * N;
@@ -321,9 +332,10 @@ int inorm_istft_impl(int nfft, int B, int S, int N, const float* tab, const floa
 int inorm_istft_bwd_impl(int nfft, int B, int S, int N, const float* tab, const float* dy, const float* xrmm, float* dout, hipStream_t st) {
     const int Tn = N / (nfft / 2) + 1;
     ProfScope ps(PK_ISTFT_B, st);
-    dim3 grid(grid_for(B * S * cdiv(Tn, 16))), block(256);
-    if (nfft == 256) NBSS_LAUNCH((inorm_istft_bwd_kernel<256>), grid, block, 0, st, B, S, N, Tn, tab, dy, xrmm, dout);
-    else if (nfft == 512) NBSS_LAUNCH((inorm_istft_bwd_kernel<512>), grid, block, 0, st, B, S, N, Tn, tab, dy, xrmm, dout);
+    const int np = istft_parts(B * S * cdiv(Tn, 16));
+    dim3 grid(grid_for(B * S * cdiv(Tn, 16) * np)), block(256);
+    if (nfft == 256) NBSS_LAUNCH((inorm_istft_bwd_kernel<256>), grid, block, 0, st, B, S, N, Tn, tab, dy, xrmm, dout, np);
+    else if (nfft == 512) NBSS_LAUNCH((inorm_istft_bwd_kernel<512>), grid, block, 0, st, B, S, N, Tn, tab, dy, xrmm, dout, np);
     else return NBSS_EUNSUPPORTED;
     return NBSS_CHECK_LAUNCH();
 }
