@@ -364,10 +364,11 @@ def _check_train_geometry(module: "TrainModule", data=None) -> None:
         if frames > 256:
             raise NotImplementedError(f"fit: training segments of {seg[0]} s are {frames} frames; the training kernels keep one whole sequence per workgroup "
                                       "in LDS (<= 256 frames: 4 s at n_hop 128 / 8 kHz) — cut data.audio_time_len[0]")
-    if (hp.get("dim_hidden"), hp.get("dim_ffn"), hp.get("dim_squeeze"), hp.get("num_heads")) != (96, 192, 8, 4):
-        raise NotImplementedError("fit: the MI355X TRAINING kernels are built for the SpatialNet-small geometry (dim_hidden 96, dim_ffn 192, dim_squeeze 8, "
-                                  f"4 heads; configs/SpatialNet.yaml as shipped); got {hp.get('dim_hidden')}/{hp.get('dim_ffn')}/{hp.get('dim_squeeze')}/"
-                                  f"{hp.get('num_heads')} — SpatialNet-large is served by validate | test | predict")
+    geo = (hp.get("dim_hidden"), hp.get("dim_ffn"), hp.get("dim_squeeze"), hp.get("num_heads"))
+    if geo not in ((96, 192, 8, 4), (192, 384, 16, 4)):
+        raise NotImplementedError("fit: the MI355X kernels are built for SpatialNet-small (dim_hidden 96, dim_ffn 192, dim_squeeze 8, 4 heads; configs/"
+                                  "SpatialNet.yaml as shipped: fused training kernels) and SpatialNet-large (192 / 384 / 16 / 4: its \"for large\" comments; "
+                                  f"generic backward, csrc/gbwd.hip); got {'/'.join(str(v) for v in geo)}")
 
 
 def _is_fused_arch(cfg: dict) -> bool:

@@ -255,6 +255,33 @@ def dry_run(args, rank, world):
         torch.distributed.destroy_process_group()
 
 
+def large_train_rate(lib, dev, batch=4, steps=2):
+    """SpatialNet-large (12 layers, 192 / 384 / squeeze 16: the "for large" comments of configs/SpatialNet.yaml), same 4-s 6-ch input, full bf16
+    train step through the geometry-generic backward (csrc/gbwd.hip: unfused, one tensor pass per operation — a correct path, not a tuned one)"""
+    from models.arch.SpatialNet import SpatialNet
+    from nbss_amd._lib import NBSS_BF16
+    from nbss_amd.engine import SpatialNetEngine, TrainStep
+    try:
+        torch.manual_seed(3)
+        net = SpatialNet(dim_input=12, dim_output=4, num_layers=12, encoder_kernel_size=5, dim_hidden=192, dim_ffn=384, num_heads=4, dropout=(0, 0, 0),
+                         kernel_size=(5, 3), conv_groups=(8, 8), norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=16, num_freqs=129, full_share=0)
+        eng = SpatialNetEngine(lib, dev, dtype=NBSS_BF16, **net.hp)
+        eng.load_params({k: v for k, v in net.named_parameters(remove_duplicate=False)})
+        ts = TrainStep(eng, n_fft=256, ref_channel=0, lr=1e-3, clip=5.0)
+        x, yr = synth_batch(batch, 6, 2, 32000, 99, dev)
+        loss0 = float(ts.step(x, yr))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            loss = ts.step(x, yr)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        return {"value": round(batch * steps / dt, 2), "unit": "utterances/s", "batch": batch, "layers": 12, "ms_per_step": round(dt / steps * 1e3, 1),
+                "loss_first": round(loss0, 4), "loss_last": round(float(loss), 4)}
+    except Exception as e:  # reported, never fatal for the headline line
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,6 +406,7 @@ def main():
                             "frac_mfma": ups * STEP_FLOPS / MFMA_PEAK, "bound": "hbm" if 204 * S_BYTES_BF16 / HBM_PEAK > STEP_FLOPS / MFMA_PEAK else "mfma"}
         base = None
         sweep = None
+        large = None
         if world == 1 and not args.no_cpu_baseline:
             # utterances/s at the other per-GPU batches of SURVEY.md §8(d) (short runs: 1 warm-up + 3 timed steps each)
             sweep = {str(B): round(B * args.steps / dt, 1)}
@@ -393,6 +421,7 @@ def main():
                     ts.step(x2, y2)
                 torch.cuda.synchronize()
                 sweep[str(b2)] = round(b2 * 3 / (time.perf_counter() - t1), 1)
+            large = large_train_rate(lib, dev)
             base = cpu_baseline()
         line = {
             "metric": "utterances/sec (4 s, 6ch, 129 freqs) SpatialNet bf16 train at 1/2/4/8 MI355X",
@@ -402,7 +431,7 @@ def main():
             "config": {"workload": "SpatialNet-small 6ch->2spk, 4-s 8-kHz utterances (32000 samples), n_fft 256/hop 128 (F=129, T=251), 8 layers, "
                                    f"full train step (STFT..Adam), bf16 stream + fp32 master/stats, {B} utterances per GPU per step", "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "final_loss": final_loss},
-            "roofline": roof, "cpu_baseline": base, "utt_per_s_by_batch": sweep,
+            "roofline": roof, "cpu_baseline": base, "utt_per_s_by_batch": sweep, "utt_per_s_large": large,
             "rccl_world": worlds, "comm_ms_per_step": comm_ms,
             "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in prof.items() if v[1] > 0},
         }

@@ -44,11 +44,11 @@ int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal
         int _e = check_cfg(*(cfg));            \
         if (_e != NBSS_OK) return _e;          \
     }
-/* backward (and a forward that saves state for it) keeps a whole sequence per workgroup: T <= NBSS_T_TRAIN_MAX; the training kernels
-   are specialised for the SpatialNet-small geometry (the large one is served forward-only) */
+/* backward (and a forward that saves state for it) keeps a whole sequence per workgroup: T <= NBSS_T_TRAIN_MAX.  The fused training kernels
+   are specialised for the SpatialNet-small geometry; every other geometry check_cfg admits (SpatialNet-large) runs the generic backward (gbwd.hip) */
 #define CHECK_CFG_TRAIN(cfg) \
     CHECK_CFG(cfg);          \
-    if ((cfg)->T > NBSS_T_TRAIN_MAX || (cfg)->H != 96) return NBSS_EUNSUPPORTED;
+    if ((cfg)->T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;
 #define CHECK_LAYER(cfg, layer) \
     if ((layer) < 0 || (layer) >= (cfg)->L) return NBSS_EINVAL;
 
@@ -258,7 +258,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     CHECK_CFG(cfg);
     if (!params || !packed || !xin || !out || (!acts && !ws)) return NBSS_EINVAL;
     const nbss_cfg& c = *cfg;
-    if (acts && (c.T > NBSS_T_TRAIN_MAX || c.H != 96)) return NBSS_EUNSUPPORTED;  // long sequences, SpatialNet-large: inference only
+    if (acts && c.T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;  // long sequences: inference only
     hipStream_t st = (hipStream_t)stream;
     const size_t sb = stream_bytes(c);
     // training: every block input is kept (acts = [5L+1 stream copies | L attention save buffers]);

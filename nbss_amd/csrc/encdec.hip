@@ -7,6 +7,7 @@
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
+#include "side.h"
 #include "prof.h"
 #include "geom.h"
 
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(nbss_cfg c, const T* _
 
 int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, const void* x, const float* dout, void* dx, void* ws,
                      hipStream_t st) {
+    if (c.H != ENC_H) return gb_decoder_bwd(c, P, G, x, dout, dx, ws, st);
     const size_t N = (size_t)c.B * c.F * c.T;
     const int CP = (c.C_out + 3) & ~3;
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
@@ -190,7 +192,7 @@ int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* d
     a.mvalid = 0; a.nvalid = 0;
     a.Ntok = c.B * c.F * c.T; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = c.enc_ks;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
-    a.A = dy; a.lda = ENC_H; a.MA = ENC_H; a.B = xin; a.ldb = c.C_in; a.NB = c.C_in;
+    a.A = dy; a.lda = c.H; a.MA = c.H; a.B = xin; a.ldb = c.C_in; a.NB = c.C_in;
     a.dW = G + param_off_enc_w(c); a.dbias = G + param_off_enc_b(c);
     return wgrad_launch(a, c.dtype, st);
 }

@@ -575,6 +575,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                    void* ws, hipStream_t st, const Side* sd) {
+    if (c.H != FC_H) return gb_fconv_bwd(c, P, G, layer, which, x, dy, dx, ws, st, sd);
     const size_t N = (size_t)c.B * c.F * c.T;
     float* stats = (float*)ws;
     void* dv = (char*)ws + ws_align(N * 2 * sizeof(float));

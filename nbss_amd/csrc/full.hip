@@ -582,6 +582,7 @@ int memset_async_impl(void* p, size_t bytes, hipStream_t st);
 
 int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* dx, void* ws,
                   hipStream_t st, const Side* sd) {
+    if (c.H != FL_H) return gb_full_bwd(c, P, G, layer, x, dy, dx, ws, st, sd);
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats | s [B*T][SQ][FKP] | dz [B*T][SQ][FKP] | z [N][SQ] | dy_pre [N][H] | ds_pre [N][SQ]
     const size_t N = (size_t)c.B * c.F * c.T, BT = (size_t)c.B * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;

@@ -1,0 +1,1046 @@
+// gbwd.hip — the backward pass for geometries the fused training kernels are not specialised for (SpatialNet-large: dim_hidden 192,
+// dim_ffn 384, dim_squeeze 16, head width 48; configs/SpatialNet.yaml "for large" comments, models/arch/SpatialNet.py:154-171).
+//
+// The fused backward kernels (fconv.hip, full.hip, mhsa_bwd.hip, tconvffn_s.hip) keep a whole slab / sequence of the small geometry in LDS;
+// at twice the widths their images do not fit, so this path is built from geometry-generic pieces instead, one tensor
+// pass each, every intermediate in the workspace (288 GB of HBM: a 4-utterance large step keeps ~40 [N][FFN] tensors per block alive
+// for microseconds):
+//   * tap_gemm      Y[n][o] = sum_tap sum_i X[n + (tap - c) S][i] W[g][tap][o][i] (+ bias, SiLU on load / on store): every per-token linear map,
+//                   the grouped convolutions along F and along T, the LinearGroup (rows = (b, t), groups = squeeze channels) AND their data
+//                   gradients (same form with the weights re-laid by wprep).  MFMA straight from global memory: weights = A, tokens = N.
+//   * row kernels   LayerNorm forward / backward (+ affine gradients), SiLU / PReLU backward, GroupNorm statistics / apply / backward,
+//                   the [N][SQ] <-> [B T][SQ][F] transposes of the full-band block
+//   * attention     two kernels per (sequence, head): queries as the N dimension (O, row statistics, dQ) and keys as the N dimension (dK, dV)
+//   * weight gradients: wgrad.hip's token-contraction kernels, which are generic in their dimensions already
+// Semantics and parity: the same oracle functions as the fused path (oracle/spatialnet_ref.py), tests/test_large.py.
+#include "launch.h"
+#include "layout.h"
+#include "prof.h"
+#include "wgrad.h"
+#include "side.h"
+
+#define GB_THREADS 256
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// weights for tap_gemm: [groups][taps][Mp][Kp] of the stream dtype, zero padded (Mp % 16 == 0, Kp % 32 == 0)
+enum { WP_LIN_FWD, WP_LIN_DGRAD, WP_CONV_FWD, WP_CONV_DGRAD, WP_LG_FWD, WP_LG_DGRAD };
+struct WPrep {
+    const float* src;
+    void* dst;
+    int mode, groups, taps, Mg, Kv, Mp, Kp;  // Mg x Kv valid per (group, tap)
+};
+template <class T>
+__global__ void gb_wprep_kernel(WPrep p) {
+    const long total = (long)p.groups * p.taps * p.Mp * p.Kp;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e % p.Kp);
+        long r = e / p.Kp;
+        const int m = (int)(r % p.Mp);
+        r /= p.Mp;
+        const int tap = (int)(r % p.taps), g = (int)(r / p.taps);
+        float v = 0.f;
+        if (m < p.Mg && k < p.Kv) {
+            switch (p.mode) {
+                case WP_LIN_FWD: v = p.src[(long)m * p.Kv + k]; break;                                                   // W[o = m][i = k]
+                case WP_LIN_DGRAD: v = p.src[(long)k * p.Mg + m]; break;                                                 // W[o = k][i = m]
+                case WP_CONV_FWD: v = p.src[(((long)g * p.Mg + m) * p.Kv + k) * p.taps + tap]; break;                    // W[g Og + o][i][tap]
+                case WP_CONV_DGRAD: v = p.src[(((long)g * p.Kv + k) * p.Mg + m) * p.taps + (p.taps - 1 - tap)]; break;   // W[g Og + o = k][i = m][flipped]
+                case WP_LG_FWD: v = p.src[((long)g * p.Mg + m) * p.Mg + k]; break;                                       // Wf[g][k' = m][h = k]   (Mg = Kv = F)
+                case WP_LG_DGRAD: v = p.src[((long)g * p.Mg + k) * p.Mg + m]; break;                                     // Wf[g][k' = k][h = m]
+            }
+        }
+        store1(reinterpret_cast<T*>(p.dst) + e, v);
+    }
+}
+
+struct TapGemm {
+    const void* X;
+    const void* W;      // prepared weights
+    const float* bias;  // [groups][bgs] or null
+    const void* R;      // optional residual, rows of ldr elements, columns as Y
+    void* Y;
+    int rows;
+    int ldx, xcol, xgs;  // X row stride, first column, column stride between groups
+    int ldy, ycol, ygs;
+    int ldr;
+    int groups, Mg, Kg, Mp, Kp, bgs;
+    int taps, center, shift;  // tap reads row n + (tap - center) * shift ...
+    int pos_div, pos_len;     // ... valid while 0 <= (n / pos_div) % pos_len + tap - center < pos_len
+    int xact, yact;           // SiLU on the loaded X / on the result
+};
+
+// One wave = 16 rows (the MFMA N dimension) x up to 64 outputs (4 tiles of 16) of one group; operands come straight from global memory
+// (B: 8 contiguous inputs of the lane's row; A: 8 contiguous prepared weights of the lane's output row — L2-resident, every wave reads
+// the same few KB).  No LDS, no staging: this is the simple generic path, not the speed-of-light one.
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_tap_gemm_kernel(TapGemm p) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const int mchunks = cdiv(p.Mp, 64);
+    const int g = blockIdx.y / mchunks, mc = blockIdx.y % mchunks;
+    const long row = ((long)blockIdx.x * (GB_THREADS / 64) + w) * 16 + l15;
+    const bool rv = row < p.rows;
+    const int pos = rv ? (int)((row / p.pos_div) % p.pos_len) : 0;
+    const T* X = reinterpret_cast<const T*>(p.X);
+    const T* Wg = reinterpret_cast<const T*>(p.W) + (size_t)g * p.taps * p.Mp * p.Kp;
+    f32x4 acc[4] = {F32X4_ZERO, F32X4_ZERO, F32X4_ZERO, F32X4_ZERO};
+    for (int tap = 0; tap < p.taps; ++tap) {
+        const int d = tap - p.center;
+        const bool valid = rv && pos + d >= 0 && pos + d < p.pos_len;
+        const T* xr = X + (size_t)(valid ? row + (long)d * p.shift : 0) * p.ldx + p.xcol + (size_t)g * p.xgs;
+        for (int k0 = 0; k0 < p.Kp; k0 += 32) {
+            const int kk = k0 + 8 * g4;
+            Frag<T> b;
+            if (valid && kk < p.Kg) {
+                frag_load(b, xr + kk);
+                if (p.xact) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) frag_set(b, j, silu_f(frag_get(b, j)));
+                }
+            } else {
+                frag_zero(b);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m0 = (mc * 4 + i) * 16;
+                if (m0 < p.Mp) {
+                    Frag<T> a;
+                    frag_load(a, Wg + ((size_t)tap * p.Mp + m0 + l15) * p.Kp + kk);
+                    acc[i] = mma(a, b, acc[i]);
+                }
+            }
+        }
+    }
+    if (!rv) return;
+    T* yr = reinterpret_cast<T*>(p.Y) + (size_t)row * p.ldy + p.ycol + (size_t)g * p.ygs;
+    const T* rr = p.R ? reinterpret_cast<const T*>(p.R) + (size_t)row * p.ldr + p.ycol + (size_t)g * p.ygs : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m0 = (mc * 4 + i) * 16 + 4 * g4;
+        if (m0 >= p.Mg) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[i][r];
+            if (p.bias && m0 + r < p.Mg) v += p.bias[(size_t)g * p.bgs + m0 + r];
+            if (p.yact) v = silu_f(v);
+            if (rr && m0 + r < p.Mg) v = load1(rr + m0 + r) + round_to(v, yr);
+            o[r] = v;
+        }
+        if (m0 + 3 < p.Mg) store4(yr + m0, o[0], o[1], o[2], o[3]);
+        else
+            for (int r = 0; r < 4 && m0 + r < p.Mg; ++r) store1(yr + m0 + r, o[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// row kernels: one wave per row, lanes over the channels (C <= 64 * GB_CPL)
+#define GB_CPL 6  // channels per lane: 384 / 64
+
+// LayerNorm over the last dim (eps 1e-5): u = xhat gamma + beta (optional), stats = (mean, rstd)
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ u, float* __restrict__ stats, long N, int C) {
+    const int lane = lane_id();
+    const long nw = (long)gridDim.x * (GB_THREADS / 64);
+    for (long n = (long)blockIdx.x * (GB_THREADS / 64) + wave_id(); n < N; n += nw) {
+        float v[GB_CPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < GB_CPL; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < C ? load1(x + n * C + c) : 0.f;
+            s += v[i];
+        }
+        const float mean = wave_sum64(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < GB_CPL; ++i) {
+            const int c = lane + 64 * i;
+            const float d = c < C ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum64(q) / C + 1e-5f);
+        if (lane == 0) {
+            stats[2 * n] = mean;
+            stats[2 * n + 1] = rstd;
+        }
+        if (u) {
+#pragma unroll
+            for (int i = 0; i < GB_CPL; ++i) {
+                const int c = lane + 64 * i;
+                if (c < C) store1(u + n * C + c, (v[i] - mean) * rstd * gamma[c] + beta[c]);
+            }
+        }
+    }
+}
+
+// dx = dy + rstd (g - mean(g) - xhat mean(g xhat)), g = du gamma;  dgamma += sum du xhat, dbeta += sum du   (per-lane sums, one atomicAdd per
+// (workgroup, channel) at the end)
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma, const T* __restrict__ dy, T* __restrict__ dx,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, long N, int C) {
+    NBSS_LDS(smem);
+    float (*red)[64 * GB_CPL] = reinterpret_cast<float (*)[64 * GB_CPL]>(smem);  // [2][64 GB_CPL]
+    const int lane = lane_id();
+    for (int i = threadIdx.x; i < 2 * 64 * GB_CPL; i += GB_THREADS) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    float dg[GB_CPL], db[GB_CPL];
+#pragma unroll
+    for (int i = 0; i < GB_CPL; ++i) dg[i] = db[i] = 0.f;
+    const long nw = (long)gridDim.x * (GB_THREADS / 64);
+    for (long n = (long)blockIdx.x * (GB_THREADS / 64) + wave_id(); n < N; n += nw) {
+        const float mean = stats[2 * n], rstd = stats[2 * n + 1];
+        float xh[GB_CPL], g[GB_CPL];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < GB_CPL; ++i) {
+            const int c = lane + 64 * i;
+            xh[i] = g[i] = 0.f;
+            if (c < C) {
+                xh[i] = (load1(x + n * C + c) - mean) * rstd;
+                const float d = load1(du + n * C + c);
+                dg[i] += d * xh[i];
+                db[i] += d;
+                g[i] = d * gamma[c];
+                m1 += g[i];
+                m2 += g[i] * xh[i];
+            }
+        }
+        m1 = wave_sum64(m1) / C;
+        m2 = wave_sum64(m2) / C;
+#pragma unroll
+        for (int i = 0; i < GB_CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) store1(dx + n * C + c, load1(dy + n * C + c) + rstd * (g[i] - m1 - xh[i] * m2));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GB_CPL; ++i) {
+        atomicAdd(&red[0][lane + 64 * i], dg[i]);
+        atomicAdd(&red[1][lane + 64 * i], db[i]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += GB_THREADS) {
+        atomicAdd(dgamma + c, red[0][c]);
+        atomicAdd(dbeta + c, red[1][c]);
+    }
+}
+
+// gout = gin * SiLU'(a)   (dense tensors; gout may be gin)
+template <class T>
+__global__ void gb_silu_bwd_kernel(const T* __restrict__ a, const T* gin, T* gout, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) store1(gout + i, load1(gin + i) * dsilu_f(load1(a + i)));
+}
+// h = SiLU(a)
+template <class T>
+__global__ void gb_silu_kernel(const T* __restrict__ a, T* __restrict__ h, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) store1(h + i, silu_f(load1(a + i)));
+}
+// PReLU: y = x + (a > 0 ? a : alpha a) is the block output; da = dy (a > 0 ? 1 : alpha[c]), dalpha[c] += sum dy min(a, 0)
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_prelu_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dy, const float* __restrict__ alpha,
+                                                                  T* __restrict__ da, float* __restrict__ dalpha, long N, int C) {
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [64 GB_CPL]
+    const int lane = lane_id();
+    for (int i = threadIdx.x; i < 64 * GB_CPL; i += GB_THREADS) red[i] = 0.f;
+    __syncthreads();
+    float ds[GB_CPL];
+#pragma unroll
+    for (int i = 0; i < GB_CPL; ++i) ds[i] = 0.f;
+    const long nw = (long)gridDim.x * (GB_THREADS / 64);
+    for (long n = (long)blockIdx.x * (GB_THREADS / 64) + wave_id(); n < N; n += nw) {
+#pragma unroll
+        for (int i = 0; i < GB_CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float av = load1(a + n * C + c), d = load1(dy + n * C + c);
+                store1(da + n * C + c, av > 0.f ? d : d * alpha[c]);
+                if (av <= 0.f) ds[i] += d * av;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GB_CPL; ++i) atomicAdd(&red[lane + 64 * i], ds[i]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += GB_THREADS) atomicAdd(dalpha + c, red[c]);
+}
+
+// [N = (b, f, t)][SQ] -> [(b, t)][SQ][FK] (columns F..FK zero) and back
+template <class T>
+__global__ void gb_sq_to_f_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int F, int Tn, int SQ, int FK) {
+    const long total = (long)B * Tn * SQ * FK;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(e % FK);
+        long r = e / FK;
+        const int g = (int)(r % SQ);
+        r /= SQ;
+        const int t = (int)(r % Tn), b = (int)(r / Tn);
+        store1(dst + e, f < F ? load1(src + (((long)b * F + f) * Tn + t) * SQ + g) : 0.f);
+    }
+}
+template <class T>
+__global__ void gb_f_to_sq_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int F, int Tn, int SQ, int FK) {
+    const long total = (long)B * F * Tn * SQ;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(e % SQ);
+        long r = e / SQ;
+        const int t = (int)(r % Tn);
+        r /= Tn;
+        const int f = (int)(r % F), b = (int)(r / F);
+        store1(dst + e, load1(src + (((long)b * Tn + t) * SQ + g) * FK + f));
+    }
+}
+// fp32 [N][Co] -> stream dtype [N][CP] (zero padded): the decoder's upstream gradient as a tap_gemm / wgrad operand
+template <class T>
+__global__ void gb_pad_cols_kernel(const float* __restrict__ src, T* __restrict__ dst, long N, int Co, int CP) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < N * CP; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CP);
+        store1(dst + e, c < Co ? src[(e / CP) * Co + c] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// GroupNorm(groups, FFN) over (T x CG) per sequence and group (eps 1e-5): statistics, h = SiLU(xhat gamma + beta), backward
+// one workgroup per (sequence, group); thread = (frame lane, channel)
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_gn_fwd_kernel(const T* __restrict__ a, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ h, float* __restrict__ stats, int Tn, int C, int CG) {
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [8]
+    const int G = C / CG, seq = blockIdx.x / G, g = blockIdx.x % G;
+    const int M = Tn * CG;
+    const T* ab = a + (size_t)seq * Tn * C + g * CG;
+    T* hb = h + (size_t)seq * Tn * C + g * CG;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum64(v);
+        __syncthreads();
+        if (lane_id() == 0) red[wave_id()] = v;
+        __syncthreads();
+        float s = 0.f;
+        for (int i = 0; i < GB_THREADS / 64; ++i) s += red[i];
+        return s;
+    };
+    float s = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) s += load1(ab + (size_t)(e / CG) * C + e % CG);
+    const float mean = block_sum(s) / M;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const float d = load1(ab + (size_t)(e / CG) * C + e % CG) - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(q) / M + 1e-5f);
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = mean;
+        stats[2 * blockIdx.x + 1] = rstd;
+    }
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const int c = e % CG;
+        const size_t o = (size_t)(e / CG) * C + c;
+        store1(hb + o, silu_f((load1(ab + o) - mean) * rstd * gamma[g * CG + c] + beta[g * CG + c]));
+    }
+}
+// in: dh = gradient w.r.t. h = SiLU(a4), a4 = xhat gamma + beta; out (in place): gradient w.r.t. the GroupNorm input a; dgamma / dbeta accumulate
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_gn_bwd_kernel(const T* __restrict__ a, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, T* __restrict__ dh, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int Tn, int C, int CG) {
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [8]
+    float *cg_w = red + 8, *cg_b = cg_w + 64;    // [64] each: CG <= 64
+    const int G = C / CG, seq = blockIdx.x / G, g = blockIdx.x % G;
+    const int M = Tn * CG;
+    const T* ab = a + (size_t)seq * Tn * C + g * CG;
+    T* db = dh + (size_t)seq * Tn * C + g * CG;
+    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    for (int i = threadIdx.x; i < 64; i += GB_THREADS) cg_w[i] = cg_b[i] = 0.f;
+    __syncthreads();
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum64(v);
+        __syncthreads();
+        if (lane_id() == 0) red[wave_id()] = v;
+        __syncthreads();
+        float s = 0.f;
+        for (int i = 0; i < GB_THREADS / 64; ++i) s += red[i];
+        return s;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const int c = e % CG;
+        const size_t o = (size_t)(e / CG) * C + c;
+        const float xh = (load1(ab + o) - mean) * rstd, gm = gamma[g * CG + c];
+        const float d4 = load1(db + o) * dsilu_f(xh * gm + beta[g * CG + c]);
+        atomicAdd(&cg_w[c], d4 * xh);
+        atomicAdd(&cg_b[c], d4);
+        s1 += d4 * gm;
+        s2 += d4 * gm * xh;
+    }
+    const float m1 = block_sum(s1) / M;
+    const float m2 = block_sum(s2) / M;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const int c = e % CG;
+        const size_t o = (size_t)(e / CG) * C + c;
+        const float xh = (load1(ab + o) - mean) * rstd, gm = gamma[g * CG + c];
+        const float d4 = load1(db + o) * dsilu_f(xh * gm + beta[g * CG + c]);
+        store1(db + o, rstd * (d4 * gm - m1 - xh * m2));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CG; c += GB_THREADS) {
+        atomicAdd(dgamma + g * CG + c, cg_w[c]);
+        atomicAdd(dbeta + g * CG + c, cg_b[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Attention backward for one (sequence, head), T <= 256, any head width DH % 8 == 0 (<= 64).  qkv [N][3H] (q | k | v, head h at columns h DH),
+// scores = q k^T / sqrt(DH), softmax over the keys, O = P V.
+//   kernel Q (queries are the MFMA N dimension; K, V of the head in LDS):  O, lse = log sum exp, D = rowsum(P dP), dQ
+//   kernel K (keys are the N dimension; Q, dO of the head in LDS):         dK, dV
+// Transposed operands (V^T, K^T, Q^T, dO^T: the token axis as K dimension) are gathered from the row-major LDS images element by element.
+#define GA_TMAX 256
+NBSS_DEV int ga_perm_k(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
+
+template <class T, int DH>
+__global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, T* __restrict__ O, T* __restrict__ dqkv,
+                                                               float* __restrict__ lse, float* __restrict__ Dv, int Tn, int H, int heads) {
+    constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NTM = GA_TMAX / 16;
+    NBSS_LDS(smem);
+    const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32);
+    T* Ks = reinterpret_cast<T*>(smem);  // [TP][DH]
+    T* Vs = Ks + (size_t)TP * DH;        // [TP][DH]
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)seq * Tn;
+    const int ld = 3 * H;
+    for (int e = threadIdx.x; e < TP * DH; e += GB_THREADS) {
+        const int t = e / DH, d = e % DH;
+        store1(Ks + e, t < Tn ? load1(qkv + (n0 + t) * ld + H + head * DH + d) : 0.f);
+        store1(Vs + e, t < Tn ? load1(qkv + (n0 + t) * ld + 2 * H + head * DH + d) : 0.f);
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)DH);
+    for (int qt = w; qt < NT; qt += GB_THREADS / 64) {
+        const int q = qt * 16 + l15;
+        const bool qv = q < Tn;
+        const size_t nq = n0 + (qv ? q : 0);
+        Frag<T> qf[KS], dof[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = 32 * ks + 8 * g4;
+            if (qv && d0 < DH) {
+                frag_load(qf[ks], qkv + nq * ld + head * DH + d0);
+                frag_load(dof[ks], dO + nq * H + head * DH + d0);
+            } else {
+                frag_zero(qf[ks]);
+                frag_zero(dof[ks]);
+            }
+        }
+        // S^T and dP^T tiles: rows = keys 16 jt + 4 g4 + r, column = the lane's query
+        f32x4 st[NTM], dp[NTM];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt) {
+            st[jt] = F32X4_ZERO;
+            dp[jt] = F32X4_ZERO;
+            if (jt < NT) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d0 = 32 * ks + 8 * g4;
+                    Frag<T> kf, vf;
+                    if (d0 < DH) {
+                        frag_load(kf, Ks + (size_t)(16 * jt + l15) * DH + d0);
+                        frag_load(vf, Vs + (size_t)(16 * jt + l15) * DH + d0);
+                    } else {
+                        frag_zero(kf);
+                        frag_zero(vf);
+                    }
+                    st[jt] = mma(kf, qf[ks], st[jt]);
+                    dp[jt] = mma(vf, dof[ks], dp[jt]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kv = 16 * jt + 4 * g4 + r < Tn;
+                    st[jt][r] = kv ? st[jt][r] * scale : -3.0e38f;
+                    mx = fmaxf(mx, st[jt][r]);
+                }
+            }
+        }
+        mx = wave_max16(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kv = jt < NT && 16 * jt + 4 * g4 + r < Tn;
+                st[jt][r] = kv ? __expf(st[jt][r] - mx) : 0.f;
+                sum += st[jt][r];
+            }
+        sum = wave_sum16(sum);
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[jt][r] *= inv;  // P^T
+                dsum += st[jt][r] * dp[jt][r];
+            }
+        dsum = wave_sum16(dsum);  // D = rowsum(P dP) = rowsum(dO O)
+        if (qv && g4 == 0) {
+            lse[nq * heads + head] = mx + __logf(sum);
+            Dv[nq * heads + head] = dsum;
+        }
+        // O^T = V^T P^T and dQ^T = K^T dS^T: K dimension = keys in pairs of tiles (permuted order of two stacked C tiles)
+        f32x4 oacc[MTD], qacc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) oacc[mt] = qacc[mt] = F32X4_ZERO;
+#pragma unroll
+        for (int kk = 0; kk < NTM / 2; ++kk) {
+            if (2 * kk < NT) {
+                f32x4 ds0, ds1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ds0[r] = st[2 * kk][r] * (dp[2 * kk][r] - dsum) * scale;
+                    ds1[r] = st[2 * kk + 1][r] * (dp[2 * kk + 1][r] - dsum) * scale;
+                }
+                Frag<T> pf, dsf;
+                frag_from_c2(pf, st[2 * kk], st[2 * kk + 1]);
+                frag_from_c2(dsf, ds0, ds1);
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) {
+                    const int d = 16 * mt + l15;
+                    Frag<T> vt, kt;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = 32 * kk + ga_perm_k(g4, j);
+                        frag_set(vt, j, d < DH ? load1(Vs + (size_t)key * DH + d) : 0.f);
+                        frag_set(kt, j, d < DH ? load1(Ks + (size_t)key * DH + d) : 0.f);
+                    }
+                    oacc[mt] = mma(vt, pf, oacc[mt]);
+                    qacc[mt] = mma(kt, dsf, qacc[mt]);
+                }
+            }
+        }
+        if (qv) {
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int d = 16 * mt + 4 * g4;
+                if (d < DH) {
+                    store4(O + nq * H + head * DH + d, oacc[mt][0], oacc[mt][1], oacc[mt][2], oacc[mt][3]);
+                    store4(dqkv + nq * ld + head * DH + d, qacc[mt][0], qacc[mt][1], qacc[mt][2], qacc[mt][3]);
+                }
+            }
+        }
+    }
+}
+
+template <class T, int DH>
+__global__ __launch_bounds__(GB_THREADS) void gb_attn_k_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, T* __restrict__ dqkv,
+                                                               const float* __restrict__ lse, const float* __restrict__ Dv, int Tn, int H, int heads) {
+    constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16;
+    NBSS_LDS(smem);
+    const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32);
+    T* Qs = reinterpret_cast<T*>(smem);   // [TP][DH]
+    T* dOs = Qs + (size_t)TP * DH;        // [TP][DH]
+    float* ls = reinterpret_cast<float*>(dOs + (size_t)TP * DH);  // [TP] lse | [TP] D
+    float* Ds = ls + TP;
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)seq * Tn;
+    const int ld = 3 * H;
+    for (int e = threadIdx.x; e < TP * DH; e += GB_THREADS) {
+        const int t = e / DH, d = e % DH;
+        store1(Qs + e, t < Tn ? load1(qkv + (n0 + t) * ld + head * DH + d) : 0.f);
+        store1(dOs + e, t < Tn ? load1(dO + (n0 + t) * H + head * DH + d) : 0.f);
+    }
+    for (int t = threadIdx.x; t < TP; t += GB_THREADS) {
+        ls[t] = t < Tn ? lse[(n0 + t) * heads + head] : 0.f;
+        Ds[t] = t < Tn ? Dv[(n0 + t) * heads + head] : 0.f;
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)DH);
+    for (int kt = w; kt < NT; kt += GB_THREADS / 64) {
+        const int key = kt * 16 + l15;
+        const bool kv = key < Tn;
+        const size_t nk = n0 + (kv ? key : 0);
+        Frag<T> kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = 32 * ks + 8 * g4;
+            if (kv && d0 < DH) {
+                frag_load(kf[ks], qkv + nk * ld + H + head * DH + d0);
+                frag_load(vf[ks], qkv + nk * ld + 2 * H + head * DH + d0);
+            } else {
+                frag_zero(kf[ks]);
+                frag_zero(vf[ks]);
+            }
+        }
+        f32x4 kacc[MTD], vacc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) kacc[mt] = vacc[mt] = F32X4_ZERO;
+        for (int kk = 0; 2 * kk < NT; ++kk) {
+            // S and dP tiles of query tiles 2 kk, 2 kk + 1: rows = queries 16 it + 4 g4 + r, column = the lane's key
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int it = 2 * kk + h2;
+                f32x4 s = F32X4_ZERO, dpv = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d0 = 32 * ks + 8 * g4;
+                    Frag<T> qf, dof;
+                    if (d0 < DH) {
+                        frag_load(qf, Qs + (size_t)(16 * it + l15) * DH + d0);
+                        frag_load(dof, dOs + (size_t)(16 * it + l15) * DH + d0);
+                    } else {
+                        frag_zero(qf);
+                        frag_zero(dof);
+                    }
+                    s = mma(qf, kf[ks], s);
+                    dpv = mma(dof, vf[ks], dpv);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * it + 4 * g4 + r;
+                    const bool ok = kv && q < Tn;
+                    const float p = ok ? __expf(s[r] * scale - ls[q]) : 0.f;
+                    pt[h2][r] = p;
+                    dst[h2][r] = p * (dpv[r] - Ds[q]) * scale;
+                }
+            }
+            Frag<T> pf, dsf;
+            frag_from_c2(pf, pt[0], pt[1]);
+            frag_from_c2(dsf, dst[0], dst[1]);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int d = 16 * mt + l15;
+                Frag<T> dot, qt;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = 32 * kk + ga_perm_k(g4, j);
+                    frag_set(dot, j, d < DH ? load1(dOs + (size_t)q * DH + d) : 0.f);
+                    frag_set(qt, j, d < DH ? load1(Qs + (size_t)q * DH + d) : 0.f);
+                }
+                vacc[mt] = mma(dot, pf, vacc[mt]);
+                kacc[mt] = mma(qt, dsf, kacc[mt]);
+            }
+        }
+        if (kv) {
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int d = 16 * mt + 4 * g4;
+                if (d < DH) {
+                    store4(dqkv + nk * ld + H + head * DH + d, kacc[mt][0], kacc[mt][1], kacc[mt][2], kacc[mt][3]);
+                    store4(dqkv + nk * ld + 2 * H + head * DH + d, vacc[mt][0], vacc[mt][1], vacc[mt][2], vacc[mt][3]);
+                }
+            }
+        }
+    }
+}
+
+// ====================================================================================================================================
+// host side
+// ====================================================================================================================================
+static int gb_blocks(long n, int per_block) {
+    const long b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : b > 4096 ? 4096 : b);
+}
+// bump allocator over the sub-block's workspace (behind the per-token statistics at its head; 256-byte aligned pieces)
+struct GbArena {
+    char* p;
+    char* end;
+    void* take(size_t bytes) {
+        void* r = p;
+        p += ws_align(bytes);
+        return p <= end ? r : nullptr;
+    }
+};
+static GbArena gb_arena(const nbss_cfg& c, void* ws) {
+    const size_t N = (size_t)c.B * c.F * c.T;
+    GbArena a;
+    a.p = (char*)ws + ws_align(N * 2 * sizeof(float));
+    a.end = (char*)ws + ws_part_offset(c);
+    return a;
+}
+
+template <class T>
+static int gb_wprep(const float* src, void* dst, int mode, int groups, int taps, int Mg, int Kv, int Mp, int Kp, hipStream_t st) {
+    WPrep p = {src, dst, mode, groups, taps, Mg, Kv, Mp, Kp};
+    NBSS_LAUNCH((gb_wprep_kernel<T>), dim3(gb_blocks((long)groups * taps * Mp * Kp, 256)), dim3(256), 0, st, p);
+    return NBSS_CHECK_LAUNCH();
+}
+static int pad16(int v) { return (v + 15) & ~15; }
+static int pad32(int v) { return (v + 31) & ~31; }
+static int pad8(int v) { return (v + 7) & ~7; }
+
+template <class T>
+static int gb_gemm(const TapGemm& p, hipStream_t st) {
+    if (p.Kg % 8 || p.ldx % 8 || p.xcol % 8 || p.xgs % 8 || p.ycol % 4 || p.ygs % 4 || p.ldy % 4) return NBSS_EUNSUPPORTED;
+    dim3 grid(cdiv(p.rows, 64), p.groups * cdiv(p.Mp, 64));
+    NBSS_LAUNCH((gb_tap_gemm_kernel<T>), grid, dim3(GB_THREADS), 0, st, p);
+    return NBSS_CHECK_LAUNCH();
+}
+// dense per-token linear map (taps = 1, one group): Y[rows][M] = act(X[rows][K] Wp^T + bias) (+ R)
+static TapGemm gb_lin(const void* X, int ldx, const void* Wp, const float* bias, void* Y, int ldy, long rows, int M, int K) {
+    TapGemm p;
+    p.X = X; p.W = Wp; p.bias = bias; p.R = nullptr; p.Y = Y;
+    p.rows = (int)rows;
+    p.ldx = ldx; p.xcol = 0; p.xgs = 0;
+    p.ldy = ldy; p.ycol = 0; p.ygs = 0; p.ldr = 0;
+    p.groups = 1; p.Mg = M; p.Kg = K; p.Mp = pad16(M); p.Kp = pad32(K); p.bgs = 0;
+    p.taps = 1; p.center = 0; p.shift = 0; p.pos_div = 1; p.pos_len = 1 << 30;
+    p.xact = 0; p.yact = 0;
+    return p;
+}
+// grouped convolution along one axis of the [B][F][T] token grid on [rows][C] tensors (C = groups * CG in and out)
+static TapGemm gb_conv(const void* X, const void* Wp, const float* bias, void* Y, long rows, int C, int groups, int taps, int shift, int pos_div,
+                       int pos_len) {
+    const int CG = C / groups;
+    TapGemm p = gb_lin(X, C, Wp, bias, Y, C, rows, CG, CG);
+    p.groups = groups; p.xgs = CG; p.ygs = CG; p.bgs = CG;
+    p.taps = taps; p.center = taps / 2; p.shift = shift; p.pos_div = pos_div; p.pos_len = pos_len;
+    return p;
+}
+
+template <class T>
+static int gb_ln_fwd(const void* x, const float* gamma, const float* beta, void* u, float* stats, long N, int C, hipStream_t st) {
+    if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
+    NBSS_LAUNCH((gb_ln_fwd_kernel<T>), dim3(gb_blocks(N, 4)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N, C);
+    return NBSS_CHECK_LAUNCH();
+}
+template <class T>
+static int gb_ln_bwd(const void* du, const void* x, const float* stats, const float* gamma, const void* dy, void* dx, float* dgamma, float* dbeta, long N,
+                     int C, hipStream_t st) {
+    if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
+    const int blocks = gb_blocks(N, 4 * 16) < 1024 ? gb_blocks(N, 4 * 16) : 1024;  // >= 16 rows per wave: the affine sums end in C atomics per workgroup
+    NBSS_LAUNCH((gb_ln_bwd_kernel<T>), dim3(blocks), dim3(GB_THREADS), 2 * 64 * GB_CPL * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N, C);
+    return NBSS_CHECK_LAUNCH();
+}
+template <class T>
+static int gb_silu_bwd(const void* a, const void* gin, void* gout, long n, hipStream_t st) {
+    NBSS_LAUNCH((gb_silu_bwd_kernel<T>), dim3(gb_blocks(n, 1024)), dim3(256), 0, st, (const T*)a, (const T*)gin, (T*)gout, n);
+    return NBSS_CHECK_LAUNCH();
+}
+template <class T>
+static int gb_silu(const void* a, void* h, long n, hipStream_t st) {
+    NBSS_LAUNCH((gb_silu_kernel<T>), dim3(gb_blocks(n, 1024)), dim3(256), 0, st, (const T*)a, (T*)h, n);
+    return NBSS_CHECK_LAUNCH();
+}
+
+static void gb_wgrad_base(WgradArgs& a, const nbss_cfg& c, void* ws, long Ntok) {
+    a.part = (float*)((char*)ws + ws_wgpart_offset(c));
+    a.mvalid = 0; a.nvalid = 0;
+    a.Ntok = (int)Ntok; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+}
+// dW[M][K] += A^T B over the rows, dbias += colsum(A); M in slices of at most 256 rows (wgrad.hip stages one A image per workgroup)
+static int gb_wgrad_dense(const nbss_cfg& c, void* ws, const void* A, int lda, int M, const void* B, int ldb, int K, float* dW, float* dbias, long Ntok,
+                          hipStream_t st) {
+    const size_t esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    for (int m0 = 0; m0 < M; m0 += 192) {
+        const int mm = M - m0 < 192 ? M - m0 : 192;
+        WgradArgs a;
+        gb_wgrad_base(a, c, ws, Ntok);
+        a.A = (const char*)A + (size_t)m0 * esz; a.lda = lda; a.MA = mm;
+        a.B = B; a.ldb = ldb; a.NB = K;
+        a.dW = dW + (size_t)m0 * K; a.dbias = dbias ? dbias + m0 : nullptr;
+        int e = wgrad_launch(a, c.dtype, st);
+        if (e) return e;
+    }
+    return NBSS_OK;
+}
+
+// ---- F-conv block (SpatialNet.py:116-127): y = x + PReLU(conv_F(LN(x))) ----------------------------------------------------------------
+template <class T>
+static int gb_fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer, int which, const void* x, const void* dy, void* dx, void* ws, hipStream_t st,
+                          const Side* sd) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const long N = (long)c.B * c.F * c.T;
+    const int H = c.H, CG = H / c.f_groups, Mp = pad16(CG), Kp = pad32(CG);
+    const int pLW = which ? P_FC2_LN_W : P_FC1_LN_W, pLB = which ? P_FC2_LN_B : P_FC1_LN_B, pW = which ? P_FC2_W : P_FC1_W, pB = which ? P_FC2_B : P_FC1_B,
+              pA = which ? P_FC2_PRELU : P_FC1_PRELU;
+    float* stats = (float*)ws;
+    GbArena ar = gb_arena(c, ws);
+    void* u = ar.take(N * H * sizeof(T));
+    void* a = ar.take(N * H * sizeof(T));
+    void* da = ar.take(N * H * sizeof(T));
+    void* du = ar.take(N * H * sizeof(T));
+    void* wf = ar.take((size_t)c.f_groups * c.f_ks * Mp * Kp * sizeof(T));
+    void* wd = ar.take((size_t)c.f_groups * c.f_ks * Mp * Kp * sizeof(T));
+    if (!wd) return NBSS_EUNSUPPORTED;
+    int e;
+    if ((e = gb_wprep<T>(lp.p[pW], wf, WP_CONV_FWD, c.f_groups, c.f_ks, CG, CG, Mp, Kp, st))) return e;
+    if ((e = gb_wprep<T>(lp.p[pW], wd, WP_CONV_DGRAD, c.f_groups, c.f_ks, CG, CG, Mp, Kp, st))) return e;
+    if ((e = gb_ln_fwd<T>(x, lp.p[pLW], lp.p[pLB], u, stats, N, H, st))) return e;
+    // a = conv along F (rows T apart, position f = (n / T) % F)
+    if ((e = gb_gemm<T>(gb_conv(u, wf, lp.p[pB], a, N, H, c.f_groups, c.f_ks, c.T, c.T, c.F), st))) return e;
+    NBSS_LAUNCH((gb_prelu_bwd_kernel<T>), dim3(gb_blocks(N, 64) < 1024 ? gb_blocks(N, 64) : 1024), dim3(GB_THREADS), 64 * GB_CPL * sizeof(float), st, (const T*)a, (const T*)dy, lp.p[pA], (T*)da,
+                G + param_off(c, layer, pA), N, H);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if ((e = gb_gemm<T>(gb_conv(da, wd, nullptr, du, N, H, c.f_groups, c.f_ks, c.T, c.T, c.F), st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[pLW], dy, dx, G + param_off(c, layer, pLW), G + param_off(c, layer, pLB), N, H, st))) return e;
+    // conv weight: dW[o][i][tap] = sum_n da[n][o] u[n + (tap - 2) T][i], bias = colsum(da)
+    const hipStream_t gs = side_fork(sd, st);
+    WgradArgs wa;
+    gb_wgrad_base(wa, c, ws, N);
+    wa.shift_stride = c.T; wa.shift_dim = 1; wa.groups = c.f_groups; wa.taps = c.f_ks;
+    wa.A = da; wa.lda = H; wa.MA = H; wa.B = u; wa.ldb = H; wa.NB = H;
+    wa.dW = G + param_off(c, layer, pW); wa.dbias = G + param_off(c, layer, pB);
+    return wgrad_launch(wa, c.dtype, gs);
+}
+
+// ---- full-band block (SpatialNet.py:129-146): y = x + SiLU(Wu LinearGroup_F(SiLU(Ws LN(x) + bs)) + bu) ---------------------------------
+template <class T>
+static int gb_full_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const long N = (long)c.B * c.F * c.T, BT = (long)c.B * c.T;
+    const int H = c.H, SQ = c.SQ, F = c.F, FK = pad8(F);
+    float* stats = (float*)ws;
+    GbArena ar = gb_arena(c, ws);
+    void* u = ar.take(N * H * sizeof(T));
+    void* sp = ar.take(N * SQ * sizeof(T));    // squeeze pre-activation, later ds_pre
+    void* s = ar.take(N * SQ * sizeof(T));     // SiLU(sp), later ds
+    void* sT = ar.take(BT * SQ * FK * sizeof(T));
+    void* zT = ar.take(BT * SQ * FK * sizeof(T));   // later ds^T
+    void* z = ar.take(N * SQ * sizeof(T));     // later dz
+    void* dzT = ar.take(BT * SQ * FK * sizeof(T));
+    void* yp = ar.take(N * H * sizeof(T));     // unsqueeze pre-activation
+    void* dyp = ar.take(N * H * sizeof(T));    // later du
+    const int Fp16 = pad16(F), Fp32 = pad32(FK);
+    void* w_sq = ar.take((size_t)pad16(SQ) * pad32(H) * sizeof(T));
+    void* w_sqT = ar.take((size_t)pad16(H) * pad32(SQ) * sizeof(T));
+    void* w_us = ar.take((size_t)pad16(H) * pad32(SQ) * sizeof(T));
+    void* w_usT = ar.take((size_t)pad16(SQ) * pad32(H) * sizeof(T));
+    void* w_lg = ar.take((size_t)SQ * Fp16 * Fp32 * sizeof(T));
+    void* w_lgT = ar.take((size_t)SQ * Fp16 * Fp32 * sizeof(T));
+    if (!w_lgT) return NBSS_EUNSUPPORTED;
+    int e;
+    if ((e = gb_wprep<T>(lp.p[P_SQ_W], w_sq, WP_LIN_FWD, 1, 1, SQ, H, pad16(SQ), pad32(H), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_SQ_W], w_sqT, WP_LIN_DGRAD, 1, 1, H, SQ, pad16(H), pad32(SQ), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_USQ_W], w_us, WP_LIN_FWD, 1, 1, H, SQ, pad16(H), pad32(SQ), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_USQ_W], w_usT, WP_LIN_DGRAD, 1, 1, SQ, H, pad16(SQ), pad32(H), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_FULL_W], w_lg, WP_LG_FWD, SQ, 1, F, F, Fp16, Fp32, st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_FULL_W], w_lgT, WP_LG_DGRAD, SQ, 1, F, F, Fp16, Fp32, st))) return e;
+    // forward chain
+    if ((e = gb_ln_fwd<T>(x, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B], u, stats, N, H, st))) return e;
+    if ((e = gb_gemm<T>(gb_lin(u, H, w_sq, lp.p[P_SQ_B], sp, SQ, N, SQ, H), st))) return e;
+    if ((e = gb_silu<T>(sp, s, N * SQ, st))) return e;
+    NBSS_LAUNCH((gb_sq_to_f_kernel<T>), dim3(gb_blocks(BT * SQ * FK, 1024)), dim3(256), 0, st, (const T*)s, (T*)sT, c.B, F, c.T, SQ, FK);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    auto lg = [&](const void* X, const void* Wp, const float* bias, void* Y) {
+        TapGemm p = gb_lin(X, SQ * FK, Wp, bias, Y, SQ * FK, BT, F, FK);
+        p.groups = SQ; p.xgs = FK; p.ygs = FK; p.bgs = F;
+        p.Mp = Fp16; p.Kp = Fp32;
+        return p;
+    };
+    if ((e = gb_gemm<T>(lg(sT, w_lg, lp.p[P_FULL_B], zT), st))) return e;
+    NBSS_LAUNCH((gb_f_to_sq_kernel<T>), dim3(gb_blocks(N * SQ, 1024)), dim3(256), 0, st, (const T*)zT, (T*)z, c.B, F, c.T, SQ, FK);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if ((e = gb_gemm<T>(gb_lin(z, SQ, w_us, lp.p[P_USQ_B], yp, H, N, H, SQ), st))) return e;
+    // backward chain
+    if ((e = gb_silu_bwd<T>(yp, dy, dyp, N * H, st))) return e;                               // dy_pre
+    void* dz = ar.take(N * SQ * sizeof(T));
+    void* ds = ar.take(N * SQ * sizeof(T));
+    if (!ds) return NBSS_EUNSUPPORTED;
+    if ((e = gb_gemm<T>(gb_lin(dyp, H, w_usT, nullptr, dz, SQ, N, SQ, H), st))) return e;      // dz = Wu^T dy_pre
+    NBSS_LAUNCH((gb_sq_to_f_kernel<T>), dim3(gb_blocks(BT * SQ * FK, 1024)), dim3(256), 0, st, (const T*)dz, (T*)dzT, c.B, F, c.T, SQ, FK);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    void* dsT = ar.take(BT * SQ * FK * sizeof(T));
+    if (!dsT) return NBSS_EUNSUPPORTED;
+    if ((e = gb_gemm<T>(lg(dzT, w_lgT, nullptr, dsT), st))) return e;                         // ds^T = Wf^T dz^T
+    NBSS_LAUNCH((gb_f_to_sq_kernel<T>), dim3(gb_blocks(N * SQ, 1024)), dim3(256), 0, st, (const T*)dsT, (T*)ds, c.B, F, c.T, SQ, FK);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if ((e = gb_silu_bwd<T>(sp, ds, ds, N * SQ, st))) return e;                               // ds_pre (in ds)
+    void* du = ar.take(N * H * sizeof(T));
+    if (!du) return NBSS_EUNSUPPORTED;
+    if ((e = gb_gemm<T>(gb_lin(ds, SQ, w_sqT, nullptr, du, H, N, H, SQ), st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_FULL_LN_W], dy, dx, G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B), N, H, st))) return e;
+    // weight gradients
+    const hipStream_t gs = side_fork(sd, st);
+    if ((e = gb_wgrad_dense(c, ws, dyp, H, H, z, SQ, SQ, G + param_off(c, layer, P_USQ_W), G + param_off(c, layer, P_USQ_B), N, gs))) return e;
+    WgradArgs wa;
+    gb_wgrad_base(wa, c, ws, BT);
+    wa.groups = SQ; wa.mvalid = F; wa.nvalid = F;
+    wa.A = dzT; wa.lda = SQ * FK; wa.MA = SQ * FK; wa.B = sT; wa.ldb = SQ * FK; wa.NB = SQ * FK;
+    wa.dW = G + param_off(c, layer, P_FULL_W); wa.dbias = G + param_off(c, layer, P_FULL_B);
+    if ((e = wgrad_launch(wa, c.dtype, gs))) return e;
+    return gb_wgrad_dense(c, ws, ds, SQ, SQ, u, H, H, G + param_off(c, layer, P_SQ_W), G + param_off(c, layer, P_SQ_B), N, gs);
+}
+
+// ---- attention block (SpatialNet.py:93-100): y = x + out_proj(MHSA(LN(x))) ---------------------------------------------------------------
+template <class T, int DH>
+static int gb_attn_launch(const nbss_cfg& c, const void* qkv, const void* dO, void* O, void* dqkv, float* lse, float* Dv, hipStream_t st) {
+    const int TP = 32 * cdiv(c.T, 32);
+    const size_t ldsq = (size_t)2 * TP * DH * sizeof(T), ldsk = ldsq + (size_t)2 * TP * sizeof(float);
+    if (c.T > GA_TMAX || ldsk > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e;
+    if ((e = NBSS_SET_MAX_LDS((gb_attn_q_kernel<T, DH>), ldsq))) return e;
+    if ((e = NBSS_SET_MAX_LDS((gb_attn_k_kernel<T, DH>), ldsk))) return e;
+    dim3 grid(c.B * c.F, c.heads);
+    NBSS_LAUNCH((gb_attn_q_kernel<T, DH>), grid, dim3(GB_THREADS), ldsq, st, (const T*)qkv, (const T*)dO, (T*)O, (T*)dqkv, lse, Dv, c.T, c.H, c.heads);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH((gb_attn_k_kernel<T, DH>), grid, dim3(GB_THREADS), ldsk, st, (const T*)qkv, (const T*)dO, (T*)dqkv, (const float*)lse, (const float*)Dv, c.T, c.H, c.heads);
+    return NBSS_CHECK_LAUNCH();
+}
+
+template <class T>
+static int gb_mhsa_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const long N = (long)c.B * c.F * c.T;
+    const int H = c.H, DH = H / c.heads;
+    float* stats = (float*)ws;
+    GbArena ar = gb_arena(c, ws);
+    void* u = ar.take(N * H * sizeof(T));
+    void* qkv = ar.take(N * 3 * H * sizeof(T));
+    void* dO = ar.take(N * H * sizeof(T));
+    void* O = ar.take(N * H * sizeof(T));
+    void* dqkv = ar.take(N * 3 * H * sizeof(T));
+    void* du = ar.take(N * H * sizeof(T));
+    float* lse = (float*)ar.take(N * c.heads * sizeof(float));
+    float* Dv = (float*)ar.take(N * c.heads * sizeof(float));
+    void* w_in = ar.take((size_t)pad16(3 * H) * pad32(H) * sizeof(T));
+    void* w_inT = ar.take((size_t)pad16(H) * pad32(3 * H) * sizeof(T));
+    void* w_outT = ar.take((size_t)pad16(H) * pad32(H) * sizeof(T));
+    if (!w_outT) return NBSS_EUNSUPPORTED;
+    int e;
+    if ((e = gb_wprep<T>(lp.p[P_INP_W], w_in, WP_LIN_FWD, 1, 1, 3 * H, H, pad16(3 * H), pad32(H), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_INP_W], w_inT, WP_LIN_DGRAD, 1, 1, H, 3 * H, pad16(H), pad32(3 * H), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_OUTP_W], w_outT, WP_LIN_DGRAD, 1, 1, H, H, pad16(H), pad32(H), st))) return e;
+    if ((e = gb_ln_fwd<T>(x, lp.p[P_MH_LN_W], lp.p[P_MH_LN_B], u, stats, N, H, st))) return e;
+    if ((e = gb_gemm<T>(gb_lin(u, H, w_in, lp.p[P_INP_B], qkv, 3 * H, N, 3 * H, H), st))) return e;
+    if ((e = gb_gemm<T>(gb_lin(dy, H, w_outT, nullptr, dO, H, N, H, H), st))) return e;  // dO = dy Wo
+    if (DH == 48) e = gb_attn_launch<T, 48>(c, qkv, dO, O, dqkv, lse, Dv, st);
+    else if (DH == 24) e = gb_attn_launch<T, 24>(c, qkv, dO, O, dqkv, lse, Dv, st);
+    else e = NBSS_EUNSUPPORTED;
+    if (e) return e;
+    if ((e = gb_gemm<T>(gb_lin(dqkv, 3 * H, w_inT, nullptr, du, H, N, H, 3 * H), st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_MH_LN_W], dy, dx, G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B), N, H, st))) return e;
+    const hipStream_t gs = side_fork(sd, st);
+    if ((e = gb_wgrad_dense(c, ws, dy, H, H, O, H, H, G + param_off(c, layer, P_OUTP_W), G + param_off(c, layer, P_OUTP_B), N, gs))) return e;
+    return gb_wgrad_dense(c, ws, dqkv, 3 * H, 3 * H, u, H, H, G + param_off(c, layer, P_INP_W), G + param_off(c, layer, P_INP_B), N, gs);
+}
+
+// ---- T-ConvFFN block (SpatialNet.py:102-114) -----------------------------------------------------------------------------------------------
+template <class T>
+static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st,
+                             const Side* sd) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const long N = (long)c.B * c.F * c.T;
+    const int H = c.H, FFN = c.FFN, CG = FFN / c.t_groups, nseq = c.B * c.F;
+    if (CG > 64) return NBSS_EUNSUPPORTED;
+    float* stats = (float*)ws;
+    GbArena ar = gb_arena(c, ws);
+    void* u = ar.take(N * H * sizeof(T));
+    void* du = ar.take(N * H * sizeof(T));
+    void* t[12];  // a1 h1 a2 h2 a3 h4 a5 h5 | g5 g3 g2 g1
+    for (int i = 0; i < 12; ++i) t[i] = ar.take(N * FFN * sizeof(T));
+    void *a1 = t[0], *h1 = t[1], *a2 = t[2], *h2 = t[3], *a3 = t[4], *h4 = t[5], *a5 = t[6], *h5 = t[7], *g5 = t[8], *g3 = t[9], *g2 = t[10], *g1 = t[11];
+    float* gstats = (float*)ar.take((size_t)nseq * c.t_groups * 2 * sizeof(float));
+    const int Mp = pad16(CG), Kp = pad32(CG);
+    void* w1 = ar.take((size_t)pad16(FFN) * pad32(H) * sizeof(T));
+    void* w1T = ar.take((size_t)pad16(H) * pad32(FFN) * sizeof(T));
+    void* w2T = ar.take((size_t)pad16(FFN) * pad32(H) * sizeof(T));
+    void* cw[3], *cwT[3];
+    for (int k = 0; k < 3; ++k) {
+        cw[k] = ar.take((size_t)c.t_groups * c.t_ks * Mp * Kp * sizeof(T));
+        cwT[k] = ar.take((size_t)c.t_groups * c.t_ks * Mp * Kp * sizeof(T));
+    }
+    if (!cwT[2]) return NBSS_EUNSUPPORTED;
+    const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convB[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
+    int e;
+    if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1T, WP_LIN_DGRAD, 1, 1, H, FFN, pad16(H), pad32(FFN), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_TF_W2], w2T, WP_LIN_DGRAD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
+    for (int k = 0; k < 3; ++k) {
+        if ((e = gb_wprep<T>(lp.p[convW[k]], cw[k], WP_CONV_FWD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
+        if ((e = gb_wprep<T>(lp.p[convW[k]], cwT[k], WP_CONV_DGRAD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
+    }
+    auto tconv = [&](const void* X, const void* Wp, const float* bias, void* Y) {  // along T: rows 1 apart, position t = n % T
+        return gb_conv(X, Wp, bias, Y, N, FFN, c.t_groups, c.t_ks, 1, 1, c.T);
+    };
+    // forward chain, every pre-activation and activation kept
+    if ((e = gb_ln_fwd<T>(x, lp.p[P_TF_LN_W], lp.p[P_TF_LN_B], u, stats, N, H, st))) return e;
+    if ((e = gb_gemm<T>(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), st))) return e;
+    if ((e = gb_silu<T>(a1, h1, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(tconv(h1, cw[0], lp.p[convB[0]], a2), st))) return e;
+    if ((e = gb_silu<T>(a2, h2, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(tconv(h2, cw[1], lp.p[convB[1]], a3), st))) return e;
+    NBSS_LAUNCH((gb_gn_fwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), 8 * sizeof(float), st, (const T*)a3, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)h4, gstats, c.T, FFN, CG);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if ((e = gb_gemm<T>(tconv(h4, cw[2], lp.p[convB[2]], a5), st))) return e;
+    if ((e = gb_silu<T>(a5, h5, N * FFN, st))) return e;
+    // backward chain: g5 = da5, g3 = da3 (through the GroupNorm), g2 = da2, g1 = da1
+    if ((e = gb_gemm<T>(gb_lin(dy, H, w2T, nullptr, g5, FFN, N, FFN, H), st))) return e;
+    if ((e = gb_silu_bwd<T>(a5, g5, g5, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(tconv(g5, cwT[2], nullptr, g3), st))) return e;
+    NBSS_LAUNCH((gb_gn_bwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), (8 + 128) * sizeof(float), st, (const T*)a3, (const float*)gstats, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)g3,
+                G + param_off(c, layer, P_TF_GN_W), G + param_off(c, layer, P_TF_GN_B), c.T, FFN, CG);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    if ((e = gb_gemm<T>(tconv(g3, cwT[1], nullptr, g2), st))) return e;
+    if ((e = gb_silu_bwd<T>(a2, g2, g2, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(tconv(g2, cwT[0], nullptr, g1), st))) return e;
+    if ((e = gb_silu_bwd<T>(a1, g1, g1, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(gb_lin(g1, FFN, w1T, nullptr, du, H, N, H, FFN), st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_TF_LN_W], dy, dx, G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), N, H, st))) return e;
+    // weight gradients (every operand above is still in place: nothing was overwritten)
+    const hipStream_t gs = side_fork(sd, st);
+    if ((e = gb_wgrad_dense(c, ws, dy, H, H, h5, FFN, FFN, G + param_off(c, layer, P_TF_W2), G + param_off(c, layer, P_TF_B2), N, gs))) return e;
+    const void* cA[3] = {g2, g3, g5};
+    const void* cB[3] = {h1, h2, h4};
+    for (int k = 0; k < 3; ++k) {
+        WgradArgs wa;
+        gb_wgrad_base(wa, c, ws, N);
+        wa.groups = c.t_groups; wa.taps = c.t_ks;
+        wa.A = cA[k]; wa.lda = FFN; wa.MA = FFN; wa.B = cB[k]; wa.ldb = FFN; wa.NB = FFN;
+        wa.dW = G + param_off(c, layer, convW[k]); wa.dbias = G + param_off(c, layer, convB[k]);
+        if ((e = wgrad_launch(wa, c.dtype, gs))) return e;
+    }
+    return gb_wgrad_dense(c, ws, g1, FFN, FFN, u, H, H, G + param_off(c, layer, P_TF_W1), G + param_off(c, layer, P_TF_B1), N, gs);
+}
+
+// ---- decoder (SpatialNet.py:200,216): out = Wd x + bd; dx = Wd^T dout ---------------------------------------------------------------------
+template <class T>
+static int gb_decoder_bwd_t(const nbss_cfg& c, const float* P, float* G, const void* x, const float* dout, void* dx, void* ws, hipStream_t st) {
+    const long N = (long)c.B * c.F * c.T;
+    const int H = c.H, Co = c.C_out, CP = pad8(Co);
+    GbArena ar = gb_arena(c, ws);
+    void* dpad = ar.take(N * CP * sizeof(T));
+    void* wT = ar.take((size_t)pad16(H) * pad32(CP) * sizeof(T));
+    if (!wT) return NBSS_EUNSUPPORTED;
+    int e;
+    NBSS_LAUNCH((gb_pad_cols_kernel<T>), dim3(gb_blocks(N * CP, 1024)), dim3(256), 0, st, dout, (T*)dpad, N, Co, CP);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    // W^T as a tap_gemm weight: M = H inputs of the decoder, K = its outputs (valid Co, stored CP wide)
+    if ((e = gb_wprep<T>(P + param_off_dec_w(c), wT, WP_LIN_DGRAD, 1, 1, H, Co, pad16(H), pad32(CP), st))) return e;
+    TapGemm p = gb_lin(dpad, CP, wT, nullptr, dx, H, N, H, CP);
+    if ((e = gb_gemm<T>(p, st))) return e;
+    WgradArgs wa;
+    gb_wgrad_base(wa, c, ws, N);
+    wa.mvalid = Co;
+    wa.A = dpad; wa.lda = CP; wa.MA = CP; wa.B = x; wa.ldb = H; wa.NB = H;
+    wa.dW = G + param_off_dec_w(c); wa.dbias = G + param_off_dec_b(c);
+    return wgrad_launch(wa, c.dtype, st);
+}
+
+// ---- entry points (capi.hip dispatches here for every geometry but SpatialNet-small) ----------------------------------------------------------
+#define GB_DISPATCH(fn, ...) (c.dtype == NBSS_BF16 ? fn<bf16_t>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+int gb_fconv_bwd(const nbss_cfg& c, const float* P, float* G, int layer, int which, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd) {
+    ProfScope ps(PK_FCONV_B, st);
+    return GB_DISPATCH(gb_fconv_bwd_t, c, P, G, layer, which, x, dy, dx, ws, st, sd);
+}
+int gb_full_bwd(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd) {
+    ProfScope ps(PK_FULL_B, st);
+    return GB_DISPATCH(gb_full_bwd_t, c, P, G, layer, x, dy, dx, ws, st, sd);
+}
+int gb_mhsa_bwd(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd) {
+    ProfScope ps(PK_MHSA_B, st);
+    return GB_DISPATCH(gb_mhsa_bwd_t, c, P, G, layer, x, dy, dx, ws, st, sd);
+}
+int gb_tconvffn_bwd(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd) {
+    ProfScope ps(PK_TCF_B, st);
+    return GB_DISPATCH(gb_tconvffn_bwd_t, c, P, G, layer, x, dy, dx, ws, st, sd);
+}
+int gb_decoder_bwd(const nbss_cfg& c, const float* P, float* G, const void* x, const float* dout, void* dx, void* ws, hipStream_t st) {
+    return GB_DISPATCH(gb_decoder_bwd_t, c, P, G, x, dout, dx, ws, st);
+}

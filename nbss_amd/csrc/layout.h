@@ -222,10 +222,15 @@ NBSS_HD size_t tc_part_bytes(const nbss_cfg& c) {
                ? (size_t)c.B * c.F * (5 * c.FFN * sizeof(float) + (size_t)3 * c.FFN * (c.FFN / c.t_groups) * c.t_ks * 2)
                : 0;
 }
+// operand regions ([N][FFN] tensors of the stream dtype) behind the statistics: 8 for the fused backward kernels of the small geometry; the generic
+// backward (gbwd.hip) keeps every intermediate of a block: the T-ConvFFN's 12 + LN output / gradient + re-laid weights
+NBSS_HD size_t ws_nops(const nbss_cfg& c) { return c.H == 96 ? 8 : 16; }
+// ... plus room for that path's re-laid weights (the LinearGroup pair at F = 272 is 10 MB in fp32), independent of the token count
+NBSS_HD size_t ws_wprep_bytes(const nbss_cfg& c) { return c.H == 96 ? 0 : (size_t)16 << 20; }
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
-    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) +
+    return ws_align(N * 2 * sizeof(float)) + ws_nops(c) * ws_align(N * c.FFN * esz) + ws_wprep_bytes(c) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) +
            ws_align(fc_part_bytes(c)) + ws_align(tc_part_bytes(c)) + 256;
 }
 // attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32
@@ -240,7 +245,7 @@ NBSS_HD size_t mhsa_save_bytes(const nbss_cfg& c) {
 // per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands
 NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
-    return ws_align(N * 2 * sizeof(float)) + 8 * ws_align(N * c.FFN * esz);
+    return ws_align(N * 2 * sizeof(float)) + ws_nops(c) * ws_align(N * c.FFN * esz) + ws_wprep_bytes(c);
 }
 
 // per-workgroup partial dW tiles of the wgrad kernels live behind those

@@ -631,6 +631,7 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
 
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                   void* dx, void* ws, hipStream_t st, const Side* sd) {
+    if (c.H != MB_H) return gb_mhsa_bwd(c, P, G, layer, x, dy, dx, ws, st, sd);
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const size_t N = (size_t)c.B * c.F * c.T;
     float* stats = (float*)ws;

@@ -189,15 +189,26 @@ struct PackTable {
     int skip[NUM_PACK_KINDS];
 };
 
+#define PACK_L_MAX 32
+// all layers in one launch (blockIdx.z = layer): the per-layer tables differ by constant strides — except the LinearGroup weight, which
+// layers share from full_share on (its per-layer source offsets travel explicitly)
+struct PackTableL {
+    PackTable t0;  // layer 0
+    long long src_stride, dst_stride;
+    long long full_src[PACK_L_MAX];
+};
+
 template <class T>
-__global__ void pack_kernel(nbss_cfg c, PackTable tb, const float* __restrict__ P, T* __restrict__ out) {
-    const int kind = blockIdx.y;
-    if (tb.skip[kind]) return;
+__global__ void pack_kernel(nbss_cfg c, PackTableL tb, const float* __restrict__ P, T* __restrict__ out) {
+    const int kind = blockIdx.y, layer = blockIdx.z;
+    const bool global = pack_is_global(kind);
+    if (tb.t0.skip[kind] || (global && layer != 0)) return;
     const PackGeom g = pack_geom(c, kind);
     const int64_t n = (int64_t)g.NB * g.MT * g.KS * 512;
-    T* dst = out + tb.dst[kind];
-    const float* W = P + tb.src[kind];
-    const float* W2 = P + (tb.src2[kind] >= 0 ? tb.src2[kind] : 0);
+    T* dst = out + tb.t0.dst[kind] + (global ? 0 : layer * tb.dst_stride);
+    const bool full = kind == K_FULL || kind == K_FULL_T;
+    const float* W = P + (full ? tb.full_src[layer] : tb.t0.src[kind] + (global ? 0 : layer * tb.src_stride));
+    const float* W2 = P + (tb.t0.src2[kind] >= 0 ? tb.t0.src2[kind] + layer * tb.src_stride : 0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t r = e >> 9;
@@ -209,10 +220,9 @@ __global__ void pack_kernel(nbss_cfg c, PackTable tb, const float* __restrict__ 
 }
 
 int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipStream_t stream) {
-    dim3 grid(16, NUM_PACK_KINDS), block(256);
     const bool small = c.H == 96 && c.FFN == 192 && c.SQ == 8 && c.heads == 4;
     ProfScope ps(PK_PACK, stream);
-    for (int layer = 0; layer < c.L; ++layer) {
+    auto table = [&](int layer) {
         PackTable tb;
         for (int k = 0; k < NUM_PACK_KINDS; ++k) {
             // (geometries other than SpatialNet-small are forward only: their backward fragment kinds are never read)
@@ -221,10 +231,37 @@ int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipSt
             tb.src2[k] = pack_src2_base(c, k, layer);
             tb.dst[k] = pack_off(c, layer, k);
         }
+        return tb;
+    };
+    // layers in launches of at most PACK_L_MAX (one launch for every shipped configuration: 8 / 12 layers; it was one launch per layer,
+    // 8 x 23 us of a 6 ms training step at batch 2).  The strides are a property of layout.h: checked, not assumed — a layout that is not
+    // uniform falls back to one launch per layer
+    const long long sstride = c.L > 1 ? pack_src_base(c, K_FC1, 1) - pack_src_base(c, K_FC1, 0) : 0, dstride = pack_layer_numel(c);
+    bool uniform = true;
+    const PackTable first = table(0);
+    for (int l = 1; l < c.L && uniform; ++l) {
+        const PackTable t = table(l);
+        for (int k = 0; k < NUM_PACK_KINDS; ++k) {
+            if (pack_is_global(k) || first.skip[k]) continue;
+            const bool full = k == K_FULL || k == K_FULL_T;
+            if ((!full && t.src[k] != first.src[k] + l * sstride) || t.dst[k] != first.dst[k] + l * dstride ||
+                (t.src2[k] >= 0 && t.src2[k] != first.src2[k] + l * sstride))
+                uniform = false;
+        }
+    }
+    const int chunk = uniform ? PACK_L_MAX : 1;
+    for (int l0 = 0; l0 < c.L; l0 += chunk) {
+        const int nl = c.L - l0 < chunk ? c.L - l0 : chunk;
+        PackTableL tl;
+        tl.t0 = table(l0);
+        tl.src_stride = sstride;
+        tl.dst_stride = dstride;
+        for (int l = 0; l < nl; ++l) tl.full_src[l] = pack_src_base(c, K_FULL, l0 + l);
+        dim3 grid(16, NUM_PACK_KINDS, nl), block(256);
         if (c.dtype == NBSS_BF16)
-            NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, tb, params, (bf16_t*)packed);
+            NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, tl, params, (bf16_t*)packed);
         else
-            NBSS_LAUNCH((pack_kernel<float>), grid, block, 0, stream, c, tb, params, (float*)packed);
+            NBSS_LAUNCH((pack_kernel<float>), grid, block, 0, stream, c, tl, params, (float*)packed);
         int e = NBSS_CHECK_LAUNCH();
         if (e) return e;
     }

@@ -10,6 +10,7 @@
 // the end).  sd == nullptr (the per-block C entry points, NBSS_SIDE_STREAM=0, the host emulator): everything stays in order on one stream.
 #pragma once
 #include "launch.h"
+#include "../../include/nbss_hip.h"
 
 #ifdef NBSS_EMU
 struct Side { hipStream_t gs; };
@@ -34,3 +35,10 @@ struct SeqTail {
     int n;           // sequences of the tail launch (the last n of B F)
     hipStream_t ts;  // its stream
 };
+
+// gbwd.hip: geometry-generic backward (every geometry but SpatialNet-small)
+int gb_fconv_bwd(const nbss_cfg& c, const float* P, float* G, int layer, int which, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd);
+int gb_full_bwd(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd);
+int gb_mhsa_bwd(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd);
+int gb_tconvffn_bwd(const nbss_cfg& c, const float* P, float* G, int layer, const void* x, const void* dy, void* dx, void* ws, hipStream_t st, const Side* sd);
+int gb_decoder_bwd(const nbss_cfg& c, const float* P, float* G, const void* x, const float* dout, void* dx, void* ws, hipStream_t st);

@@ -1159,6 +1159,7 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,
                       void* dx, void* ws, hipStream_t st, const Side* sd) {
+    if (c.H != TF_H) return gb_tconvffn_bwd(c, P, G, layer, x, dy, dx, ws, st, sd);
     if (tsave && c.dtype == NBSS_BF16) return tconvffn_bwd_saved(c, P, G, packed, layer, x, dy, const_cast<void*>(tsave), dx, ws, st, sd);
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     // workspace: stats [N][2] f32 | h1 h2 h4 h5 da1 da2 da3 da5, each [N][FFN] of the stream dtype

@@ -35,7 +35,7 @@ class SpatialNetEngine:
         n = lib.nbss_param_count(C.byref(cfg0))
         if n <= 0:
             raise NbssError("this SpatialNet configuration has no HIP kernels in this build: SpatialNet-small (96 / 192 / squeeze 8, training + inference) "
-                            "and SpatialNet-large (192 / 384 / squeeze 16, inference only), 4 heads, conv groups (8, 8), kernel sizes (5, 3)")
+                            "and SpatialNet-large (192 / 384 / squeeze 16, inference + the generic backward), 4 heads, conv groups (8, 8), kernel sizes (5, 3)")
         self.table = param_table(lib, cfg0)
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros_like(self.params)
