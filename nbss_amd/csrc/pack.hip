@@ -193,9 +193,12 @@ struct PackTable {
 // all layers in one launch (blockIdx.z = layer): the per-layer tables differ by constant strides — except the LinearGroup weight, which
 // layers share from full_share on (its per-layer source offsets travel explicitly)
 struct PackTableL {
-    PackTable t0;  // layer 0
-    long long src_stride, dst_stride;
-    long long full_src[PACK_L_MAX];
+    PackTable t0;  // first layer of the launch
+    long long dst_stride;
+    // source offset of layer l relative to the first: lbase[l] for the parameters in front of the LinearGroup weight in a layer's block,
+    // lbase[l] + ladj[l] behind it (layers beyond full_share do not own one: their blocks are shorter), full_src[l] for the LinearGroup itself
+    long long lbase[PACK_L_MAX], ladj[PACK_L_MAX], full_src[PACK_L_MAX];
+    int cls[NUM_PACK_KINDS];
 };
 
 template <class T>
@@ -207,8 +210,9 @@ __global__ void pack_kernel(nbss_cfg c, PackTableL tb, const float* __restrict__
     const int64_t n = (int64_t)g.NB * g.MT * g.KS * 512;
     T* dst = out + tb.t0.dst[kind] + (global ? 0 : layer * tb.dst_stride);
     const bool full = kind == K_FULL || kind == K_FULL_T;
-    const float* W = P + (full ? tb.full_src[layer] : tb.t0.src[kind] + (global ? 0 : layer * tb.src_stride));
-    const float* W2 = P + (tb.t0.src2[kind] >= 0 ? tb.t0.src2[kind] + layer * tb.src_stride : 0);
+    const long long rel = global ? 0 : tb.lbase[layer] + (tb.cls[kind] ? tb.ladj[layer] : 0);
+    const float* W = P + (full ? tb.full_src[layer] : tb.t0.src[kind] + rel);
+    const float* W2 = P + (tb.t0.src2[kind] >= 0 ? tb.t0.src2[kind] + rel : 0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t r = e >> 9;
@@ -233,30 +237,48 @@ int pack_params_impl(const nbss_cfg& c, const float* params, void* packed, hipSt
         }
         return tb;
     };
-    // layers in launches of at most PACK_L_MAX (one launch for every shipped configuration: 8 / 12 layers; it was one launch per layer,
-    // 8 x 23 us of a 6 ms training step at batch 2).  The strides are a property of layout.h: checked, not assumed — a layout that is not
-    // uniform falls back to one launch per layer
-    const long long sstride = c.L > 1 ? pack_src_base(c, K_FC1, 1) - pack_src_base(c, K_FC1, 0) : 0, dstride = pack_layer_numel(c);
-    bool uniform = true;
+    // all layers in one launch (it was one launch per layer: 8 x 23 us of a 6 ms training step at batch 2).  The relative offsets are a
+    // property of layout.h: checked, not assumed — anything else (or more than PACK_L_MAX layers) falls back to one launch per layer
+    const long long dstride = pack_layer_numel(c);
+    bool uniform = c.L <= PACK_L_MAX;
     const PackTable first = table(0);
-    for (int l = 1; l < c.L && uniform; ++l) {
+    PackTableL tl;
+    for (int k = 0; k < NUM_PACK_KINDS; ++k) tl.cls[k] = 0;
+    for (int l = 0; l < c.L && uniform; ++l) {
         const PackTable t = table(l);
+        tl.lbase[l] = t.src[K_FC1] - first.src[K_FC1];
+        tl.ladj[l] = (t.src[K_TF_W2] - first.src[K_TF_W2]) - tl.lbase[l];
+        tl.full_src[l] = t.src[K_FULL];
         for (int k = 0; k < NUM_PACK_KINDS; ++k) {
-            if (pack_is_global(k) || first.skip[k]) continue;
-            const bool full = k == K_FULL || k == K_FULL_T;
-            if ((!full && t.src[k] != first.src[k] + l * sstride) || t.dst[k] != first.dst[k] + l * dstride ||
-                (t.src2[k] >= 0 && t.src2[k] != first.src2[k] + l * sstride))
+            if (pack_is_global(k) || first.skip[k] || k == K_FULL || k == K_FULL_T) continue;
+            const long long rel = t.src[k] - first.src[k];
+            if (rel == tl.lbase[l] && (!tl.cls[k] || tl.ladj[l] == 0)) {
+            } else if (rel == tl.lbase[l] + tl.ladj[l]) {
+                tl.cls[k] = 1;
+            } else {
                 uniform = false;
+            }
+            if (t.dst[k] != first.dst[k] + l * dstride || (t.src2[k] >= 0 && t.src2[k] - first.src2[k] != rel)) uniform = false;
         }
     }
-    const int chunk = uniform ? PACK_L_MAX : 1;
+    // (a kind classified "in front" on an early layer and "behind" later cannot happen: the class is a property of the parameter order; a
+    //  second pass confirms every layer against the final classes)
+    for (int l = 0; l < c.L && uniform; ++l) {
+        const PackTable t = table(l);
+        for (int k = 0; k < NUM_PACK_KINDS; ++k) {
+            if (pack_is_global(k) || first.skip[k] || k == K_FULL || k == K_FULL_T) continue;
+            if (t.src[k] - first.src[k] != tl.lbase[l] + (tl.cls[k] ? tl.ladj[l] : 0)) uniform = false;
+        }
+    }
+    const int chunk = uniform ? c.L : 1;
     for (int l0 = 0; l0 < c.L; l0 += chunk) {
         const int nl = c.L - l0 < chunk ? c.L - l0 : chunk;
-        PackTableL tl;
+        if (!uniform) {  // one launch per layer: the layer's own table, no relative offsets
+            tl.lbase[0] = 0; tl.ladj[0] = 0;
+            tl.full_src[0] = pack_src_base(c, K_FULL, l0);
+        }
         tl.t0 = table(l0);
-        tl.src_stride = sstride;
         tl.dst_stride = dstride;
-        for (int l = 0; l < nl; ++l) tl.full_src[l] = pack_src_base(c, K_FULL, l0 + l);
         dim3 grid(16, NUM_PACK_KINDS, nl), block(256);
         if (c.dtype == NBSS_BF16)
             NBSS_LAUNCH((pack_kernel<bf16_t>), grid, block, 0, stream, c, tl, params, (bf16_t*)packed);
