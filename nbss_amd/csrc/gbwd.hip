@@ -67,7 +67,45 @@ struct TapGemm {
     int taps, center, shift;  // tap reads row n + (tap - center) * shift ...
     int pos_div, pos_len;     // ... valid while 0 <= (n / pos_div) % pos_len + tap - center < pos_len
     int xact, yact;           // SiLU on the loaded X / on the result
+    void* Y2;                 // optional second output, layout of Y: SiLU(result) next to the pre-activation (a and h of a forward step in one pass)
+    const void* Dact;         // optional pre-activation tensor, layout of Y: the result is multiplied by SiLU'(Dact) (dh -> da of a backward step)
 };
+
+// epilogue of one row: 4 output tiles in C layout (lane: outputs 16 i + 4 g4 + r of its row)
+template <class T>
+NBSS_DEV void gb_tap_store(const TapGemm& p, const f32x4 (&acc)[4], long row, int g, int mc, int g4) {
+    const size_t ro = (size_t)row * p.ldy + p.ycol + (size_t)g * p.ygs;
+    T* yr = reinterpret_cast<T*>(p.Y) + ro;
+    T* y2 = p.Y2 ? reinterpret_cast<T*>(p.Y2) + ro : nullptr;
+    const T* da = p.Dact ? reinterpret_cast<const T*>(p.Dact) + ro : nullptr;
+    const T* rr = p.R ? reinterpret_cast<const T*>(p.R) + (size_t)row * p.ldr + p.ycol + (size_t)g * p.ygs : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m0 = (mc * 4 + i) * 16 + 4 * g4;
+        if (m0 >= p.Mg) continue;
+        float o[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[i][r];
+            const bool ok = m0 + r < p.Mg;
+            if (p.bias && ok) v += p.bias[(size_t)g * p.bgs + m0 + r];
+            if (p.yact) v = silu_f(v);
+            if (da && ok) v *= dsilu_f(load1(da + m0 + r));
+            if (rr && ok) v = load1(rr + m0 + r) + round_to(v, yr);
+            o[r] = v;
+            o2[r] = silu_f(round_to(v, yr));  // (the activation of the STORED pre-activation: what a separate pass over Y would compute)
+        }
+        if (m0 + 3 < p.Mg) {
+            store4(yr + m0, o[0], o[1], o[2], o[3]);
+            if (y2) store4(y2 + m0, o2[0], o2[1], o2[2], o2[3]);
+        } else {
+            for (int r = 0; r < 4 && m0 + r < p.Mg; ++r) {
+                store1(yr + m0 + r, o[r]);
+                if (y2) store1(y2 + m0 + r, o2[r]);
+            }
+        }
+    }
+}
 
 // One wave = 16 rows (the MFMA N dimension) x up to 64 outputs (4 tiles of 16) of one group; operands come straight from global memory
 // (B: 8 contiguous inputs of the lane's row; A: 8 contiguous prepared weights of the lane's output row — L2-resident, every wave reads
@@ -110,25 +148,69 @@ __global__ __launch_bounds__(GB_THREADS) void gb_tap_gemm_kernel(TapGemm p) {
             }
         }
     }
-    if (!rv) return;
-    T* yr = reinterpret_cast<T*>(p.Y) + (size_t)row * p.ldy + p.ycol + (size_t)g * p.ygs;
-    const T* rr = p.R ? reinterpret_cast<const T*>(p.R) + (size_t)row * p.ldr + p.ycol + (size_t)g * p.ygs : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m0 = (mc * 4 + i) * 16 + 4 * g4;
-        if (m0 >= p.Mg) continue;
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[i][r];
-            if (p.bias && m0 + r < p.Mg) v += p.bias[(size_t)g * p.bgs + m0 + r];
-            if (p.yact) v = silu_f(v);
-            if (rr && m0 + r < p.Mg) v = load1(rr + m0 + r) + round_to(v, yr);
-            o[r] = v;
+    if (rv) gb_tap_store<T>(p, acc, row, g, mc, g4);
+}
+
+// The same contraction with the weights of the workgroup's (group, 64-output chunk) staged in LDS for all taps and GT_R row tiles per wave:
+// without it every wave re-read its 64 x K weight block from L2 for 16 rows of work (25.8 % of the large train step).  Row stride of the image:
+// Kp + 8 elements (a multiple of 16 bytes that is not a multiple of 128: the 16 rows of a fragment read spread over the banks).
+#define GT_R 4
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_tap_gemm_lds_kernel(TapGemm p) {
+    NBSS_LDS(smem);
+    T* Wl = reinterpret_cast<T*>(smem);  // [taps][64][Kp + 8]
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const int mchunks = cdiv(p.Mp, 64);
+    const int g = blockIdx.y / mchunks, mc = blockIdx.y % mchunks;
+    const int LDW = p.Kp + 8;
+    const int mrows = p.Mp - mc * 64 < 64 ? p.Mp - mc * 64 : 64;  // rows of this chunk (a multiple of 16)
+    {
+        const T* Wg = reinterpret_cast<const T*>(p.W) + (size_t)g * p.taps * p.Mp * p.Kp;
+        constexpr int VE = 16 / sizeof(T);  // elements per 16-byte piece
+        const int vpr = p.Kp / VE, nv = p.taps * mrows * vpr;
+        for (int v = threadIdx.x; v < nv; v += GB_THREADS) {
+            const int col = (v % vpr) * VE, r = (v / vpr) % mrows, tap = v / (vpr * mrows);
+            *reinterpret_cast<u32x4*>(Wl + ((size_t)tap * 64 + r) * LDW + col) =
+                *reinterpret_cast<const u32x4*>(Wg + ((size_t)tap * p.Mp + mc * 64 + r) * p.Kp + col);
         }
-        if (m0 + 3 < p.Mg) store4(yr + m0, o[0], o[1], o[2], o[3]);
-        else
-            for (int r = 0; r < 4 && m0 + r < p.Mg; ++r) store1(yr + m0 + r, o[r]);
+    }
+    __syncthreads();
+    const T* X = reinterpret_cast<const T*>(p.X);
+    for (int rt = 0; rt < GT_R; ++rt) {
+        const long row = (((long)blockIdx.x * (GB_THREADS / 64) + w) * GT_R + rt) * 16 + l15;
+        if ((row - l15) >= p.rows) break;  // (wave-uniform: the tile's first row)
+        const bool rv = row < p.rows;
+        const int pos = rv ? (int)((row / p.pos_div) % p.pos_len) : 0;
+        f32x4 acc[4] = {F32X4_ZERO, F32X4_ZERO, F32X4_ZERO, F32X4_ZERO};
+        for (int tap = 0; tap < p.taps; ++tap) {
+            const int d = tap - p.center;
+            const bool valid = rv && pos + d >= 0 && pos + d < p.pos_len;
+            const T* xr = X + (size_t)(valid ? row + (long)d * p.shift : 0) * p.ldx + p.xcol + (size_t)g * p.xgs;
+            const T* wt = Wl + (size_t)tap * 64 * LDW + (size_t)l15 * LDW;
+#pragma unroll 2
+            for (int k0 = 0; k0 < p.Kp; k0 += 32) {
+                const int kk = k0 + 8 * g4;
+                Frag<T> b;
+                if (valid && kk < p.Kg) {
+                    frag_load(b, xr + kk);
+                    if (p.xact) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) frag_set(b, j, silu_f(frag_get(b, j)));
+                    }
+                } else {
+                    frag_zero(b);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i * 16 < mrows) {
+                        Frag<T> a;
+                        frag_load(a, wt + (size_t)i * 16 * LDW + kk);
+                        acc[i] = mma(a, b, acc[i]);
+                    }
+                }
+            }
+        }
+        if (rv) gb_tap_store<T>(p, acc, row, g, mc, g4);
     }
 }
 
@@ -227,15 +309,170 @@ __global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd_kernel(const T* __restri
     }
 }
 
+
+// ---- the same three row kernels with 16 lanes per row (4 rows per wave; lane = 4 contiguous channels of every 64: 8-byte pieces, 128 contiguous
+// bytes per row and step) for widths that are multiples of 64: a whole wave per 192-wide row spent its time in six-step wave reductions
+// (LayerNorm backward: 144 us per launch for a 50 MB tensor)
+template <class T, int NQ>
+__global__ __launch_bounds__(GB_THREADS) void gb_ln_fwd4_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                T* __restrict__ u, float* __restrict__ stats, long N) {
+    constexpr int C = 64 * NQ;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 4;
+    for (long n0 = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 4; n0 < N; n0 += nw) {  // (whole-wave loop: row_sum16 is a wave collective)
+        const long n = n0 + g4;
+        const bool v_ = n < N;
+        float v[NQ][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (v_) load4(x + n * C + 64 * i + 4 * l15, v[i]);
+            else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = row_sum16(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[i][r] - mean;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(row_sum16(q) * (1.0f / C) + 1e-5f);
+        if (v_ && l15 == 0) {
+            stats[2 * n] = mean;
+            stats[2 * n + 1] = rstd;
+        }
+        if (u && v_) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int c = 64 * i + 4 * l15;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mean) * rstd * gamma[c + r] + beta[c + r];
+                store4(u + n * C + c, o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+template <class T, int NQ>
+__global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd4_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma, const T* __restrict__ dy, T* __restrict__ dx,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long N) {
+    constexpr int C = 64 * NQ;
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [2][C]
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    for (int i = threadIdx.x; i < 2 * C; i += GB_THREADS) red[i] = 0.f;
+    __syncthreads();
+    float dg[NQ][4], db[NQ][4], gm[NQ][4];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dg[i][r] = db[i][r] = 0.f;
+            gm[i][r] = gamma[64 * i + 4 * l15 + r];
+        }
+    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 4;
+    for (long n0 = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 4; n0 < N; n0 += nw) {
+        const long n = n0 + g4;
+        const bool v_ = n < N;
+        const float mean = v_ ? stats[2 * n] : 0.f, rstd = v_ ? stats[2 * n + 1] : 0.f;
+        float xh[NQ][4], g[NQ][4];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            float xv[4], dv[4];
+            if (v_) {
+                load4(x + n * C + 64 * i + 4 * l15, xv);
+                load4(du + n * C + 64 * i + 4 * l15, dv);
+            } else {
+                xv[0] = xv[1] = xv[2] = xv[3] = mean;
+                dv[0] = dv[1] = dv[2] = dv[3] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[i][r] = (xv[r] - mean) * rstd;
+                dg[i][r] += dv[r] * xh[i][r];
+                db[i][r] += dv[r];
+                g[i][r] = dv[r] * gm[i][r];
+                m1 += g[i][r];
+                m2 += g[i][r] * xh[i][r];
+            }
+        }
+        m1 = row_sum16(m1) * (1.0f / C);
+        m2 = row_sum16(m2) * (1.0f / C);
+        if (v_) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int c = 64 * i + 4 * l15;
+                float yv[4], o[4];
+                load4(dy + n * C + c, yv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = yv[r] + rstd * (g[i][r] - m1 - xh[i][r] * m2);
+                store4(dx + n * C + c, o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            atomicAdd(&red[64 * i + 4 * l15 + r], dg[i][r]);
+            atomicAdd(&red[C + 64 * i + 4 * l15 + r], db[i][r]);
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += GB_THREADS) {
+        atomicAdd(dgamma + c, red[c]);
+        atomicAdd(dbeta + c, red[C + c]);
+    }
+}
+template <class T, int NQ>
+__global__ __launch_bounds__(GB_THREADS) void gb_prelu_bwd4_kernel(const T* __restrict__ a, const T* __restrict__ dy, const float* __restrict__ alpha,
+                                                                   T* __restrict__ da, float* __restrict__ dalpha, long N) {
+    constexpr int C = 64 * NQ;
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [C]
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    for (int i = threadIdx.x; i < C; i += GB_THREADS) red[i] = 0.f;
+    __syncthreads();
+    float ds[NQ][4], al[NQ][4];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ds[i][r] = 0.f;
+            al[i][r] = alpha[64 * i + 4 * l15 + r];
+        }
+    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 4;
+    for (long n = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 4 + g4; n < N; n += nw) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c = 64 * i + 4 * l15;
+            float av[4], dv[4], o[4];
+            load4(a + n * C + c, av);
+            load4(dy + n * C + c, dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = av[r] > 0.f ? dv[r] : dv[r] * al[i][r];
+                if (av[r] <= 0.f) ds[i][r] += dv[r] * av[r];
+            }
+            store4(da + n * C + c, o[0], o[1], o[2], o[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&red[64 * i + 4 * l15 + r], ds[i][r]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += GB_THREADS) atomicAdd(dalpha + c, red[c]);
+}
+
 // gout = gin * SiLU'(a)   (dense tensors; gout may be gin)
 template <class T>
 __global__ void gb_silu_bwd_kernel(const T* __restrict__ a, const T* gin, T* gout, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) store1(gout + i, load1(gin + i) * dsilu_f(load1(a + i)));
-}
-// h = SiLU(a)
-template <class T>
-__global__ void gb_silu_kernel(const T* __restrict__ a, T* __restrict__ h, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) store1(h + i, silu_f(load1(a + i)));
 }
 // PReLU: y = x + (a > 0 ? a : alpha a) is the block output; da = dy (a > 0 ? 1 : alpha[c]), dalpha[c] += sum dy min(a, 0)
 template <class T>
@@ -365,25 +602,34 @@ __global__ __launch_bounds__(GB_THREADS) void gb_gn_bwd_kernel(const T* __restri
         for (int i = 0; i < GB_THREADS / 64; ++i) s += red[i];
         return s;
     };
-    float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
-        const int c = e % CG;
-        const size_t o = (size_t)(e / CG) * C + c;
-        const float xh = (load1(ab + o) - mean) * rstd, gm = gamma[g * CG + c];
-        const float d4 = load1(db + o) * dsilu_f(xh * gm + beta[g * CG + c]);
-        atomicAdd(&cg_w[c], d4 * xh);
-        atomicAdd(&cg_b[c], d4);
-        s1 += d4 * gm;
-        s2 += d4 * gm * xh;
+    // thread = (frame lane tl, channel ch): the channel's affine sums stay in registers over the frames (one LDS atomic per thread at the end;
+    // as one LDS atomic per ELEMENT on 48 addresses the kernel took 531 us per launch)
+    const int TPC = GB_THREADS / CG, tl = threadIdx.x / CG, ch = threadIdx.x % CG;
+    const bool act = tl < TPC;
+    const float gm = act ? gamma[g * CG + ch] : 0.f, bt = act ? beta[g * CG + ch] : 0.f;
+    float s1 = 0.f, s2 = 0.f, dw = 0.f, dbv = 0.f;
+    if (act) {
+        for (int t = tl; t < Tn; t += TPC) {
+            const size_t o = (size_t)t * C + ch;
+            const float xh = (load1(ab + o) - mean) * rstd;
+            const float d4 = load1(db + o) * dsilu_f(xh * gm + bt);
+            dw += d4 * xh;
+            dbv += d4;
+            s1 += d4 * gm;
+            s2 += d4 * gm * xh;
+        }
+        atomicAdd(&cg_w[ch], dw);
+        atomicAdd(&cg_b[ch], dbv);
     }
     const float m1 = block_sum(s1) / M;
     const float m2 = block_sum(s2) / M;
-    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
-        const int c = e % CG;
-        const size_t o = (size_t)(e / CG) * C + c;
-        const float xh = (load1(ab + o) - mean) * rstd, gm = gamma[g * CG + c];
-        const float d4 = load1(db + o) * dsilu_f(xh * gm + beta[g * CG + c]);
-        store1(db + o, rstd * (d4 * gm - m1 - xh * m2));
+    if (act) {
+        for (int t = tl; t < Tn; t += TPC) {
+            const size_t o = (size_t)t * C + ch;
+            const float xh = (load1(ab + o) - mean) * rstd;
+            const float d4 = load1(db + o) * dsilu_f(xh * gm + bt);
+            store1(db + o, rstd * (d4 * gm - m1 - xh * m2));
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < CG; c += GB_THREADS) {
@@ -677,6 +923,14 @@ static int pad8(int v) { return (v + 7) & ~7; }
 template <class T>
 static int gb_gemm(const TapGemm& p, hipStream_t st) {
     if (p.Kg % 8 || p.ldx % 8 || p.xcol % 8 || p.xgs % 8 || p.ycol % 4 || p.ygs % 4 || p.ldy % 4) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)p.taps * 64 * (p.Kp + 8) * sizeof(T);
+    if (lds <= 150 * 1024) {
+        int e = NBSS_SET_MAX_LDS((gb_tap_gemm_lds_kernel<T>), lds);
+        if (e) return e;
+        dim3 grid(cdiv(p.rows, 64 * GT_R), p.groups * cdiv(p.Mp, 64));
+        NBSS_LAUNCH((gb_tap_gemm_lds_kernel<T>), grid, dim3(GB_THREADS), lds, st, p);
+        return NBSS_CHECK_LAUNCH();
+    }
     dim3 grid(cdiv(p.rows, 64), p.groups * cdiv(p.Mp, 64));
     NBSS_LAUNCH((gb_tap_gemm_kernel<T>), grid, dim3(GB_THREADS), 0, st, p);
     return NBSS_CHECK_LAUNCH();
@@ -690,7 +944,7 @@ static TapGemm gb_lin(const void* X, int ldx, const void* Wp, const float* bias,
     p.ldy = ldy; p.ycol = 0; p.ygs = 0; p.ldr = 0;
     p.groups = 1; p.Mg = M; p.Kg = K; p.Mp = pad16(M); p.Kp = pad32(K); p.bgs = 0;
     p.taps = 1; p.center = 0; p.shift = 0; p.pos_div = 1; p.pos_len = 1 << 30;
-    p.xact = 0; p.yact = 0;
+    p.xact = 0; p.yact = 0; p.Y2 = nullptr; p.Dact = nullptr;
     return p;
 }
 // grouped convolution along one axis of the [B][F][T] token grid on [rows][C] tensors (C = groups * CG in and out)
@@ -706,7 +960,9 @@ static TapGemm gb_conv(const void* X, const void* Wp, const float* bias, void* Y
 template <class T>
 static int gb_ln_fwd(const void* x, const float* gamma, const float* beta, void* u, float* stats, long N, int C, hipStream_t st) {
     if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
-    NBSS_LAUNCH((gb_ln_fwd_kernel<T>), dim3(gb_blocks(N, 4)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N, C);
+    if (C == 192) NBSS_LAUNCH((gb_ln_fwd4_kernel<T, 3>), dim3(gb_blocks(N, 16)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N);
+    else if (C == 384) NBSS_LAUNCH((gb_ln_fwd4_kernel<T, 6>), dim3(gb_blocks(N, 16)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N);
+    else NBSS_LAUNCH((gb_ln_fwd_kernel<T>), dim3(gb_blocks(N, 4)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N, C);
     return NBSS_CHECK_LAUNCH();
 }
 template <class T>
@@ -714,17 +970,18 @@ static int gb_ln_bwd(const void* du, const void* x, const float* stats, const fl
                      int C, hipStream_t st) {
     if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
     const int blocks = gb_blocks(N, 4 * 16) < 1024 ? gb_blocks(N, 4 * 16) : 1024;  // >= 16 rows per wave: the affine sums end in C atomics per workgroup
-    NBSS_LAUNCH((gb_ln_bwd_kernel<T>), dim3(blocks), dim3(GB_THREADS), 2 * 64 * GB_CPL * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N, C);
+    const int blocks4 = gb_blocks(N, 16 * 8) < 1024 ? gb_blocks(N, 16 * 8) : 1024;  // (>= 8 rows per 16-lane group)
+    if (C == 192)
+        NBSS_LAUNCH((gb_ln_bwd4_kernel<T, 3>), dim3(blocks4), dim3(GB_THREADS), 2 * 192 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
+    else if (C == 384)
+        NBSS_LAUNCH((gb_ln_bwd4_kernel<T, 6>), dim3(blocks4), dim3(GB_THREADS), 2 * 384 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
+    else
+        NBSS_LAUNCH((gb_ln_bwd_kernel<T>), dim3(blocks), dim3(GB_THREADS), 2 * 64 * GB_CPL * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N, C);
     return NBSS_CHECK_LAUNCH();
 }
 template <class T>
 static int gb_silu_bwd(const void* a, const void* gin, void* gout, long n, hipStream_t st) {
     NBSS_LAUNCH((gb_silu_bwd_kernel<T>), dim3(gb_blocks(n, 1024)), dim3(256), 0, st, (const T*)a, (const T*)gin, (T*)gout, n);
-    return NBSS_CHECK_LAUNCH();
-}
-template <class T>
-static int gb_silu(const void* a, void* h, long n, hipStream_t st) {
-    NBSS_LAUNCH((gb_silu_kernel<T>), dim3(gb_blocks(n, 1024)), dim3(256), 0, st, (const T*)a, (T*)h, n);
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -734,12 +991,18 @@ static void gb_wgrad_base(WgradArgs& a, const nbss_cfg& c, void* ws, long Ntok) 
     a.Ntok = (int)Ntok; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = 1;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
 }
-// dW[M][K] += A^T B over the rows, dbias += colsum(A); M in slices of at most 256 rows (wgrad.hip stages one A image per workgroup)
+// dW[M][K] += A^T B over the rows, dbias += colsum(A).  M in slices whose tiles fit one workgroup of wgrad.hip's transposing-read kernel
+// (<= 112 tiles of 16 x 16, <= 7 staging slots): as one 576 x 192 problem the in_proj gradient took the column-range fallback with its
+// atomic flush (17.8 % of the large train step for the five dense problems of a layer)
 static int gb_wgrad_dense(const nbss_cfg& c, void* ws, const void* A, int lda, int M, const void* B, int ldb, int K, float* dW, float* dbias, long Ntok,
                           hipStream_t st) {
     const size_t esz = c.dtype == NBSS_BF16 ? 2 : 4;
-    for (int m0 = 0; m0 < M; m0 += 192) {
-        const int mm = M - m0 < 192 ? M - m0 : 192;
+    int mt = 112 / cdiv(K, 16);
+    if (mt > 12) mt = 12;
+    while (mt > 1 && cdiv(mt * 16, 64) + cdiv(K, 64) > 7) --mt;
+    const int ms = mt * 16;
+    for (int m0 = 0; m0 < M; m0 += ms) {
+        const int mm = M - m0 < ms ? M - m0 : ms;
         WgradArgs a;
         gb_wgrad_base(a, c, ws, Ntok);
         a.A = (const char*)A + (size_t)m0 * esz; a.lda = lda; a.MA = mm;
@@ -775,8 +1038,12 @@ static int gb_fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer
     if ((e = gb_ln_fwd<T>(x, lp.p[pLW], lp.p[pLB], u, stats, N, H, st))) return e;
     // a = conv along F (rows T apart, position f = (n / T) % F)
     if ((e = gb_gemm<T>(gb_conv(u, wf, lp.p[pB], a, N, H, c.f_groups, c.f_ks, c.T, c.T, c.F), st))) return e;
-    NBSS_LAUNCH((gb_prelu_bwd_kernel<T>), dim3(gb_blocks(N, 64) < 1024 ? gb_blocks(N, 64) : 1024), dim3(GB_THREADS), 64 * GB_CPL * sizeof(float), st, (const T*)a, (const T*)dy, lp.p[pA], (T*)da,
-                G + param_off(c, layer, pA), N, H);
+    if (H == 192)
+        NBSS_LAUNCH((gb_prelu_bwd4_kernel<T, 3>), dim3(gb_blocks(N, 16 * 8) < 1024 ? gb_blocks(N, 16 * 8) : 1024), dim3(GB_THREADS), 192 * sizeof(float), st, (const T*)a,
+                    (const T*)dy, lp.p[pA], (T*)da, G + param_off(c, layer, pA), N);
+    else
+        NBSS_LAUNCH((gb_prelu_bwd_kernel<T>), dim3(gb_blocks(N, 64) < 1024 ? gb_blocks(N, 64) : 1024), dim3(GB_THREADS), 64 * GB_CPL * sizeof(float), st, (const T*)a, (const T*)dy,
+                    lp.p[pA], (T*)da, G + param_off(c, layer, pA), N, H);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     if ((e = gb_gemm<T>(gb_conv(da, wd, nullptr, du, N, H, c.f_groups, c.f_ks, c.T, c.T, c.F), st))) return e;
     if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[pLW], dy, dx, G + param_off(c, layer, pLW), G + param_off(c, layer, pLB), N, H, st))) return e;
@@ -824,8 +1091,11 @@ static int gb_full_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer,
     if ((e = gb_wprep<T>(lp.p[P_FULL_W], w_lgT, WP_LG_DGRAD, SQ, 1, F, F, Fp16, Fp32, st))) return e;
     // forward chain
     if ((e = gb_ln_fwd<T>(x, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B], u, stats, N, H, st))) return e;
-    if ((e = gb_gemm<T>(gb_lin(u, H, w_sq, lp.p[P_SQ_B], sp, SQ, N, SQ, H), st))) return e;
-    if ((e = gb_silu<T>(sp, s, N * SQ, st))) return e;
+    {
+        TapGemm p = gb_lin(u, H, w_sq, lp.p[P_SQ_B], sp, SQ, N, SQ, H);
+        p.Y2 = s;  // s = SiLU(s_pre) in the same pass
+        if ((e = gb_gemm<T>(p, st))) return e;
+    }
     NBSS_LAUNCH((gb_sq_to_f_kernel<T>), dim3(gb_blocks(BT * SQ * FK, 1024)), dim3(256), 0, st, (const T*)s, (T*)sT, c.B, F, c.T, SQ, FK);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     auto lg = [&](const void* X, const void* Wp, const float* bias, void* Y) {
@@ -961,26 +1231,25 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
     };
     // forward chain, every pre-activation and activation kept
     if ((e = gb_ln_fwd<T>(x, lp.p[P_TF_LN_W], lp.p[P_TF_LN_B], u, stats, N, H, st))) return e;
-    if ((e = gb_gemm<T>(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), st))) return e;
-    if ((e = gb_silu<T>(a1, h1, N * FFN, st))) return e;
-    if ((e = gb_gemm<T>(tconv(h1, cw[0], lp.p[convB[0]], a2), st))) return e;
-    if ((e = gb_silu<T>(a2, h2, N * FFN, st))) return e;
+    auto with = [](TapGemm p, void* y2, const void* dact) {  // second output SiLU(Y) / result times SiLU'(dact): the activation passes ride along
+        p.Y2 = y2;
+        p.Dact = dact;
+        return p;
+    };
+    if ((e = gb_gemm<T>(with(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), h1, nullptr), st))) return e;
+    if ((e = gb_gemm<T>(with(tconv(h1, cw[0], lp.p[convB[0]], a2), h2, nullptr), st))) return e;
     if ((e = gb_gemm<T>(tconv(h2, cw[1], lp.p[convB[1]], a3), st))) return e;
     NBSS_LAUNCH((gb_gn_fwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), 8 * sizeof(float), st, (const T*)a3, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)h4, gstats, c.T, FFN, CG);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
-    if ((e = gb_gemm<T>(tconv(h4, cw[2], lp.p[convB[2]], a5), st))) return e;
-    if ((e = gb_silu<T>(a5, h5, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(with(tconv(h4, cw[2], lp.p[convB[2]], a5), h5, nullptr), st))) return e;
     // backward chain: g5 = da5, g3 = da3 (through the GroupNorm), g2 = da2, g1 = da1
-    if ((e = gb_gemm<T>(gb_lin(dy, H, w2T, nullptr, g5, FFN, N, FFN, H), st))) return e;
-    if ((e = gb_silu_bwd<T>(a5, g5, g5, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(with(gb_lin(dy, H, w2T, nullptr, g5, FFN, N, FFN, H), nullptr, a5), st))) return e;
     if ((e = gb_gemm<T>(tconv(g5, cwT[2], nullptr, g3), st))) return e;
     NBSS_LAUNCH((gb_gn_bwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), (8 + 128) * sizeof(float), st, (const T*)a3, (const float*)gstats, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)g3,
                 G + param_off(c, layer, P_TF_GN_W), G + param_off(c, layer, P_TF_GN_B), c.T, FFN, CG);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
-    if ((e = gb_gemm<T>(tconv(g3, cwT[1], nullptr, g2), st))) return e;
-    if ((e = gb_silu_bwd<T>(a2, g2, g2, N * FFN, st))) return e;
-    if ((e = gb_gemm<T>(tconv(g2, cwT[0], nullptr, g1), st))) return e;
-    if ((e = gb_silu_bwd<T>(a1, g1, g1, N * FFN, st))) return e;
+    if ((e = gb_gemm<T>(with(tconv(g3, cwT[1], nullptr, g2), nullptr, a2), st))) return e;
+    if ((e = gb_gemm<T>(with(tconv(g2, cwT[0], nullptr, g1), nullptr, a1), st))) return e;
     if ((e = gb_gemm<T>(gb_lin(g1, FFN, w1T, nullptr, du, H, N, H, FFN), st))) return e;
     if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_TF_LN_W], dy, dx, G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), N, H, st))) return e;
     // weight gradients (every operand above is still in place: nothing was overwritten)
