@@ -34,10 +34,11 @@ extern "C" {
 
 /* SpatialNet hyper-parameters: models/arch/SpatialNet.py:154-171 (ctor) + batch geometry.
  * Geometries this build has kernels for (anything else: NBSS_EUNSUPPORTED):
- *   small  H 96,  FFN 192, SQ 8,  4 heads   (configs/SpatialNet.yaml:16-24)          forward + backward
- *   large  H 192, FFN 384, SQ 16, 4 heads   (the "for large" comments of that file)  forward only (every *_bwd refuses it)
+ *   small  H 96,  FFN 192, SQ 8,  4 heads   (configs/SpatialNet.yaml:16-24)          forward + backward (fused training kernels)
+ *   large  H 192, FFN 384, SQ 16, 4 heads   (the "for large" comments of that file)  forward + backward (geometry-generic backward, csrc/gbwd.hip:
+ *                                                                                     one tensor pass per operation, every intermediate in ws)
  *   both with conv groups (8, 8), kernel sizes (5, 3), encoder kernel 5; C_in % 4 == 0, C_in / C_out <= 16.
- *   F <= 272 (n_fft 256 -> 129, n_fft 512 -> 257); fp32-stream backward: F <= 160.
+ *   F <= 272 (n_fft 256 -> 129, n_fft 512 -> 257); fp32-stream backward of the small geometry: F <= 160 (F-conv block).
  *   T <= 256 for a forward that saves state and for every backward; forward without `acts`: T <= 4096. */
 typedef struct nbss_cfg {
     int32_t B, F, T;         /* batch, frequencies (129 | 257), frames (251 for 4 s) */
@@ -124,8 +125,13 @@ int nbss_encoder_bwd(const nbss_cfg* cfg, float* grads, const void* xin, const v
  * Native sequencing of the sub-block kernels: encoder, L x [fconv1, full, fconv2, mhsa, tconvffn],
  * decoder.  xin [B,F,T,C_in] of cfg->dtype, out/dout [B,F,T,C_out] fp32.
  * acts: nbss_acts_bytes() bytes holding the 5L+1 block inputs, the L attention outputs and the L T-ConvFFN
- * saves that backward re-reads; pass NULL for inference (then ws, >= nbss_train_ws_bytes(), is used as two
- * ping-pong stream buffers).  Backward accumulates into `grads` and needs ws >= nbss_train_ws_bytes(). */
+ * saves that backward re-reads; pass NULL for inference (then ws, >= nbss_workspace_bytes() + two [B,F,T,H] stream tensors, is used
+ * as two ping-pong stream buffers behind one workspace).  Backward accumulates into `grads` and needs ws >= nbss_train_ws_bytes():
+ * one workspace per sub-block kind of a layer + three gradient stream buffers — the walk launches everything that only produces
+ * parameter gradients on a library-owned second stream (fork / done / join events; csrc/side.h), overlapping it with the next
+ * sub-blocks' data-gradient kernels, and the copies keep those launches' operands alive.  When a backward call returns, the
+ * caller's stream has been made to wait for that second stream: work enqueued on `stream` afterwards (the gradient all-reduce,
+ * the optimizer) sees every gradient of the range.  NBSS_SIDE_STREAM=0 in the environment keeps everything on `stream`. */
 int64_t nbss_acts_bytes(const nbss_cfg* cfg);
 int64_t nbss_train_ws_bytes(const nbss_cfg* cfg);
 int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* xin, void* acts, void* ws, float* out,
