@@ -22,6 +22,8 @@ python tools/wgrad_breakdown.py gpurun_out/${TAG}_prof > gpurun_out/${TAG}_wgrad
 python tools/sim_throughput.py 32 12 2>/dev/null | tail -1 > gpurun_out/${TAG}_sim_throughput.json; cat gpurun_out/${TAG}_sim_throughput.json
 python tools/online_throughput.py 16 32 2>/dev/null | tail -1 > gpurun_out/${TAG}_online_throughput.json; cut -c1-400 gpurun_out/${TAG}_online_throughput.json
 find gpurun_out/${TAG}_prof -name "*.db" -delete
+# SpatialNet-large train step (generic backward): kernel trace
+bash tools/large_prof.sh 4 > /dev/null 2>&1; cp gpurun_out/large_rocprof.md gpurun_out/${TAG}_large_rocprof.md; head -12 gpurun_out/${TAG}_large_rocprof.md | tail -5
 # PMC passes LAST: on this pool a bench run that follows rocprofv3 --pmc passes was measured 12 % slower (mhsa_fwd 2x), so the
 # timed runs above must not come after them.  bench.py reads roofline.traffic from profiles/pmc_traffic.json (the previous
 # collection); the fresh figure for the same kernel is patched into the saved line here.
