@@ -206,6 +206,26 @@ int nbss_online_tconvffn_step(int B, int F, int C, const float* ln_w, const floa
                               const float* c1b, const float* c2w, const float* c2b, const float* gn_w, const float* gn_b, const float* c3w, const float* c3b,
                               const float* w2_t, const float* b2, float* s1, float* s2, float* s3, float* a3, float* gn_sums, float* x, void* stream);
 
+/* ---- narrow-band building blocks (models/arch/NBC2.py:152-238 in the reference: pre-norm self-attention over time + convolutional feed-forward with
+ * GroupBatchNorm, per (batch, frequency) sequence) -------------------------------------------------------------------------------------------------
+ * Geometry-generic kernels (csrc/gbwd.hip), one operation per call on caller-owned tensors of `dtype` (NBSS_F32 | NBSS_BF16) in the [nseq][T][C] layout
+ * of the reference's [B*F, T, C] activations; weights / biases / affines are the fp32 parameters in their state_dict layout.  nbss_amd/nbc2.py sequences an
+ * NBC2 forward from them.  act_in / act_out: 1 = SiLU applied to the input as it is read / to the result.
+ * conv_t: y[n][t][o] = sum_tap sum_i x[n][t + tap - taps/2][i] w[o][i][tap] + bias[o] (+ residual[n][t][o]), grouped, zero padded ("same"); taps = 1 is a
+ * per-token Linear (w [Cout][Cin]).  x rows are ldx elements apart (ldx >= Cin; groups = 1: ldx % 8 == 0 and the columns Cin..round_up(Cin, 8) must be
+ * zero; groups > 1: ldx == Cin, Cin / groups % 8 == 0).  ws: nbss_nb_ws_bytes(Cout, Cin, groups, taps) bytes of scratch (the re-laid weights). */
+int64_t nbss_nb_ws_bytes(int Cout, int Cin, int groups, int taps);
+int nbss_nb_conv_t(int dtype, int64_t nseq, int T, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                   const void* residual, int act_in, int act_out, void* ws, void* stream);
+/* LayerNorm over C (eps 1e-5): y = xhat gamma + beta; stats [rows][2] fp32 scratch (mean, rstd) */
+int nbss_nb_layernorm(int dtype, int64_t rows, int C, const void* x, const float* gamma, const float* beta, void* y, float* stats, void* stream);
+/* GroupBatchNorm (NBC2.py:57-145, share_along_sequence_dim = false): statistics over the F sequences of an utterance x C features per frame, from the input
+ * itself; x, y [B][F][T][C]; gamma / beta [C] or NULL */
+int nbss_nb_group_batch_norm(int dtype, int B, int F, int T, int C, const void* x, const float* gamma, const float* beta, float eps, int act_out, void* y,
+                             void* stream);
+/* softmax(q k^T / sqrt(dh)) v per (sequence, head): qkv [nseq][T][3H] (q | k | v; head h at columns h dh), o [nseq][T][H]; T <= 256, dh in {24, 48} */
+int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, void* o, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */

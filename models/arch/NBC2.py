@@ -3,7 +3,8 @@ same forward [B,F,T,dim_input] -> [B,F,T,dim_output], same state_dict keys (`enc
 conv.{1,3,4,6},linear2}`, `decoder`).  Each T-F sequence goes through `n_layers` blocks of pre-norm self-attention over time and a
 convolutional feed-forward (1x1 -> 3 grouped k=3 convs along T with a norm in the middle -> 1x1).  GroupBatchNorm (:57-145)
 normalises with statistics shared by the `group_size` (= num_freqs) sequences of one utterance, in training AND evaluation.
-Plain PyTorch."""
+torch.nn modules for training and on the CPU; inference on a HIP device runs the native forward of
+nbss_amd/nbc2.py (MFMA tap-GEMMs, attention, GroupBatchNorm and LayerNorm kernels behind the `nbss_nb_*` entry points of the C ABI)."""
 from typing import Any, Dict, Optional, Tuple
 
 import torch
@@ -133,8 +134,19 @@ class NBC2(nn.Module):
         self.sa_layers = nn.ModuleList([NBC2Block(dim_hidden=dim_hidden, dim_ffn=dim_ffn, **bk) for _ in range(n_layers)])
         self.decoder = nn.Linear(dim_hidden, dim_output)
 
+    def _native(self):
+        """the HIP forward (nbss_amd/nbc2.py) when this configuration is one its kernels are built for, else None"""
+        if not hasattr(self, "_native_fwd"):
+            from nbss_amd._lib import hip
+            from nbss_amd.nbc2 import NativeNBC2, supported
+            object.__setattr__(self, "_native_fwd", NativeNBC2(self, hip()) if supported(self) is None else None)
+        return self._native_fwd
+
     def forward(self, x: Tensor) -> Tensor:
         B, F, T, _ = x.shape
+        # inference on a HIP device (validate / test / predict, torch.no_grad()): the native forward; training and CPU: the torch.nn modules below
+        if x.is_cuda and not torch.is_grad_enabled() and T <= 256 and x.dtype in (torch.float32, torch.bfloat16) and self._native() is not None:
+            return self._native().forward(x.contiguous())
         h = self.encoder(x.reshape(B * F, T, -1).transpose(1, 2)).transpose(1, 2)
         for block in self.sa_layers:
             h, _ = block(h)

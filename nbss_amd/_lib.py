@@ -78,6 +78,11 @@ SIGNATURES = {
     "nbss_online_mhsa_step": (_I, [_I, _I, _I, _I] + [_P] * 11),
     "nbss_online_advance": (_I, [_P, _I, _P]),
     "nbss_online_tconvffn_step": (_I, [_I, _I, _I] + [_P] * 21),
+    "nbss_nb_ws_bytes": (C.c_int64, [_I, _I, _I, _I]),
+    "nbss_nb_conv_t": (_I, [_I, C.c_int64, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "nbss_nb_layernorm": (_I, [_I, C.c_int64, _I, _P, _P, _P, _P, _P, _P]),
+    "nbss_nb_group_batch_norm": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, C.c_float, _I, _P, _P]),
+    "nbss_nb_attention_fwd": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P]),
     "nbss_clip_adam_step": (_I, [C.c_int64, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P]),
     "nbss_selftest_mma": (_I, [_I, _I, _P, _P, _P, _P]),
     "nbss_build_info": (C.c_char_p, []),

@@ -38,6 +38,13 @@ int pit_sisdr_impl(int B, int S, int N, const float* p, const float* t, float* l
 int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal, float max_norm, float grad_scale, float lr, float beta1,
                    float beta2, float eps, float wd, int step, int flags, hipStream_t st);
 
+size_t nb_ws_bytes_impl(int M, int K, int groups, int taps);
+int nb_conv_t_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                   const void* residual, int act_in, int act_out, void* ws, hipStream_t st);
+int nb_layernorm_impl(int dtype, long rows, int C, const void* x, const float* gamma, const float* beta, void* y, float* stats, hipStream_t st);
+int nb_gbn_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, void* y, hipStream_t st);
+int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st);
+
 #define CHECK_CFG(cfg)                         \
     if (!(cfg)) return NBSS_EINVAL;            \
     {                                          \
@@ -442,6 +449,31 @@ int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, 
     if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || n <= 0) return NBSS_EINVAL;
     return clip_adam_impl((size_t)n, params, grads, exp_avg, exp_avg_sq, scratch, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
                           flags, (hipStream_t)stream);
+}
+
+static bool nb_dtype_ok(int dtype) { return dtype == NBSS_F32 || dtype == NBSS_BF16; }
+int64_t nbss_nb_ws_bytes(int Cout, int Cin, int groups, int taps) {
+    if (Cout <= 0 || Cin <= 0 || groups <= 0 || taps <= 0 || Cout % groups || Cin % groups) return -1;
+    return (int64_t)nb_ws_bytes_impl(Cout, Cin, groups, taps);
+}
+int nbss_nb_conv_t(int dtype, int64_t nseq, int T, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                   const void* residual, int act_in, int act_out, void* ws, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || taps <= 0 || !(taps & 1) || !x || !w || !y || !ws || x == y) return NBSS_EINVAL;
+    if (nseq * T >= ((int64_t)1 << 31)) return NBSS_EUNSUPPORTED;
+    return nb_conv_t_impl(dtype, (long)nseq, T, Cin, ldx, Cout, groups, taps, x, w, bias, y, residual, act_in, act_out, ws, (hipStream_t)stream);
+}
+int nbss_nb_layernorm(int dtype, int64_t rows, int C, const void* x, const float* gamma, const float* beta, void* y, float* stats, void* stream) {
+    if (!nb_dtype_ok(dtype) || rows <= 0 || C <= 0 || !x || !gamma || !beta || !y || !stats) return NBSS_EINVAL;
+    return nb_layernorm_impl(dtype, (long)rows, C, x, gamma, beta, y, stats, (hipStream_t)stream);
+}
+int nbss_nb_group_batch_norm(int dtype, int B, int F, int T, int C, const void* x, const float* gamma, const float* beta, float eps, int act_out, void* y,
+                             void* stream) {
+    if (!nb_dtype_ok(dtype) || B <= 0 || F <= 0 || T <= 0 || C <= 0 || !x || !y || (!gamma) != (!beta)) return NBSS_EINVAL;
+    return nb_gbn_impl(dtype, B, F, T, C, x, gamma, beta, eps, act_out, y, (hipStream_t)stream);
+}
+int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, void* o, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !o) return NBSS_EINVAL;
+    return nb_attention_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, o, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

@@ -638,6 +638,45 @@ __global__ __launch_bounds__(GB_THREADS) void gb_gn_bwd_kernel(const T* __restri
     }
 }
 
+
+// GroupBatchNorm of the narrow-band conformer (models/arch/NBC2.py:57-145 in the reference; share_along_sequence_dim = False): statistics over the
+// F sequences of one utterance x the C features, per frame, always from the input itself (training AND evaluation); per-feature affine, optional SiLU.
+// x [B][F][T][C]; one workgroup per (b, t).
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_gbn_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                            int F, int Tn, int C, float eps, int act) {
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [8]
+    const int b = blockIdx.x / Tn, t = blockIdx.x % Tn;
+    const size_t base = ((size_t)b * F * Tn + t) * C, fs = (size_t)Tn * C;  // element (f, c) at base + f fs + c
+    const int M = F * C;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum64(v);
+        __syncthreads();
+        if (lane_id() == 0) red[wave_id()] = v;
+        __syncthreads();
+        float s = 0.f;
+        for (int i = 0; i < GB_THREADS / 64; ++i) s += red[i];
+        return s;
+    };
+    float s = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) s += load1(x + base + (size_t)(e / C) * fs + e % C);
+    const float mean = block_sum(s) / M;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const float d = load1(x + base + (size_t)(e / C) * fs + e % C) - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(q) / M + eps);
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const int c = e % C;
+        const size_t o = base + (size_t)(e / C) * fs + c;
+        float v = (load1(x + o) - mean) * rstd;
+        if (gamma) v = v * gamma[c] + beta[c];
+        store1(y + o, act ? silu_f(v) : v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Attention backward for one (sequence, head), T <= 256, any head width DH % 8 == 0 (<= 64).  qkv [N][3H] (q | k | v, head h at columns h DH),
 // scores = q k^T / sqrt(DH), softmax over the keys, O = P V.
@@ -647,7 +686,8 @@ __global__ __launch_bounds__(GB_THREADS) void gb_gn_bwd_kernel(const T* __restri
 #define GA_TMAX 256
 NBSS_DEV int ga_perm_k(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
 
-template <class T, int DH>
+// BWD = false: the forward alone (O; dO / dqkv / lse / Dv are not touched) — the attention of the narrow-band building blocks (nbss_nb_attention_fwd)
+template <class T, int DH, bool BWD>
 __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, T* __restrict__ O, T* __restrict__ dqkv,
                                                                float* __restrict__ lse, float* __restrict__ Dv, int Tn, int H, int heads) {
     constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NTM = GA_TMAX / 16;
@@ -674,12 +714,12 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = 32 * ks + 8 * g4;
+            frag_zero(dof[ks]);
             if (qv && d0 < DH) {
                 frag_load(qf[ks], qkv + nq * ld + head * DH + d0);
-                frag_load(dof[ks], dO + nq * H + head * DH + d0);
+                if (BWD) frag_load(dof[ks], dO + nq * H + head * DH + d0);
             } else {
                 frag_zero(qf[ks]);
-                frag_zero(dof[ks]);
             }
         }
         // S^T and dP^T tiles: rows = keys 16 jt + 4 g4 + r, column = the lane's query
@@ -702,7 +742,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
                         frag_zero(vf);
                     }
                     st[jt] = mma(kf, qf[ks], st[jt]);
-                    dp[jt] = mma(vf, dof[ks], dp[jt]);
+                    if (BWD) dp[jt] = mma(vf, dof[ks], dp[jt]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -733,7 +773,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
                 dsum += st[jt][r] * dp[jt][r];
             }
         dsum = wave_sum16(dsum);  // D = rowsum(P dP) = rowsum(dO O)
-        if (qv && g4 == 0) {
+        if (BWD && qv && g4 == 0) {
             lse[nq * heads + head] = mx + __logf(sum);
             Dv[nq * heads + head] = dsum;
         }
@@ -764,7 +804,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
                         frag_set(kt, j, d < DH ? load1(Ks + (size_t)key * DH + d) : 0.f);
                     }
                     oacc[mt] = mma(vt, pf, oacc[mt]);
-                    qacc[mt] = mma(kt, dsf, qacc[mt]);
+                    if (BWD) qacc[mt] = mma(kt, dsf, qacc[mt]);
                 }
             }
         }
@@ -774,7 +814,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
                 const int d = 16 * mt + 4 * g4;
                 if (d < DH) {
                     store4(O + nq * H + head * DH + d, oacc[mt][0], oacc[mt][1], oacc[mt][2], oacc[mt][3]);
-                    store4(dqkv + nq * ld + head * DH + d, qacc[mt][0], qacc[mt][1], qacc[mt][2], qacc[mt][3]);
+                    if (BWD) store4(dqkv + nq * ld + head * DH + d, qacc[mt][0], qacc[mt][1], qacc[mt][2], qacc[mt][3]);
                 }
             }
         }
@@ -1145,10 +1185,10 @@ static int gb_attn_launch(const nbss_cfg& c, const void* qkv, const void* dO, vo
     const size_t ldsq = (size_t)2 * TP * DH * sizeof(T), ldsk = ldsq + (size_t)2 * TP * sizeof(float);
     if (c.T > GA_TMAX || ldsk > 160 * 1024) return NBSS_EUNSUPPORTED;
     int e;
-    if ((e = NBSS_SET_MAX_LDS((gb_attn_q_kernel<T, DH>), ldsq))) return e;
+    if ((e = NBSS_SET_MAX_LDS((gb_attn_q_kernel<T, DH, true>), ldsq))) return e;
     if ((e = NBSS_SET_MAX_LDS((gb_attn_k_kernel<T, DH>), ldsk))) return e;
     dim3 grid(c.B * c.F, c.heads);
-    NBSS_LAUNCH((gb_attn_q_kernel<T, DH>), grid, dim3(GB_THREADS), ldsq, st, (const T*)qkv, (const T*)dO, (T*)O, (T*)dqkv, lse, Dv, c.T, c.H, c.heads);
+    NBSS_LAUNCH((gb_attn_q_kernel<T, DH, true>), grid, dim3(GB_THREADS), ldsq, st, (const T*)qkv, (const T*)dO, (T*)O, (T*)dqkv, lse, Dv, c.T, c.H, c.heads);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     NBSS_LAUNCH((gb_attn_k_kernel<T, DH>), grid, dim3(GB_THREADS), ldsk, st, (const T*)qkv, (const T*)dO, (T*)dqkv, (const float*)lse, (const float*)Dv, c.T, c.H, c.heads);
     return NBSS_CHECK_LAUNCH();
@@ -1312,4 +1352,58 @@ int gb_tconvffn_bwd(const nbss_cfg& c, const float* P, float* G, int layer, cons
 }
 int gb_decoder_bwd(const nbss_cfg& c, const float* P, float* G, const void* x, const float* dout, void* dx, void* ws, hipStream_t st) {
     return GB_DISPATCH(gb_decoder_bwd_t, c, P, G, x, dout, dx, ws, st);
+}
+
+// ---- narrow-band building blocks behind the C ABI (nbss_nb_*: include/nbss_hip.h) ----------------------------------------------------------
+// The same generic kernels, one operation per call on caller-owned tensors: what a narrow-band network other than SpatialNet (NBC2: pre-norm
+// attention over time + convolutional feed-forward with GroupBatchNorm) is sequenced from on the host side (nbss_amd/nbc2.py).
+size_t nb_ws_bytes_impl(int M, int K, int groups, int taps) { return ws_align((size_t)groups * taps * pad16(M / groups) * pad32(pad8(K / groups)) * sizeof(float)); }
+
+template <class T>
+static int nb_conv_t(long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y, const void* residual,
+                     int act_in, int act_out, void* ws, hipStream_t st) {
+    if (groups <= 0 || Cin % groups || Cout % groups || (groups > 1 && ldx != Cin)) return NBSS_EINVAL;
+    const int Kv = Cin / groups, Kg = groups > 1 ? Kv : pad8(Kv), Mg = Cout / groups;
+    if (Kg % 8 || ldx < (groups > 1 ? Cin : Kg)) return NBSS_EUNSUPPORTED;
+    int e = gb_wprep<T>(w, ws, taps > 1 ? WP_CONV_FWD : WP_LIN_FWD, groups, taps, Mg, Kv, pad16(Mg), pad32(Kg), st);
+    if (e) return e;
+    TapGemm p = gb_lin(x, ldx, ws, bias, y, Cout, nseq * Tn, Mg, Kg);
+    p.groups = groups; p.xgs = groups > 1 ? Kv : 0; p.ygs = groups > 1 ? Mg : 0; p.bgs = Mg;
+    p.taps = taps; p.center = taps / 2; p.shift = 1; p.pos_div = 1; p.pos_len = Tn;
+    p.xact = act_in; p.yact = act_out;
+    p.R = residual; p.ldr = Cout;
+    return gb_gemm<T>(p, st);
+}
+int nb_conv_t_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                   const void* residual, int act_in, int act_out, void* ws, hipStream_t st) {
+    return dtype == NBSS_BF16 ? nb_conv_t<bf16_t>(nseq, Tn, Cin, ldx, Cout, groups, taps, x, w, bias, y, residual, act_in, act_out, ws, st)
+                              : nb_conv_t<float>(nseq, Tn, Cin, ldx, Cout, groups, taps, x, w, bias, y, residual, act_in, act_out, ws, st);
+}
+int nb_layernorm_impl(int dtype, long rows, int C, const void* x, const float* gamma, const float* beta, void* y, float* stats, hipStream_t st) {
+    return dtype == NBSS_BF16 ? gb_ln_fwd<bf16_t>(x, gamma, beta, y, stats, rows, C, st) : gb_ln_fwd<float>(x, gamma, beta, y, stats, rows, C, st);
+}
+int nb_gbn_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, void* y, hipStream_t st) {
+    if (dtype == NBSS_BF16)
+        NBSS_LAUNCH((gb_gbn_kernel<bf16_t>), dim3(B * Tn), dim3(GB_THREADS), 8 * sizeof(float), st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, F, Tn, C, eps, act);
+    else
+        NBSS_LAUNCH((gb_gbn_kernel<float>), dim3(B * Tn), dim3(GB_THREADS), 8 * sizeof(float), st, (const float*)x, gamma, beta, (float*)y, F, Tn, C, eps, act);
+    return NBSS_CHECK_LAUNCH();
+}
+template <class T, int DH>
+static int nb_attn_fwd(long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st) {
+    const int TP = 32 * cdiv(Tn, 32);
+    const size_t lds = (size_t)2 * TP * DH * sizeof(T);
+    if (Tn > GA_TMAX || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e = NBSS_SET_MAX_LDS((gb_attn_q_kernel<T, DH, false>), lds);
+    if (e) return e;
+    NBSS_LAUNCH((gb_attn_q_kernel<T, DH, false>), dim3((unsigned)nseq, heads), dim3(GB_THREADS), lds, st, (const T*)qkv, (const T*)nullptr, (T*)o, (T*)nullptr, (float*)nullptr,
+                (float*)nullptr, Tn, H, heads);
+    return NBSS_CHECK_LAUNCH();
+}
+int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st) {
+    if (heads <= 0 || H % heads) return NBSS_EINVAL;
+    const int dh = H / heads;
+    if (dh == 48) return dtype == NBSS_BF16 ? nb_attn_fwd<bf16_t, 48>(nseq, Tn, H, heads, qkv, o, st) : nb_attn_fwd<float, 48>(nseq, Tn, H, heads, qkv, o, st);
+    if (dh == 24) return dtype == NBSS_BF16 ? nb_attn_fwd<bf16_t, 24>(nseq, Tn, H, heads, qkv, o, st) : nb_attn_fwd<float, 24>(nseq, Tn, H, heads, qkv, o, st);
+    return NBSS_EUNSUPPORTED;
 }

@@ -1,0 +1,108 @@
+"""Native NBC2 forward (nbss_amd/nbc2.py over the nbss_nb_* building blocks of the C ABI) against the torch.nn module it reads its parameters
+from (models/arch/NBC2.py, itself pinned to the reference's NBC2 by tests/test_nb_models.py), and each building block against torch."""
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from nbss_amd import ops
+from nbss_amd._lib import NBSS_BF16, NBSS_F32
+from util import rel_l2
+
+DTYPES = [pytest.param(NBSS_F32, id="f32"), pytest.param(NBSS_BF16, id="bf16")]
+
+
+def _td(dtype):
+    return torch.bfloat16 if dtype == NBSS_BF16 else torch.float32
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_building_blocks(backend, dtype):
+    import ctypes as C
+    lib, dev, td = backend.lib, backend.device, _td(dtype)
+    tol = 2e-5 if dtype == NBSS_F32 else 1.5e-2
+    g = torch.Generator().manual_seed(0)
+    nseq, T = 6, 37
+
+    def dv(t):
+        return t.to(td).to(dev).contiguous()
+
+    def conv(x, cin, ldx, cout, groups, taps, w, b, res=None, act_in=0, act_out=0):
+        y = torch.empty(nseq, T, cout, dtype=td, device=dev)
+        ws = torch.empty(lib._dll.nbss_nb_ws_bytes(cout, (cin + 7) // 8 * 8 if groups == 1 else cin, groups, taps), dtype=torch.uint8, device=dev)
+        w, b = w.to(dev), b.to(dev)  # (named: a temporary's device memory is handed to the next allocation before the call that reads it is even made)
+        lib.call("nbss_nb_conv_t", dtype, nseq, T, cin, ldx, cout, groups, taps, ops._ptr(lib, x), ops._ptr(lib, w), ops._ptr(lib, b), ops._ptr(lib, y),
+                 ops._ptr(lib, res) if res is not None else None, act_in, act_out, ops._ptr(lib, ws), ops._stream(lib, x))
+        return y
+
+    # grouped conv along T with SiLU on the input and a residual
+    x = torch.randn(nseq, T, 48, generator=g)
+    w, b = torch.randn(48, 24, 3, generator=g) * 0.2, torch.randn(48, generator=g) * 0.1
+    res = torch.randn(nseq, T, 48, generator=g)
+    xd, rd = dv(x), dv(res)
+    y = conv(xd, 48, 48, 48, 2, 3, w, b, res=rd, act_in=1)
+    want = rd.double().cpu() + Fn.conv1d(Fn.silu(xd.double().cpu()).transpose(1, 2), w.double(), b.double(), padding="same", groups=2).transpose(1, 2)
+    assert rel_l2(y, want) < tol
+    # dense odd-width input (12 valid of 16 stored columns), kernel 5, SiLU on the output
+    x = torch.zeros(nseq, T, 16)
+    x[..., :12] = torch.randn(nseq, T, 12, generator=g)
+    w, b = torch.randn(40, 12, 5, generator=g) * 0.2, torch.randn(40, generator=g) * 0.1
+    xd = dv(x)
+    y = conv(xd, 12, 16, 40, 1, 5, w, b, act_out=1)
+    want = Fn.silu(Fn.conv1d(xd[..., :12].double().cpu().transpose(1, 2), w.double(), b.double(), padding="same").transpose(1, 2))
+    assert rel_l2(y, want) < tol
+    # LayerNorm
+    x = torch.randn(nseq, T, 96, generator=g)
+    gam, bet = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g) * 0.1
+    xd = dv(x)
+    y, stats = torch.empty_like(xd), torch.empty(nseq * T, 2, device=dev)
+    gd, bd = gam.to(dev), bet.to(dev)
+    lib.call("nbss_nb_layernorm", dtype, nseq * T, 96, ops._ptr(lib, xd), ops._ptr(lib, gd), ops._ptr(lib, bd), ops._ptr(lib, y), ops._ptr(lib, stats),
+             ops._stream(lib, xd))
+    assert rel_l2(y, Fn.layer_norm(xd.double().cpu(), (96,), gam.double(), bet.double(), 1e-5)) < tol
+    # GroupBatchNorm: 2 utterances of 3 sequences, statistics per (utterance, frame) over (sequence, feature)
+    from models.arch.NBC2 import GroupBatchNorm
+    m = GroupBatchNorm(96, 3).double()
+    with torch.no_grad():
+        m.weight.copy_(gam.double())
+        m.bias.copy_(bet.double())
+    y = torch.empty_like(xd)
+    lib.call("nbss_nb_group_batch_norm", dtype, 2, 3, T, 96, ops._ptr(lib, xd), ops._ptr(lib, gd), ops._ptr(lib, bd), C.c_float(1e-5), 1, ops._ptr(lib, y),
+             ops._stream(lib, xd))
+    assert rel_l2(y, Fn.silu(m(xd.double().cpu())).detach()) < tol
+    # attention, 2 heads of 48
+    qkv = torch.randn(nseq, T, 288, generator=g)
+    qd = dv(qkv)
+    o = torch.empty(nseq, T, 96, dtype=td, device=dev)
+    lib.call("nbss_nb_attention_fwd", dtype, nseq, T, 96, 2, ops._ptr(lib, qd), ops._ptr(lib, o), ops._stream(lib, qd))
+    q, k, v = [t.reshape(nseq, T, 2, 48).transpose(1, 2) for t in qd.double().cpu().split(96, dim=-1)]
+    want = (torch.softmax(q @ k.transpose(-1, -2) / 48 ** 0.5, -1) @ v).transpose(1, 2).reshape(nseq, T, 96)
+    assert rel_l2(o, want) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_native_nbc2_forward_equals_the_module(backend, dtype):
+    from models.arch.NBC2 import NBC2
+    from nbss_amd.nbc2 import NativeNBC2, supported
+    torch.manual_seed(3)
+    B, F, T = (2, 5, 21) if backend.name == "emu" else (2, 129, 251)
+    net = NBC2(dim_input=16, dim_output=6, n_layers=2 if backend.name == "emu" else 8, dim_hidden=96, dim_ffn=192, num_freqs=F).eval()
+    assert supported(net) is None
+    x = torch.randn(B, F, T, 16)
+    with torch.no_grad():
+        want = net.double()(x.double())
+    net = net.float().to(backend.device)
+    xd = x.to(_td(dtype)).to(backend.device)
+    y = NativeNBC2(net, backend.lib).forward(xd)
+    assert y.shape == (B, F, T, 6) and y.dtype == xd.dtype
+    assert rel_l2(y, want) < (1e-4 if dtype == NBSS_F32 else 4e-2)
+
+
+def test_supported_names_the_reason():
+    from models.arch.NBC2 import NBC2
+    from nbss_amd.nbc2 import supported
+    assert supported(NBC2(dim_input=12, dim_output=4, n_layers=1, dim_hidden=96, dim_ffn=192, num_freqs=9)) is None
+    bk = {"n_heads": 2, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 8, "norms": ("LN", "LN", "GN")}
+    assert "norms" in supported(NBC2(dim_input=12, dim_output=4, n_layers=1, dim_hidden=96, dim_ffn=192, num_freqs=9, block_kwargs=bk))
+    bk = {"n_heads": 8, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 8, "norms": ("LN", "GBN", "GBN"),
+          "group_batch_norm_kwargs": {"share_along_sequence_dim": False}}
+    assert "head width" in supported(NBC2(dim_input=12, dim_output=4, n_layers=1, dim_hidden=96, dim_ffn=192, num_freqs=9, block_kwargs=bk))
