@@ -63,6 +63,18 @@ def main():
         out[f"{nm}_large_full"] = ops.full_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
         out[f"{nm}_large_mhsa"] = ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=ops.mhsa_save(cs.lib, cs.cfg, x.device))
         out[f"{nm}_large_tconvffn"] = ops.tconvffn_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x)
+        # ... and the geometry-generic backward (gbwd.hip: LDS-staged tap-GEMM weights, LDS partial sums of the row / GroupNorm kernels, the two attention kernels)
+        dy, _ = cs.stream(seed=34)
+        save = ops.mhsa_save(cs.lib, cs.cfg, x.device)
+        for name, fn in (("fconv_bwd", lambda G, ws: ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, 1, x, dy, ws)),
+                         ("full_bwd", lambda G, ws: ops.full_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws)),
+                         ("mhsa_bwd", lambda G, ws: ops.mhsa_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, save, ws)),
+                         ("tconvffn_bwd", lambda G, ws: ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws))):
+            G = torch.zeros_like(cs.flat)
+            ws = ops.workspace(cs.lib, cs.cfg, x.device)
+            ws.zero_()
+            out[f"{nm}_large_{name}"] = fn(G, ws)
+            out[f"{nm}_large_{name}_G"] = G
     torch.save(out, sys.argv[1])
 
 

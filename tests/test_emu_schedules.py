@@ -27,9 +27,13 @@ def _run(mode: str, tmp: Path) -> dict:
 def test_outputs_do_not_depend_on_the_wave_schedule(tmp_path):
     from nbss_amd.build import build_emu
     build_emu()  # once, before the workers race to build it
-    base = _run("fwd", tmp_path)
-    for mode in ("wave", "waverev", "waverand", "rev"):
-        got = _run(mode, tmp_path)
+    from concurrent.futures import ThreadPoolExecutor
+    modes = ("fwd", "wave", "waverev", "waverand", "rev")
+    with ThreadPoolExecutor(len(modes)) as ex:  # five independent worker processes (25 s each)
+        res = dict(zip(modes, ex.map(lambda m: _run(m, tmp_path), modes)))
+    base = res["fwd"]
+    for mode in modes[1:]:
+        got = res[mode]
         bad = []
         for k, a in base.items():
             b = got[k]
