@@ -96,7 +96,7 @@ def test_large_network_forward(backend, dtype):
 
 
 def bwd_shapes(backend):
-    return [(1, 5, 19), (2, 9, 40)] + ([(2, 129, 251)] if backend.name == "hip" else [])
+    return [(1, 5, 19), (2, 9, 40)] + ([(1, 129, 251)] if backend.name == "hip" else [])  # (one utterance at the reference's shape: the fp64 oracle's autograd is the slow side)
 
 
 def run_large_bwd(backend, dtype, B, F, T, fwd_ref, bwd_op, names, seed, bf16_tol=3e-2, f32_tol=1e-4):
@@ -122,7 +122,7 @@ def test_large_fconv_bwd(backend, dtype, which):
     for (B, F, T) in bwd_shapes(backend) + [(1, 257, 3)]:
         run_large_bwd(backend, dtype, B, F, T, lambda x, p: ref.fconv(x, p, pre),
                       lambda cs, G, x, dy, ws: ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, which, x, dy, ws), names, seed=40 + which, bf16_tol=5e-2,
-                      # PReLU kink: of the 12.4 M pre-activations of the (2, 129, 251) case a handful lie within fp32 rounding of zero; each one whose
+                      # PReLU kink: of the millions of pre-activations of the 129 x 251 case a handful lie within fp32 rounding of zero (12.4 M at batch 2: three); each one whose
                       # sign differs from the fp64 oracle's moves dx by (1 - alpha) dy there (measured 3.7e-4 with three of them)
                       f32_tol=1e-4 if B * F * T < 10000 else 1e-3)
 
