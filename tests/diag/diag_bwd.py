@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')  # run from the repo root: python tests/diag/diag_bwd.py
 from nbss_amd._lib import hip, NBSS_BF16, NBSS_F32
 from nbss_amd.engine import SpatialNetEngine
 from oracle import spatialnet_ref as ref

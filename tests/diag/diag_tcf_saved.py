@@ -1,8 +1,8 @@
 """T-ConvFFN backward: recomputing kernel vs the saved-pre-activation kernel, per-tensor rel-L2 against the fp64 oracle (emulator or HIP).
-usage: python tools/diag_tcf_saved.py [emu|hip] B F T"""
+usage: python tests/diag/diag_tcf_saved.py [emu|hip] B F T"""
 import os, sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 os.environ.setdefault("NBSS_POISON_SCRATCH", "1")
 import torch

@@ -1,5 +1,5 @@
 import torch, time, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')  # run from the repo root: python tests/diag/long_time.py
 from nbss_amd._lib import hip as hip_lib, NBSS_BF16, NBSS_F32
 from nbss_amd.engine import SpatialNetEngine
 from oracle import spatialnet_ref as ref
