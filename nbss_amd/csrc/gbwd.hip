@@ -1365,7 +1365,7 @@ static int nb_conv_t(long nseq, int Tn, int Cin, int ldx, int Cout, int groups, 
     if (groups <= 0 || Cin % groups || Cout % groups || (groups > 1 && ldx != Cin)) return NBSS_EINVAL;
     const int Kv = Cin / groups, Kg = groups > 1 ? Kv : pad8(Kv), Mg = Cout / groups;
     if (Kg % 8 || ldx < (groups > 1 ? Cin : Kg)) return NBSS_EUNSUPPORTED;
-    int e = gb_wprep<T>(w, ws, taps > 1 ? WP_CONV_FWD : WP_LIN_FWD, groups, taps, Mg, Kv, pad16(Mg), pad32(Kg), st);
+    int e = gb_wprep<T>(w, ws, taps > 1 || groups > 1 ? WP_CONV_FWD : WP_LIN_FWD, groups, taps, Mg, Kv, pad16(Mg), pad32(Kg), st);
     if (e) return e;
     TapGemm p = gb_lin(x, ldx, ws, bias, y, Cout, nseq * Tn, Mg, Kg);
     p.groups = groups; p.xgs = groups > 1 ? Kv : 0; p.ygs = groups > 1 ? Mg : 0; p.bgs = Mg;

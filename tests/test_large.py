@@ -209,3 +209,28 @@ def test_large_dropin_module_inference(hip_lib):
     ref.spatialnet(x.double().cpu(), p64, 3).sum().backward()
     worst = max(rel_l2(v.grad, p64[k].grad) for k, v in sd.items() if v.requires_grad)
     assert worst < 2e-3, worst
+
+
+def test_large_block_backward_random_shapes(emu_lib):
+    """the four block backward passes of the generic path on random small grids (emulator, fp32): single frames / frequencies, sizes around the 16-row
+    tiles and the conv kernels' reach"""
+    from hypothesis import given, settings, strategies as st
+    from conftest import Backend
+    from test_kernels_bwd import FULL_NAMES, TF_NAMES
+    be = Backend("emu", emu_lib, torch.device("cpu"))
+    mh = ["layers.0.norm_mhsa.weight", "layers.0.norm_mhsa.bias", "layers.0.mhsa.in_proj_weight", "layers.0.mhsa.in_proj_bias", "layers.0.mhsa.out_proj.weight",
+          "layers.0.mhsa.out_proj.bias"]
+    fc = [f"layers.0.fconv1.{k}" for k in ("0.weight", "0.bias", "1.weight", "1.bias", "2.weight")]
+
+    @settings(max_examples=12, deadline=None)
+    @given(B=st.integers(1, 2), F=st.sampled_from([1, 2, 3, 5, 17]), T=st.sampled_from([1, 2, 3, 16, 17, 33]), block=st.sampled_from(["fconv", "full", "mhsa", "tconvffn"]))
+    def check(B, F, T, block):
+        ops_ = {"fconv": (lambda x, p: ref.fconv(x, p, "layers.0.fconv1"), lambda cs, G, x, dy, ws: ops.fconv_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, 0, x, dy, ws), fc),
+                "full": (lambda x, p: ref.full(x, p, "layers.0"), lambda cs, G, x, dy, ws: ops.full_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws), FULL_NAMES),
+                "mhsa": (lambda x, p: ref.mhsa(x, p, "layers.0"),
+                         lambda cs, G, x, dy, ws: ops.mhsa_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ops.mhsa_save(cs.lib, cs.cfg, x.device), ws), mh),
+                "tconvffn": (lambda x, p: ref.tconvffn(x, p, "layers.0"), lambda cs, G, x, dy, ws: ops.tconvffn_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, ws), TF_NAMES)}
+        fwd, bwd, names = ops_[block]
+        run_large_bwd(be, NBSS_F32, B, F, T, fwd, bwd, names, seed=7, f32_tol=2e-4)
+
+    check()

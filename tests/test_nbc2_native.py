@@ -106,3 +106,86 @@ def test_supported_names_the_reason():
     bk = {"n_heads": 8, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 8, "norms": ("LN", "GBN", "GBN"),
           "group_batch_norm_kwargs": {"share_along_sequence_dim": False}}
     assert "head width" in supported(NBC2(dim_input=12, dim_output=4, n_layers=1, dim_hidden=96, dim_ffn=192, num_freqs=9, block_kwargs=bk))
+
+
+def test_conv_t_random_shapes(emu_lib):
+    """the tap-GEMM behind every Linear / Conv1d of the generic paths against torch on random shapes (emulator): group counts, group widths that do and
+    do not fill a 32-wide k-step or a 16-row tile, kernel sizes, sequence lengths around the 16-row tile and 64-row workgroup boundaries, both
+    activation flags, residual on / off"""
+    from hypothesis import given, settings, strategies as st
+    lib, dev = emu_lib, torch.device("cpu")
+
+    @settings(max_examples=60, deadline=None)
+    @given(nseq=st.integers(1, 3), T=st.integers(1, 70), groups=st.sampled_from([1, 2, 8]), cgi=st.sampled_from([8, 24, 40]), cgo=st.sampled_from([4, 16, 24, 72]),
+           taps=st.sampled_from([1, 3, 5]), act_in=st.integers(0, 1), act_out=st.integers(0, 1), res=st.booleans(), seed=st.integers(0, 1000))
+    def check(nseq, T, groups, cgi, cgo, taps, act_in, act_out, res, seed):
+        g = torch.Generator().manual_seed(seed)
+        cin, cout = groups * cgi, groups * cgo
+        x = torch.randn(nseq, T, cin, generator=g)
+        w = torch.randn(cout, cgi, taps, generator=g) * 0.3
+        b = torch.randn(cout, generator=g) * 0.1
+        r = torch.randn(nseq, T, cout, generator=g) if res else None
+        y = torch.empty(nseq, T, cout)
+        ws = torch.empty(lib._dll.nbss_nb_ws_bytes(cout, cin, groups, taps), dtype=torch.uint8)
+        wk = w.reshape(cout, cgi).contiguous() if taps == 1 else w
+        lib.call("nbss_nb_conv_t", NBSS_F32, nseq, T, cin, cin, cout, groups, taps, ops._ptr(lib, x), ops._ptr(lib, wk), ops._ptr(lib, b), ops._ptr(lib, y),
+                 ops._ptr(lib, r) if res else None, act_in, act_out, ops._ptr(lib, ws), None)
+        xin = Fn.silu(x.double()) if act_in else x.double()
+        want = Fn.conv1d(xin.transpose(1, 2), w.double(), b.double(), padding="same", groups=groups).transpose(1, 2)
+        if act_out:
+            want = Fn.silu(want)
+        if res:
+            want = want + r.double()
+        assert rel_l2(y, want) < 2e-5, (nseq, T, groups, cgi, cgo, taps, act_in, act_out, res)
+
+    check()
+
+
+def test_attention_layernorm_gbn_random_shapes(emu_lib):
+    """the attention, LayerNorm and GroupBatchNorm building blocks on random shapes (emulator): sequence lengths from 1 to 256 (partial 16-key tiles, odd
+    tile pairs), both head widths, channel counts with and without the 16-lane row kernels"""
+    import ctypes as C
+    from hypothesis import given, settings, strategies as st
+    from models.arch.NBC2 import GroupBatchNorm
+    lib = emu_lib
+
+    @settings(max_examples=20, deadline=None)
+    @given(nseq=st.integers(1, 2), T=st.sampled_from([1, 2, 15, 16, 17, 31, 33, 48, 100, 255, 256]), dh=st.sampled_from([24, 48]), heads=st.integers(1, 3), seed=st.integers(0, 99))
+    def attn(nseq, T, dh, heads, seed):
+        g = torch.Generator().manual_seed(seed)
+        H = dh * heads
+        qkv = torch.randn(nseq, T, 3 * H, generator=g)
+        o = torch.empty(nseq, T, H)
+        lib.call("nbss_nb_attention_fwd", NBSS_F32, nseq, T, H, heads, ops._ptr(lib, qkv), ops._ptr(lib, o), None)
+        q, k, v = [t.reshape(nseq, T, heads, dh).transpose(1, 2) for t in qkv.double().split(H, dim=-1)]
+        want = (torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) @ v).transpose(1, 2).reshape(nseq, T, H)
+        assert rel_l2(o, want) < 2e-5, (nseq, T, dh, heads)
+
+    @settings(max_examples=20, deadline=None)
+    @given(rows=st.integers(1, 70), Cc=st.sampled_from([8, 40, 96, 192, 384]), seed=st.integers(0, 99))
+    def ln(rows, Cc, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(rows, Cc, generator=g) * 2 + 0.5
+        gam, bet = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+        y, stats = torch.empty_like(x), torch.empty(rows, 2)
+        lib.call("nbss_nb_layernorm", NBSS_F32, rows, Cc, ops._ptr(lib, x), ops._ptr(lib, gam), ops._ptr(lib, bet), ops._ptr(lib, y), ops._ptr(lib, stats), None)
+        assert rel_l2(y, Fn.layer_norm(x.double(), (Cc,), gam.double(), bet.double(), 1e-5)) < 2e-5, (rows, Cc)
+
+    @settings(max_examples=15, deadline=None)
+    @given(B=st.integers(1, 2), F=st.integers(1, 5), T=st.integers(1, 9), Cc=st.sampled_from([8, 96, 192]), act=st.integers(0, 1), seed=st.integers(0, 99))
+    def gbn(B, F, T, Cc, act, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B * F, T, Cc, generator=g) * 2 + 0.3
+        m = GroupBatchNorm(Cc, F).double()
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(Cc, generator=g).double() + 0.5)
+            m.bias.copy_(torch.randn(Cc, generator=g).double())
+        y = torch.empty_like(x)
+        gw, gb = m.weight.float().contiguous(), m.bias.float().contiguous()
+        lib.call("nbss_nb_group_batch_norm", NBSS_F32, B, F, T, Cc, ops._ptr(lib, x), ops._ptr(lib, gw), ops._ptr(lib, gb), C.c_float(1e-5), act, ops._ptr(lib, y), None)
+        want = m(x.double()).detach()
+        assert rel_l2(y, Fn.silu(want) if act else want) < 2e-5, (B, F, T, Cc, act)
+
+    attn()
+    ln()
+    gbn()
