@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WG_THREADS, TPW <= 4 ? 4 : 2) void wgrad_kernel(Wgr
                     // index along the shifted axis of row r (frames wrap at T; the frequency changes every T rows)
                     int pr = pos;
                     if (shifted) {
-                        if (a.shift_dim == 0) { pr = pos + r; if (pr >= a.T) pr -= a.T; }
+                        if (a.shift_dim == 0) { pr = pos + r; while (pr >= a.T) pr -= a.T; }  // (T < 4: a quad of rows wraps more than once)
                         else if (tb + r >= a.T) pr = (n / a.T) % a.F;
                     }
                     if (n < a.Ntok && pr + bd[u] >= 0 && pr + bd[u] < lim) {
