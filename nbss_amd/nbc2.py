@@ -63,6 +63,9 @@ class NativeNBC2:
         B, F, T, Cin = x.shape
         if T > 256:
             raise NbssError(f"NBC2 native forward: {T} frames; the attention kernel keeps a sequence's K / V in LDS (<= 256 frames)")
+        gs = net.sa_layers[0].norm2.group_size
+        if F != gs:  # (the torch.nn module groups `group_size` consecutive sequences whatever F is; the kernel's groups are the utterances)
+            raise NbssError(f"NBC2 native forward: {F} frequencies per utterance, GroupBatchNorm group_size {gs}")
         dt = NBSS_BF16 if x.dtype == torch.bfloat16 else NBSS_F32
         td = x.dtype if dt == NBSS_BF16 else torch.float32
         dev, nseq, N = x.device, B * F, B * F * T
