@@ -145,7 +145,8 @@ class NBC2(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         B, F, T, _ = x.shape
         # inference on a HIP device (validate / test / predict, torch.no_grad()): the native forward; training and CPU: the torch.nn modules below
-        if x.is_cuda and not torch.is_grad_enabled() and T <= 256 and x.dtype in (torch.float32, torch.bfloat16) and self._native() is not None:
+        if (x.is_cuda and not torch.is_grad_enabled() and T <= 256 and x.dtype in (torch.float32, torch.bfloat16) and self._native() is not None
+                and F == self.sa_layers[0].norm2.group_size):  # (groups of the GroupBatchNorm = the utterances)
             return self._native().forward(x.contiguous())
         h = self.encoder(x.reshape(B * F, T, -1).transpose(1, 2)).transpose(1, 2)
         for block in self.sa_layers:
