@@ -97,3 +97,10 @@ def test_16khz_geometry(backend):
     views = eng.param_views(eng.grads)
     bad = [(k, rel_l2(views[k], g)) for k, g in wg.items() if rel_l2(views[k], g) > 0.12]  # bf16 stream, whole network (tests/test_e2e_headline.py)
     assert not bad, bad
+
+
+def test_graft_smoke_body_on_the_emulator(emu_lib):
+    """__graft_entry__.smoke() runs this body on cuda:0 at the round's end; here the same code on the host emulator at a small grid"""
+    import __graft_entry__ as g
+    r = g._smoke(emu_lib, torch.device("cpu"), F=9, T=21, L=2)
+    assert r["forward"] < 3e-2 and r["walk_forward"] < 3e-2 and r["gradient"] < 6e-2, r
