@@ -97,6 +97,26 @@ NBSS_DEV void lds_barrier() {
 #endif
 }
 
+// nothing is scheduled across this point (keeps independent register-hungry sections — e.g. the two strips of a LayerNorm — from being
+// interleaved by the scheduler, which doubles their live temporaries)
+NBSS_DEV void sched_fence() {
+#ifndef NBSS_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// LDS written by one lane and read by another lane of the SAME wave: the hardware executes a wave's LDS instructions in order;
+// the compiler must not reorder across this point and the emulator's fibers must meet here
+NBSS_DEV void wave_lds_sync() {
+#ifdef NBSS_EMU
+    hipemu::wave_sync();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 NBSS_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 NBSS_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
 // same value, but known to the compiler as wave-uniform: index arithmetic derived from it stays in SGPRs
@@ -187,6 +207,13 @@ NBSS_DEV void store4_nt(bf16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<u32x2*>(p) = v;
 #else
     __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+#endif
+}
+NBSS_DEV void store16_nt(bf16_t* p, const u32x4& v) {  // one 16-byte streaming store
+#ifdef NBSS_EMU
+    *reinterpret_cast<u32x4*>(p) = v;
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 #endif
 }
 NBSS_DEV void store1(float* p, float a) { *p = a; }

@@ -233,13 +233,15 @@ NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     return ws_align(N * 2 * sizeof(float)) + ws_nops(c) * ws_align(N * c.FFN * esz) + ws_wprep_bytes(c) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) +
            ws_align(fc_part_bytes(c)) + ws_align(tc_part_bytes(c)) + 256;
 }
-// attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32
+// attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32 | LayerNorm statistics [N][2] fp32
 NBSS_HD size_t mhsa_lse_offset(const nbss_cfg& c) {
     return ws_align((size_t)c.B * c.F * c.T * c.H * (c.dtype == NBSS_BF16 ? 2 : 4));
 }
+// ... | LayerNorm (mean, rstd) of every token [N][2] fp32: the backward kernels re-apply the LayerNorm without recomputing its statistics
+NBSS_HD size_t mhsa_stat_offset(const nbss_cfg& c) { return mhsa_lse_offset(c) + ws_align((size_t)c.B * c.F * c.T * c.heads * sizeof(float)); }
 // (T > 256, forward only: the same buffer is the K | V scratch of the long-sequence attention path, two stream tensors)
 NBSS_HD size_t mhsa_save_bytes(const nbss_cfg& c) {
-    const size_t s = mhsa_lse_offset(c) + ws_align((size_t)c.B * c.F * c.T * c.heads * sizeof(float));
+    const size_t s = mhsa_stat_offset(c) + ws_align((size_t)c.B * c.F * c.T * 2 * sizeof(float));
     return (c.T > NBSS_T_TRAIN_MAX || c.H != 96) && s < 2 * mhsa_lse_offset(c) ? 2 * mhsa_lse_offset(c) : s;
 }
 // per-workgroup partial sums of the small (affine) parameter gradients live behind the wgrad operands

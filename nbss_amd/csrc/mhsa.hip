@@ -34,7 +34,7 @@
 
 // LN of a 16-frame strip held as natural-order B fragments (lane: frame l&15, channels 32ks+8g+j)
 template <class T>
-NBSS_DEV void ln_strip(const T* __restrict__ xr, bool valid, const float (&gam)[MH_KS][8], const float (&bet)[MH_KS][8], Frag<T> (&u)[MH_KS]) {
+NBSS_DEV void ln_strip(const T* __restrict__ xr, bool valid, const float (&gam)[MH_KS][8], const float (&bet)[MH_KS][8], Frag<T> (&u)[MH_KS], float* __restrict__ stat = nullptr) {
     const int g4 = lane_id() >> 4;
     float v[MH_KS][8];
     float sum = 0.f;
@@ -57,6 +57,10 @@ NBSS_DEV void ln_strip(const T* __restrict__ xr, bool valid, const float (&gam)[
             q += d * d;
         }
     const float rstd = rsqrtf(wave_sum16(q) * (1.0f / MH_H) + 1e-5f);
+    if (stat && valid && g4 == 0) {  // training-mode forward: the row statistics go to the save buffer (layout.h: mhsa_stat_offset)
+        stat[0] = mean;
+        stat[1] = rstd;
+    }
 #pragma unroll
     for (int ks = 0; ks < MH_KS; ++ks)
 #pragma unroll
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
     const T* xb = x + (size_t)bf * T_ * MH_H;
     T* yb = y + (size_t)bf * T_ * MH_H;
     const float qscale = 1.4426950408889634f * rsqrtf((float)MH_DH);
+    float* lnstat = osave ? reinterpret_cast<float*>(reinterpret_cast<char*>(osave) + mhsa_stat_offset(c)) : nullptr;
 
     float gam[MH_KS][8], bet[MH_KS][8];
 #pragma unroll
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
 #pragma unroll
             for (int si = 0; si < NSW; ++si) {
                 const int t = (w * NSW + si) * 16 + l15;
-                ln_strip<T>(xb + (size_t)t * MH_H, t < T_, gam, bet, u[si]);
+                ln_strip<T>(xb + (size_t)t * MH_H, t < T_, gam, bet, u[si], lnstat ? lnstat + ((size_t)bf * T_ + t) * 2 : nullptr);
             }
             if (WLDS) {
                 wwin_store();

@@ -608,6 +608,396 @@ __global__ __launch_bounds__(MB_NTHR) void mhsa_bwd_kernel(nbss_cfg c, LayerPtrs
 }
 PHASE_READER(nbss_phase_read_mhsa_bwd)
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// bf16 stream, round 4: ONE sweep, one workgroup per (sequence, HEAD), two workgroups per CU.
+//
+// The two-sweep kernel above builds every S / dP tile twice (once per operand orientation: 14 MFMAs and 16 exponentials per 32 x 32
+// block of scores) and is one 218-register workgroup per CU, parked in s_waitcnt / barriers for half of its wave time.  Here a wave
+// owns 32 KEYS (dK, dV and its K, V strips never leave its registers) and walks the queries once:
+//     S = Q' K^T - lse,  dP = dO V^T - D   (the subtractions are the accumulators' initial values)
+//     P = exp2(S),  dS = P dP,  dV^T += dO^T P,  dK^T += Q'^T dS                     (8 MFMAs, 8 exponentials per 16 x 32 block)
+// and hands dS — the only quantity the dQ product needs in the OTHER orientation — to a 64-query LDS image [key][query]; after a
+// barrier the eight waves each contract one (16-query strip, dh half) of the chunk over all keys through transposing LDS reads:
+//     dQ^T = K^T dS^T   (fixed summation order: no atomics, bitwise repeatable)
+// 10 MFMAs per block instead of 14, half the exponentials, and the 72 KB / <= 128 registers of a workgroup let two share a CU.
+// The four heads of a sequence are four workgroups on the same XCD (x / dy rows come from its L2); the saved attention output, the
+// log2-sum-exp rows and this head's 24 weight fragments (staged in the LDS region that becomes the dS image) are read per head.
+// Padding frames (T not a multiple of 16): K rows are zero and lse = 1e30, so they contribute nothing anywhere.
+#define MH_QC 64   // queries per dS chunk
+#define MH_RS 68   // dS image row stride (elements): rows 34 dwords apart — the 16 key rows of a b64 store hit 16 distinct bank pairs
+#define MH_TP 256
+
+NBSS_DEV void frag_pack_c2(Frag<bf16_t>& f, const f32x4& lo, const f32x4& hi) {  // four v_cvt_pk_bf16_f32
+    const u32x4 v = {pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
+    f.v = __builtin_bit_cast(s16x8, v);
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(512, 4) void mhsa_bwd_h_kernel(nbss_cfg c, LayerPtrs lp, int nseq, const bf16_t* __restrict__ Win, const bf16_t* __restrict__ WoutT,
+                                                            const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ osave,
+                                                            const float* __restrict__ lse, const float* __restrict__ stats, bf16_t* __restrict__ dqkv) {
+    typedef bf16_t T;
+    NBSS_LDS(smem);
+    // blocks b, b + 8, b + 16, b + 24 (same XCD, dispatched back to back) = the four heads of one sequence
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, head = bi & 3, bf = (bi >> 2) * 8 + xcd;
+    if (bf >= nseq) return;
+    const int T_ = c.T, nst = FULL ? MB_NT : cdiv(T_, 16), nkp = FULL ? MB_NT / 2 : cdiv(nst, 2);
+    T* Qr = reinterpret_cast<T*>(smem);
+    T* Kr = Qr + MH_TP * MB_DH;
+    T* dOr = Kr + MH_TP * MB_DH;
+    float* nm2 = reinterpret_cast<float*>(dOr + MH_TP * MB_DH);  // -lse (log2 domain) per query; -1e30 for padding frames
+    float* nDd = nm2 + MH_TP;                                    // -D = -rowsum(dO * O)
+    float* lnp = nDd + MH_TP;                                    // LayerNorm gamma | beta [2 H], this head's q | k | v bias rows [3 dh]
+    T* dqs = reinterpret_cast<T*>(lnp + 2 * MB_H + 3 * MB_DH);   // dQ rows of the current chunk [MH_QC][24] (leave as 16-byte pieces of one 3 KB run)
+    T* dsb = dqs + MH_QC * MB_DH;                                // dS image of the current chunk [key][MH_RS]
+    T* wl = dsb;                                                 // (until the images are built: this head's 24 weight fragments)
+    PHASE_BEGIN(dsb + MH_TP * MH_RS);
+    const size_t ntok = (size_t)c.B * c.F * T_;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id_u();
+    const size_t n0 = (size_t)bf * T_;
+    const T* xb = x + n0 * MB_H;
+    const T* dyb = dy + n0 * MB_H;
+    const T* ob = osave + n0 * MB_H;
+    const float* bin = lp.p[P_INP_B];
+    const float rs_dh = rsqrtf((float)MB_DH);
+    const float qscale = 1.4426950408889634f * rs_dh;
+
+    int tt[2];
+    bool tv[2], sact[2];
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+        tt[si] = (w * 2 + si) * 16 + l15;
+        tv[si] = tt[si] < T_;
+        sact[si] = FULL || (w * 2 + si) < nst;  // wave-uniform
+    }
+    // wave-uniform sequence bases + 32-bit lane offsets (check_cfg: 3 H ntok < 2^31), so that no 64-bit lane addresses stay live
+    T* dq_seq = dqkv + n0 * MB_DH;
+    const int gstride = (int)ntok * MB_DH;
+    auto dqkv_off = [&](int grp, int t) -> int { return grp * gstride + t * MB_DH; };
+    const float* lse_seq = lse + n0 * MB_HEADS;
+    const float* stats_seq = stats + n0 * 2;
+
+    Frag<T> kf[2], vf[2];
+    // ---------------- prologue: EVERY global request first, then LayerNorm, then the four projections of this head ----------------
+    // (one memory round trip per workgroup: with two workgroups per CU nothing else hides a second one — the first version asked for
+    // gamma / beta after the statistics, for dy / O after the first barrier and for the bias rows inside the projections: 65 % of its wave
+    // time, profiles/r04b_phase_mhsa_bwd.txt)
+    {
+        Frag<T> uf[2][MB_KS], dr[2][MB_KS];
+        RawRow4<T> orw0[2], orw1[2];
+        float lsev[2];
+        f32x2 ms[2];
+        u32x4 wreg[3];  // 24 fragments = 1 536 16-byte pieces: in_proj (which, half, ks) of this head, then out_proj^T (half, ks)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int v = threadIdx.x + i * 512, lf = v >> 6, pl = v & 63;
+            const T* src = lf < 18 ? Win + ((size_t)(((lf / 6) * MB_HEADS + head) * 6 + lf % 6) * 64 + pl) * 8
+                                   : WoutT + ((size_t)(head * 6 + lf - 18) * 64 + pl) * 8;
+            wreg[i] = *reinterpret_cast<const u32x4*>(src);
+        }
+        // LayerNorm gamma | beta (48 four-float pieces) and this head's q | k | v bias rows (18 pieces) go through LDS
+        f32x4 ppc = F32X4_ZERO;
+        {
+            const int t = threadIdx.x;
+            const float* src = t < 24 ? lp.p[P_MH_LN_W] + 4 * t : t < 48 ? lp.p[P_MH_LN_B] + 4 * (t - 24)
+                                      : bin + ((t - 48) / 6) * MB_H + head * MB_DH + 4 * ((t - 48) % 6);
+            if (t < 66) ppc = *reinterpret_cast<const f32x4*>(src);
+        }
+        // Global rows are read as 16-byte pieces of CONTIGUOUS runs (a strip of x / dy is 3 KB, a strip of this head's O columns 16 x 48 B) and
+        // turned into MFMA fragments through a wave-private LDS round trip: the direct fragment form (lane = token l15, piece g4) makes the four
+        // lanes of every quad touch four different rows — 64 cache-line lookups per wave instruction instead of 8, and the vector memory pipe,
+        // not VALU or MFMA, was what this kernel waited for (TCP_TOTAL_CACHE_ACCESSES: 12 bytes per access, profiles/README.md round 4).
+        u32x4 xc[2][MB_KS], dc[2][MB_KS], oc[2];
+        const int tlast = T_ - 1;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            const int t0 = (w * 2 + si) * 16;
+#pragma unroll
+            for (int i = 0; i < MB_KS; ++i) {
+#ifdef MH_STAGE_X  // piece p = 64 i + lane of the strip's 192: row p / 12, 16-byte column p % 12
+                const int pc = i * 64 + lane, r = pc / 12, cc = pc - r * 12;
+                const int tr = t0 + r < tlast ? t0 + r : tlast;  // clamped: the padding frames' values are replaced on use
+                xc[si][i] = *reinterpret_cast<const u32x4*>(xb + (tr * MB_H + cc * 8));
+                dc[si][i] = *reinterpret_cast<const u32x4*>(dyb + (tr * MB_H + cc * 8));
+#else  // fragments straight from global memory (lane = token l15, piece g4)
+                const int tc = tv[si] ? tt[si] : tlast;
+                frag_load(uf[si][i], xb + (tc * MB_H + i * 32 + 8 * g4));
+                frag_load(dr[si][i], dyb + (tc * MB_H + i * 32 + 8 * g4));
+#endif
+            }
+        }
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            const int t0 = (w * 2 + si) * 16;
+            const int lo = lane < 48 ? lane : 47, r = lo / 3, cc = lo - r * 3;  // 48 pieces: row l / 3, 16-byte column l % 3 of the head's 48 bytes
+            const int tr = t0 + r < tlast ? t0 + r : tlast;
+            oc[si] = *reinterpret_cast<const u32x4*>(ob + (tr * MB_H + head * MB_DH + cc * 8));
+            const int tc = tv[si] ? tt[si] : tlast;
+            lsev[si] = lse_seq[tc * MB_HEADS + head];
+            ms[si] = *reinterpret_cast<const f32x2*>(stats_seq + tc * 2);
+        }
+        PHASE(8);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) reinterpret_cast<u32x4*>(wl)[threadIdx.x + i * 512] = wreg[i];
+        PHASE(9);
+        if (threadIdx.x < 66) *reinterpret_cast<f32x4*>(lnp + 4 * threadIdx.x) = ppc;
+        // wave-private staging: this wave's own rows of the Q' | K images (2 x 1.5 KB = one strip of x or dy) and of the dO image (O rows);
+        // nobody else touches them before the barrier that follows the projections
+        {
+            T* sA = Qr + w * 32 * MB_DH;
+            T* sB = Kr + w * 32 * MB_DH;
+            T* sO = dOr + w * 32 * MB_DH;
+            auto stg = [&](int pc) -> T* { return (pc < 96 ? sA : sB - 96 * 8) + pc * 8; };  // piece pc of a strip
+            auto fr = [&](int ks) -> const T* { const int pc = l15 * 12 + ks * 4 + g4; return (pc < 96 ? sA : sB - 96 * 8) + pc * 8; };
+#ifdef MH_STAGE_X
+#pragma unroll
+            for (int which = 0; which < 2; ++which)
+#pragma unroll
+                for (int si = 0; si < 2; ++si) {
+#pragma unroll
+                    for (int i = 0; i < MB_KS; ++i) *reinterpret_cast<u32x4*>(stg(i * 64 + lane)) = which ? dc[si][i] : xc[si][i];
+                    wave_lds_sync();
+#pragma unroll
+                    for (int ks = 0; ks < MB_KS; ++ks) frag_load(which ? dr[si][ks] : uf[si][ks], fr(ks));
+                    wave_lds_sync();
+                }
+#endif
+#pragma unroll
+            for (int si = 0; si < 2; ++si)
+                if (lane < 48) *reinterpret_cast<u32x4*>(sO + si * 16 * MB_DH + lane * 8) = oc[si];
+            wave_lds_sync();
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                orw0[si].load(sO + (si * 16 + l15) * MB_DH + 4 * g4);
+                orw1[si].load(sO + (si * 16 + l15) * MB_DH + 16 + 4 * (g4 & 1));
+            }
+            wave_lds_sync();
+        }
+        // LayerNorm statistics: the forward pass left (mean, rstd) of every token in the save buffer (layout.h: mhsa_stat_offset) — recomputing
+        // them was 4 of the prologue's 8.5 VALU operations per element, in a kernel whose VALU is busier than its MFMA pipe
+        float mean[2], rsv[2];
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            mean[si] = ms[si][0];
+            rsv[si] = keep_if(tv[si], ms[si][1]);  // padding frames (a clamped, finite row was loaded): LN(x) = beta without a branch per element
+        }
+        PHASE(10);
+        lds_barrier();  // the weight fragments and the parameter rows are in LDS
+        PHASE(0);
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            const short dmask = tv[si] ? (short)-1 : (short)0;
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                float gm[8], bt[8];
+                load8(lnp + ks * 32 + 8 * g4, gm);
+                load8(lnp + MB_H + ks * 32 + 8 * g4, bt);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) frag_set(uf[si][ks], j, (frag_get(uf[si][ks], j) - mean[si]) * rsv[si] * gm[j] + bt[j]);
+                dr[si][ks].v &= dmask;  // dy = 0 for padding frames
+            }
+            sched_fence();
+        }
+#pragma unroll
+        for (int which = 0; which < 4; ++which) {  // 0 q, 1 k, 2 v, 3 dO
+            f32x4 ct[2][2];
+#pragma unroll
+            for (int si = 0; si < 2; ++si) ct[si][0] = ct[si][1] = F32X4_ZERO;
+#pragma unroll
+            for (int ks = 0; ks < MB_KS; ++ks) {
+                Frag<T> a[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) frag_load(a[half], wl + (((which * 6 + half * MB_KS + ks) * 64 + lane) * 8));
+#pragma unroll
+                for (int si = 0; si < 2; ++si) {
+                    if (!sact[si]) continue;
+                    ct[si][0] = mma(a[0], which < 3 ? uf[si][ks] : dr[si][ks], ct[si][0]);
+                    ct[si][1] = mma(a[1], which < 3 ? uf[si][ks] : dr[si][ks], ct[si][1]);
+                }
+            }
+            float b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (which < 3) {
+                load4(lnp + 2 * MB_H + which * MB_DH + 4 * g4, b0);
+                load4(lnp + 2 * MB_H + which * MB_DH + 16 + 4 * (g4 & 1), b1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b1[r] = keep_if(g4 < 2, b1[r]);
+            }
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                if (!sact[si]) continue;
+                const int t = tt[si];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ct[si][0][r] += b0[r];
+                    ct[si][1][r] += b1[r];
+                    if (which == 0) {
+                        ct[si][0][r] *= qscale;
+                        ct[si][1][r] *= qscale;
+                    }
+                    if (which == 1) {  // padding frames: zero keys (their dS columns then vanish from dQ)
+                        ct[si][0][r] = keep_if(tv[si], ct[si][0][r]);
+                        ct[si][1][r] = keep_if(tv[si], ct[si][1][r]);
+                    }
+                }
+                if (which == 0) {
+                    store_row24<T>(Qr + t * MB_DH, ct[si][0], ct[si][1]);
+                } else if (which == 1) {
+                    frag_pack_c2(kf[si], ct[si][0], ct[si][1]);
+                    store_row24<T>(Kr + t * MB_DH, ct[si][0], ct[si][1]);
+                } else if (which == 2) {
+                    frag_pack_c2(vf[si], ct[si][0], ct[si][1]);
+                } else {
+                    store_row24<T>(dOr + t * MB_DH, ct[si][0], ct[si][1]);
+                    // D = rowsum(dO * O) with the saved forward attention output
+                    float o0[4], o1[4];
+                    orw0[si].get(o0);
+                    orw1[si].get(o1);
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dsum += round_to(ct[si][0][r], x) * keep_if(tv[si], o0[r]) + round_to(ct[si][1][r], x) * keep_if(tv[si] && g4 < 2, o1[r]);
+                    const float Dv = wave_sum16(dsum);
+                    if (g4 == 0) {
+                        nDd[t] = -Dv;
+                        nm2[t] = tv[si] ? -lsev[si] : -1e30f;  // padding frame: P = exp2(S - 1e30) = 0
+                    }
+                }
+            }
+        }
+    }
+    PHASE(1);
+    lds_barrier();  // images complete; nobody reads the weight fragments any more (the dS image takes their place)
+    PHASE(2);
+
+    f32x4 dk[2][2], dv[2][2];
+#pragma unroll
+    for (int si = 0; si < 2; ++si) dk[si][0] = dk[si][1] = dv[si][0] = dv[si][1] = F32X4_ZERO;
+    const int qs = w >> 1, qh = w & 1;  // dQ role: query strip of the chunk, dh half
+    const int nch = FULL ? MH_TP / MH_QC : cdiv(nkp, 2);
+    for (int ch = 0; ch < nch; ++ch) {
+        // ---------------- key side: this wave's 32 keys x the chunk's 64 queries ----------------
+#pragma unroll
+        for (int jl = 0; jl < 2; ++jl) {
+            const int jp = 2 * ch + jl;
+            if (!FULL && jp >= nkp) break;
+            Frag<T> qa[2], doa[2], aq[2], ado[2];
+            f32x4 nml[2], ndd[2];
+            const bool hi_valid = FULL || 2 * jp + 1 < nst;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jj = 2 * jp + e;
+                if (FULL || jj < nst) {
+                    row_pieces<T>(qa[e], Qr + (jj * 16 + l15) * MB_DH);
+                    row_pieces<T>(doa[e], dOr + (jj * 16 + l15) * MB_DH);
+                    nml[e] = *reinterpret_cast<const f32x4*>(nm2 + jj * 16 + 4 * g4);
+                    ndd[e] = *reinterpret_cast<const f32x4*>(nDd + jj * 16 + 4 * g4);
+                } else {
+                    frag_zero(qa[e]);
+                    frag_zero(doa[e]);
+                    nml[e] = (f32x4){-1e30f, -1e30f, -1e30f, -1e30f};
+                    ndd[e] = F32X4_ZERO;
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                col_frag_tr(ado[half], dOr, half, jp, hi_valid);
+                col_frag_tr(aq[half], Qr, half, jp, hi_valid);
+            }
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                if (!sact[si]) continue;
+                f32x4 pt[2], dst[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f32x4 sq = mma(qa[e], kf[si], nml[e]);   // rows = queries 16 jj + 4 g4 + r, column = key l15
+                    const f32x4 dp = mma(doa[e], vf[si], ndd[e]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(sq[r]);
+                        pt[e][r] = p;
+                        dst[e][r] = p * dp[r];
+                    }
+                }
+                Frag<T> pf, dsf;
+                frag_pack_c2(pf, pt[0], pt[1]);
+                frag_pack_c2(dsf, dst[0], dst[1]);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    dv[si][half] = mma(ado[half], pf, dv[si][half]);
+                    dk[si][half] = mma(aq[half], dsf, dk[si][half]);
+                }
+                // dS[key][query]: this lane's key row, queries 4 g4 + r of the pair's two tiles
+                const u32x4 dsv = __builtin_bit_cast(u32x4, dsf.v);
+                T* drow = dsb + (tt[si] * MH_RS + jl * 32 + 4 * g4);
+                *reinterpret_cast<u32x2*>(drow) = (u32x2){dsv[0], dsv[1]};
+                *reinterpret_cast<u32x2*>(drow + 16) = (u32x2){dsv[2], dsv[3]};
+            }
+        }
+        PHASE(3);
+        lds_barrier();  // the chunk's dS image is complete
+        PHASE(4);
+        // ---------------- query side: dQ^T (this wave: strip qs of the chunk, dh half qh) over all keys ----------------
+        if (FULL || 4 * ch + qs < nst) {
+            f32x4 acc[2] = {F32X4_ZERO, F32X4_ZERO};
+#pragma unroll 4
+            for (int kb = 0; kb < nkp; ++kb) {
+                const bool hi_valid = FULL || 2 * kb + 1 < nst;
+                Frag<T> akt, dst;
+                col_frag_tr(akt, Kr, qh, kb, hi_valid);
+                const T* p = dsb + ((kb * 32 + 4 * g4 + (l15 >> 2)) * MH_RS + qs * 16 + 4 * (l15 & 3));
+                const u32x2 lo = lds_tr4_b16(p);
+                u32x2 hi = {0u, 0u};
+                if (hi_valid) hi = lds_tr4_b16(p + 16 * MH_RS);
+                const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+                dst.v = __builtin_bit_cast(s16x8, v);
+                acc[kb & 1] = mma(akt, dst, acc[kb & 1]);
+            }
+            if (qh == 0 || g4 < 2)
+                store4(dqs + ((qs * 16 + l15) * MB_DH + qh * 16 + 4 * g4), (acc[0][0] + acc[1][0]) * rs_dh, (acc[0][1] + acc[1][1]) * rs_dh,
+                       (acc[0][2] + acc[1][2]) * rs_dh, (acc[0][3] + acc[1][3]) * rs_dh);
+        }
+        PHASE(5);
+        lds_barrier();  // dQ rows staged; the dS image may be overwritten
+        PHASE(6);
+        {   // the chunk's dQ rows are one 3 KB run of the group-major operand: 24 16-byte pieces per wave
+            const int pc = w * 24 + lane, tq = ch * MH_QC + pc / 3;
+            if (lane < 24 && tq < T_) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(dqs + pc * 8);
+                store16_nt(dq_seq + (dqkv_off(head, ch * MH_QC) + pc * 8), v);
+            }
+        }
+    }
+    {   // dK, dV rows of this wave's 32 keys: through its own rows of the Q' / dO images (dead since the last key-side pass; the barrier after it
+        // has been passed by everyone) and out as 16-byte pieces of one 1.5 KB run each
+        T* sK = Qr + w * 32 * MB_DH;
+        T* sV = dOr + w * 32 * MB_DH;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+            if (!sact[si]) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dk[si][0][r] *= 0.6931471805599453f;  // Q' carries log2(e)/sqrt(dh): dk = dS^T q / sqrt(dh) = dS^T Q' ln2
+                dk[si][1][r] *= 0.6931471805599453f;
+            }
+            store_row24<T>(sK + (si * 16 + l15) * MB_DH, dk[si][0], dk[si][1]);
+            store_row24<T>(sV + (si * 16 + l15) * MB_DH, dv[si][0], dv[si][1]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // 96 pieces per tensor: row pc / 3
+            const int pc = i * 64 + lane, t = w * 32 + pc / 3;
+            if (pc < 96 && t < T_) {  // (padding keys only ever produced their own, discarded, rows)
+                const u32x4 vk = *reinterpret_cast<const u32x4*>(sK + pc * 8), vv = *reinterpret_cast<const u32x4*>(sV + pc * 8);
+                store16_nt(dq_seq + (dqkv_off(1 * MB_HEADS + head, w * 32) + pc * 8), vk);
+                store16_nt(dq_seq + (dqkv_off(2 * MB_HEADS + head, w * 32) + pc * 8), vv);
+            }
+        }
+    }
+    PHASE(7);
+    PHASE_END();
+}
+
 int tailw_mhsa(const nbss_cfg& c, const LayerPtrs& lp, const void* packed, int layer, const void* x, const void* dy, void* dx, float* stats,
                const void* dqkv, float* wgpart, float* G, hipStream_t st, const Side* sd, hipStream_t* gs);
 
@@ -629,6 +1019,22 @@ static int mhsa_bwd_t(const nbss_cfg& c, const float* P, float* part, const void
     return NBSS_CHECK_LAUNCH();
 }
 
+template <bool FULL>
+static int mhsa_bwd_h_t(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, const void* dy, const void* osave, const float* stats,
+                        void* dqkv, hipStream_t st) {
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    if (c.T > MH_TP) return NBSS_EUNSUPPORTED;
+    const size_t lds = (size_t)3 * MH_TP * MB_DH * sizeof(bf16_t) + (size_t)(2 * MH_TP + 2 * MB_H + 3 * MB_DH) * sizeof(float) + (size_t)(MH_QC * MB_DH + MH_TP * MH_RS) * sizeof(bf16_t) + PHASE_LDS_BYTES;  // 76 KB: two per CU
+    const bf16_t* pk = (const bf16_t*)packed;
+    int e = NBSS_SET_MAX_LDS((mhsa_bwd_h_kernel<FULL>), lds);
+    if (e) return e;
+    const int nseq = c.B * c.F;
+    dim3 grid(cdiv(nseq, 8) * 8 * MB_HEADS), block(512);
+    NBSS_LAUNCH((mhsa_bwd_h_kernel<FULL>), grid, block, lds, st, c, lp, nseq, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_OUTP_T), (const bf16_t*)x,
+                (const bf16_t*)dy, (const bf16_t*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)), stats, (bf16_t*)dqkv);
+    return NBSS_CHECK_LAUNCH();
+}
+
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                   void* dx, void* ws, hipStream_t st, const Side* sd) {
     if (c.H != MB_H) return gb_mhsa_bwd(c, P, G, layer, x, dy, dx, ws, st, sd);
@@ -643,11 +1049,18 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
 #else
     const bool xt = c.dtype == NBSS_BF16;  // tail + in_proj weight gradient in tailw.hip
 #endif
+#ifndef NBSS_MHSA_BWD_V1
+    // single-sweep kernel: the LayerNorm row statistics are the forward pass's (save buffer), for it and for the tail kernel
+    if (xt) stats = (float*)((char*)osave + mhsa_stat_offset(c));
+#endif
     int e;
     hipStream_t gs = st;  // parameter-gradient launches (side.h)
     {
     ProfScope ps(PK_MHSA_B, st);  // ONE profiler interval per nbss_mhsa_bwd call: data-gradient kernel (+ fused tail / in_proj wgrad kernel)
     e = c.dtype != NBSS_BF16 ? mhsa_bwd_t<float, false, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
+#ifndef NBSS_MHSA_BWD_V1  // (A/B flavour: the two-sweep kernel of rounds 1-3)
+            : xt ? (full ? mhsa_bwd_h_t<true>(c, P, packed, layer, x, dy, osave, stats, dqkv, st) : mhsa_bwd_h_t<false>(c, P, packed, layer, x, dy, osave, stats, dqkv, st))
+#endif
             : xt ? (full ? mhsa_bwd_t<bf16_t, true, true>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
                          : mhsa_bwd_t<bf16_t, false, true>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st))
             : full ? mhsa_bwd_t<bf16_t, true, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)

@@ -45,18 +45,6 @@ NBSS_DEV f32x16 f32x16_zero() {
     return z;
 }
 
-// LDS written by one lane and read by another lane of the SAME wave: the hardware executes a wave's LDS instructions in order;
-// the compiler must not reorder across this point and the emulator's fibers must meet here
-NBSS_DEV void wave_lds_sync() {
-#ifdef NBSS_EMU
-    hipemu::wave_sync();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
-}
-
 NBSS_DEV float bf_lo(uint32_t d) { return __builtin_bit_cast(float, d << 16); }
 NBSS_DEV float bf_hi(uint32_t d) { return __builtin_bit_cast(float, d & 0xFFFF0000u); }
 
