@@ -120,7 +120,10 @@ class TrainModule(nn.Module):
         Tp = (T + chunk - 1) // chunk * chunk
         if Tp != T:
             feats = torch.nn.functional.pad(feats, (0, 0, 0, Tp - T))
-        key = (B, chunk, str(x.device))
+        # the native streamer keeps packed COPIES of the weights: the key carries a weights version (every in-place update — optimizer step,
+        # load_state_dict, load_checkpoint — bumps a parameter's _version), so a cached streamer never serves stale weights
+        wver = sum(int(p._version) for p in self.arch.parameters()) + sum(int(b._version) for b in self.arch.buffers())
+        key = (B, chunk, str(x.device), use_graph, native, wver, tuple(id(p) for p in self.arch.parameters()))
         if getattr(self, "_streamer_key", None) != key:
             # on a HIP device the native step (nbss_amd/online.py: HIP kernels for the causal encoder, the recurrent retention and the causal
             # T-ConvFFN + the cross-band kernels, one HIP graph per chunk) serves the geometry it is built for; everything else — other
@@ -238,11 +241,11 @@ def _unique_params(module: "TrainModule"):
     return list(module.named_parameters())
 
 
-def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, global_step: int = 0) -> None:
+def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, global_step: int = 0, plateau: "Optional[_Plateau]" = None) -> None:
     """Lightning-shaped checkpoint that the reference's trainer can load: `state_dict` with the reference's keys (`arch.*` and the
     persistent `stft.window` buffer, general_steps.py:189-199), `optimizer_states[0]` as a torch.optim.Adam state_dict (per-parameter
     `exp_avg` / `exp_avg_sq` / `step` sliced out of the fused optimizer's flat buffers, in `module.parameters()` order),
-    `lr_schedulers` (a full ExponentialLR state_dict), `epoch`, `global_step`, `pytorch-lightning_version`.  Weights, optimizer and
+    `lr_schedulers` (a full ExponentialLR — or, with `plateau`, ReduceLROnPlateau — state_dict), `epoch`, `global_step`, `pytorch-lightning_version`.  Weights, optimizer and
     scheduler are Lightning-resumable; `loops` (Lightning's fit-loop progress counters) is left empty — Lightning then restarts its
     epoch counter from `epoch`."""
     sd = {"arch." + k: v.detach().cpu().clone() for k, v in module.arch.state_dict().items()}
@@ -260,16 +263,20 @@ def save_checkpoint(path: str, module: "TrainModule", ts=None, epoch: int = 0, g
         group = {"lr": float(ts.lr), "betas": tuple(ts.betas), "eps": ts.eps, "weight_decay": ts.wd, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
         ck["optimizer_states"] = [{"state": state, "param_groups": [group]}]
-        # a complete torch.optim.lr_scheduler.ExponentialLR.state_dict() (what Lightning stores and restores)
-        gamma = float((module.lr_scheduler or (None, {}))[1].get("gamma", 1.0)) if module.lr_scheduler and module.lr_scheduler[0] == "ExponentialLR" else 1.0
-        base_lr = float(module.optimizer[1].get("lr", 1e-3))
-        ck["lr_schedulers"] = [{"gamma": gamma, "base_lrs": [base_lr], "last_epoch": epoch + 1, "verbose": False, "_step_count": epoch + 2,
-                                "_get_lr_called_within_step": False, "_last_lr": [float(ts.lr)]}]
+        if plateau is not None:
+            # a torch.optim.lr_scheduler.ReduceLROnPlateau.state_dict(): best / bad-epoch count / cooldown travel with the checkpoint
+            ck["lr_schedulers"] = [plateau.state_dict(ts.lr)]
+        else:
+            # a complete torch.optim.lr_scheduler.ExponentialLR.state_dict() (what Lightning stores and restores)
+            gamma = float((module.lr_scheduler or (None, {}))[1].get("gamma", 1.0)) if module.lr_scheduler and module.lr_scheduler[0] == "ExponentialLR" else 1.0
+            base_lr = float(module.optimizer[1].get("lr", 1e-3))
+            ck["lr_schedulers"] = [{"gamma": gamma, "base_lrs": [base_lr], "last_epoch": epoch + 1, "verbose": False, "_step_count": epoch + 2,
+                                    "_get_lr_called_within_step": False, "_last_lr": [float(ts.lr)]}]
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ck, path)
 
 
-def load_checkpoint(path: str, module: "TrainModule", ts=None) -> int:
+def load_checkpoint(path: str, module: "TrainModule", ts=None, plateau: "Optional[_Plateau]" = None) -> int:
     """weights and — when `ts` is given — the Adam moments / step / decayed lr of a checkpoint written by save_checkpoint OR by the
     reference's Lightning trainer (same layout: torch.optim state indexed in `module.parameters()` order); returns the epoch to resume
     after.  A checkpoint without optimizer state resumes with fresh moments and says so."""
@@ -293,6 +300,8 @@ def load_checkpoint(path: str, module: "TrainModule", ts=None) -> int:
             ts.lr = float(opt["param_groups"][0]["lr"])
         else:
             print(f"[SharedTrainer] {path} has no optimizer state: Adam moments, step count and learning rate start fresh", flush=True)
+    if plateau is not None and ck.get("lr_schedulers"):
+        plateau.load_state_dict(ck["lr_schedulers"][0])
     return int(ck.get("epoch", -1))
 
 
@@ -320,7 +329,7 @@ def _fused_step_for(module: "TrainModule", cfg: dict, dev):
         if sname == "ExponentialLR":
             gamma = float(skw.get("gamma", 1.0))
         elif sname == "ReduceLROnPlateau":  # on the monitored validation metric (general_steps.py:259-271): handled by fit()'s _Plateau
-            gamma = _Plateau(**{k: v for k, v in skw.items() if k in ("mode", "factor", "patience", "threshold", "min_lr", "cooldown")})
+            gamma = _Plateau(**{k: v for k, v in skw.items() if k not in ("verbose", "optimizer")})  # unknown arguments raise, none is dropped
         else:
             raise NotImplementedError(f"lr_scheduler {sname}: ExponentialLR (configs/SpatialNet.yaml) and ReduceLROnPlateau are implemented")
     ts = TrainStep(eng, n_fft=module.stft.n_fft, ref_channel=module.channels.index(module.ref_channel), lr=okw.get("lr", 1e-3),
@@ -331,24 +340,60 @@ def _fused_step_for(module: "TrainModule", cfg: dict, dev):
 
 
 class _Plateau:
-    """torch.optim.lr_scheduler.ReduceLROnPlateau's rule (mode / factor / patience / rel. threshold / cooldown / min_lr) on a plain float lr"""
+    """torch.optim.lr_scheduler.ReduceLROnPlateau's rule on a plain float lr (the fused optimizer has no torch param_groups): mode, factor,
+    patience, threshold + threshold_mode (rel | abs), cooldown, min_lr and the eps rule (a reduction smaller than eps is ignored).
+    state_dict() / load_state_dict() use torch's field names, so a checkpoint written here resumes under Lightning and vice versa."""
 
-    def __init__(self, mode: str = "min", factor: float = 0.1, patience: int = 10, threshold: float = 1e-4, min_lr: float = 0.0, cooldown: int = 0):
-        self.mode, self.factor, self.patience, self.threshold, self.min_lr, self.cooldown = mode, factor, patience, threshold, min_lr, cooldown
-        self.best, self.bad, self.cool = None, 0, 0
+    def __init__(self, mode: str = "min", factor: float = 0.1, patience: int = 10, threshold: float = 1e-4, threshold_mode: str = "rel",
+                 cooldown: int = 0, min_lr: float = 0.0, eps: float = 1e-8, **unknown):
+        if unknown:
+            raise NotImplementedError(f"ReduceLROnPlateau arguments {sorted(unknown)} are not implemented by the fused step")
+        if mode not in ("min", "max") or threshold_mode not in ("rel", "abs"):
+            raise ValueError(f"ReduceLROnPlateau: mode={mode!r}, threshold_mode={threshold_mode!r}")
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        if isinstance(min_lr, (list, tuple)):
+            if len(min_lr) != 1:
+                raise NotImplementedError("the fused optimizer has one parameter group: min_lr must be one value")
+            min_lr = min_lr[0]
+        self.mode, self.factor, self.patience, self.threshold, self.threshold_mode = mode, float(factor), int(patience), float(threshold), threshold_mode
+        self.cooldown, self.min_lr, self.eps = int(cooldown), float(min_lr), float(eps)
+        self.best = float("inf") if mode == "min" else -float("inf")
+        self.bad, self.cool, self.last_epoch, self.last_lr = 0, 0, 0, None
+
+    def _is_better(self, a: float) -> bool:
+        if self.mode == "min":
+            return a < (self.best * (1.0 - self.threshold) if self.threshold_mode == "rel" else self.best - self.threshold)
+        return a > (self.best * (self.threshold + 1.0) if self.threshold_mode == "rel" else self.best + self.threshold)
 
     def step(self, metric: float, lr: float) -> float:
-        better = self.best is None or (metric < self.best * (1 - self.threshold) if self.mode == "min" else metric > self.best * (1 + self.threshold))
-        if better:
+        metric = float(metric)
+        self.last_epoch += 1
+        if self._is_better(metric):
             self.best, self.bad = metric, 0
         else:
             self.bad += 1
         if self.cool > 0:
-            self.cool, self.bad = self.cool - 1, 0
+            self.cool, self.bad = self.cool - 1, 0  # bad epochs are ignored in cooldown
         if self.bad > self.patience:
+            new_lr = max(lr * self.factor, self.min_lr)
+            if lr - new_lr > self.eps:
+                lr = new_lr
             self.cool, self.bad = self.cooldown, 0
-            return max(lr * self.factor, self.min_lr)
+        self.last_lr = lr
         return lr
+
+    def state_dict(self, lr: float) -> dict:
+        return {"factor": self.factor, "min_lrs": [self.min_lr], "default_min_lr": self.min_lr, "patience": self.patience, "cooldown": self.cooldown,
+                "eps": self.eps, "last_epoch": self.last_epoch, "_last_lr": [float(lr)], "mode_worse": float("inf") if self.mode == "min" else -float("inf"),
+                "mode": self.mode, "threshold": self.threshold, "threshold_mode": self.threshold_mode, "best": self.best,
+                "cooldown_counter": self.cool, "num_bad_epochs": self.bad}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if "num_bad_epochs" not in sd:
+            raise RuntimeError("checkpoint's lr_schedulers entry is not a ReduceLROnPlateau state (the YAML's lr_scheduler changed since it was written)")
+        self.best, self.bad, self.cool = float(sd["best"]), int(sd["num_bad_epochs"]), int(sd["cooldown_counter"])
+        self.last_epoch = int(sd.get("last_epoch", 0))
 
 
 def _check_train_geometry(module: "TrainModule", data=None) -> None:
@@ -407,7 +452,7 @@ def fit(cfg: dict) -> Dict[str, Any]:
     eng, ts, gamma = _fused_step_for(module, cfg, dev)
     first_epoch = 0
     if cfg.get("ckpt_path"):
-        first_epoch = load_checkpoint(cfg["ckpt_path"], module, ts) + 1  # (weights again: a no-op; now also the Adam state)
+        first_epoch = load_checkpoint(cfg["ckpt_path"], module, ts, gamma if isinstance(gamma, _Plateau) else None) + 1  # (weights again: a no-op; now also the Adam and scheduler state)
         eng.version += 1
     ts.sync_replicas()  # rank 0's parameters / Adam state / step / lr on every rank (Lightning DDP's broadcast at fit start); no-op on one GPU
     ckpt_dir = tr.get("default_root_dir")
@@ -436,7 +481,8 @@ def fit(cfg: dict) -> Dict[str, Any]:
         if rank == 0:
             print(json.dumps(rec), flush=True)
             if ckpt_dir:
-                save_checkpoint(os.path.join(ckpt_dir, "checkpoints", "last.ckpt"), module, ts, epoch, global_step=ts.step_count)
+                save_checkpoint(os.path.join(ckpt_dir, "checkpoints", "last.ckpt"), module, ts, epoch, global_step=ts.step_count,
+                                plateau=gamma if isinstance(gamma, _Plateau) else None)
     if world > 1:
         torch.distributed.destroy_process_group()
     return {"log": log, "module": module}

@@ -181,6 +181,14 @@ int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, 
                         float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int flags,
                         void* stream);
 
+/* The same update for HIP-graph replay (nbss_amd/engine.py: TrainStep.graph_step; the reference's per-step host work is Lightning's optimizer
+ * loop, general_steps.py:243-271): the per-step scalars are read from the DEVICE buffer hyper[3] = {lr, 1 - beta1^step, sqrt(1 - beta2^step)},
+ * which nbss_adam_hyper fills on the HOST (hyper_host: 3 floats of host memory, copied to the device by the caller before the replay) with the
+ * very expressions nbss_clip_adam_step evaluates — a replayed step is bitwise the eager one. */
+int nbss_clip_adam_step_dev(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* scratch, const float* hyper, float max_norm,
+                            float grad_scale, float beta1, float beta2, float eps, float weight_decay, int flags, void* stream);
+int nbss_adam_hyper(int step, float lr, float beta1, float beta2, float* hyper_host);
+
 /* ---- OnlineSpatialNet: native streaming step (models/arch/OnlineSpatialNet.py:22-60,171-200,333-354; base/retention.py:194-253) -------
  * One call advances a chunk of C <= 32 frames of every (batch, frequency) sequence; all state lives in caller-owned fp32 device
  * buffers updated in place, so a whole step is a fixed launch sequence (capturable in a HIP graph).  fp32; geometry: dim_hidden 96,
@@ -201,7 +209,8 @@ int nbss_online_mhsa_step(int BF, int C, int scope, int ring, const float* ln_w,
 int nbss_online_advance(int32_t* pos, int C, void* stream);
 /* x += causal T-ConvFFN(x): LayerNorm -> 1x1 -> SiLU -> causal gconv -> SiLU -> causal gconv -> GroupNorm of each FRAME over (24 channels
  * x all F frequencies) -> SiLU -> causal gconv -> SiLU -> 1x1.  w1_t [96][192], w2_t [192][96] transposed; conv weights [192][24][3];
- * s1 s2 s3 [BF][2][192] = the last two input frames of the three convs; a3 [BF][C][192] and gn_sums [B][C][8][2] are scratch. */
+ * s1 s2 s3 [BF][2][192] = the last two input frames of the three convs; a3 [BF][C][192] and gn_sums [B + BF][C][8][2] (the per-frame
+ * GroupNorm sums, then every frequency's partials: folded in frequency order, no atomics — bitwise repeatable) are scratch. */
 int nbss_online_tconvffn_step(int B, int F, int C, const float* ln_w, const float* ln_b, const float* w1_t, const float* b1, const float* c1w,
                               const float* c1b, const float* c2w, const float* c2b, const float* gn_w, const float* gn_b, const float* c3w, const float* c3b,
                               const float* w2_t, const float* b2, float* s1, float* s2, float* s3, float* a3, float* gn_sums, float* x, void* stream);

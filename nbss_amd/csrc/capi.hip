@@ -35,6 +35,9 @@ int inorm_istft_impl(int nfft, int B, int S, int N, const float* tab, const floa
 int inorm_istft_bwd_impl(int nfft, int B, int S, int N, const float* tab, const float* dy, const float* xrmm, float* dout, hipStream_t st);
 size_t pit_ws_floats(int B, int S);
 int pit_sisdr_impl(int B, int S, int N, const float* p, const float* t, float* loss, int* perm, float* dp, float* ws, hipStream_t st);
+int clip_adam_dev_impl(size_t n, float* p, float* g, float* m, float* v, float* scal, const float* hyper, float max_norm, float grad_scale, float beta1,
+                       float beta2, float eps, float wd, int flags, hipStream_t st);
+int adam_hyper_impl(int step, float lr, float beta1, float beta2, float* out);
 int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal, float max_norm, float grad_scale, float lr, float beta1,
                    float beta2, float eps, float wd, int step, int flags, hipStream_t st);
 
@@ -239,7 +242,14 @@ struct SideState {
     int ncu = 256;
 };
 static SideState g_side;
-static SideState* side_state() {
+// `st` = the caller's stream: while it is being captured into a HIP graph the walks stay in order on it (a captured fork / join per sub-block
+// turns the graph into ~100 branches, which ROCm 7.2 replays at ~45 us per kernel node: batch 2 went from 5.7 ms eager to 13.6 ms replayed;
+// the linear chain replays at the ~1.5 us boundary cost)
+static SideState* side_state(hipStream_t st = nullptr) {
+    if (st) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+    }
     SideState& s = g_side;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -284,7 +294,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     // tail launches of the bf16 row kernels (side.h: SeqTail): when the last round of sequences is at most half full
     SeqTail tl = {0, st};
 #ifndef NBSS_EMU
-    SideState* ss = side_state();
+    SideState* ss = side_state(st);
     const int ncu = ss ? ss->ncu : 0;
     if (ss) tl.ts = ss->sd.gs;
 #else
@@ -338,7 +348,7 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
     int k = 5 * layer_hi;
     int e;
 #ifndef NBSS_EMU
-    SideState* ss = side_state();
+    SideState* ss = side_state(st);
     Side side;
     if (ss) {
         side = ss->sd;
@@ -348,20 +358,23 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
     bool rec[BWD_KINDS] = {false, false, false, false, false};
     int reader[3] = {-1, -1, -1};  // kind whose gradient-stream launches read buffer b (as their dy)
     // before sub-block `kind` writes buffer `out`: its own workspace copy and that buffer must be free of gradient-stream readers
+    // (a failed wait / record would be a silent race on a workspace copy or a rotating gradient buffer: it ends the walk with NBSS_ELAUNCH)
+    bool ev_ok = true;
     auto before = [&](int kind, int out) {
         if (!ss) return;
-        if (rec[kind]) hipStreamWaitEvent(st, ss->done[kind], 0);
-        if (reader[out] >= 0 && reader[out] != kind) hipStreamWaitEvent(st, ss->done[reader[out]], 0);
+        if (rec[kind]) ev_ok = ev_ok && hipStreamWaitEvent(st, ss->done[kind], 0) == hipSuccess;
+        if (reader[out] >= 0 && reader[out] != kind) ev_ok = ev_ok && hipStreamWaitEvent(st, ss->done[reader[out]], 0) == hipSuccess;
         reader[out] = -1;
     };
     auto after = [&](int kind, int in) {
         if (!ss) return;
-        hipEventRecord(ss->done[kind], side.gs);
+        ev_ok = ev_ok && hipEventRecord(ss->done[kind], side.gs) == hipSuccess;
         rec[kind] = true;
         if (in >= 0) reader[in] = kind;  // (only the T-ConvFFN's W2 and the attention's out_proj problems contract against the upstream gradient)
     };
 #else
     const Side* sd = nullptr;
+    const bool ev_ok = true;
     auto before = [&](int, int) {};
     auto after = [&](int, int) {};
 #endif
@@ -384,6 +397,7 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
         before(4, (j + 5) % 3);
         if ((e = fconv_bwd_impl(c, params, grads, packed, l, 0, act(k - 5), gbuf(j + 4), gbuf(j + 5), wsk(4), st, sd))) return e;
         after(4, -1);
+        if (!ev_ok) return NBSS_ELAUNCH;
         j += BWD_KINDS;
         k -= 5;
     }
@@ -450,6 +464,15 @@ int nbss_clip_adam_step(int64_t n, float* params, float* grads, float* exp_avg, 
     return clip_adam_impl((size_t)n, params, grads, exp_avg, exp_avg_sq, scratch, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step,
                           flags, (hipStream_t)stream);
 }
+
+int nbss_clip_adam_step_dev(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* scratch, const float* hyper, float max_norm,
+                            float grad_scale, float beta1, float beta2, float eps, float weight_decay, int flags, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch || !hyper || n <= 0) return NBSS_EINVAL;
+    return clip_adam_dev_impl((size_t)n, params, grads, exp_avg, exp_avg_sq, scratch, hyper, max_norm, grad_scale, beta1, beta2, eps, weight_decay, flags,
+                              (hipStream_t)stream);
+}
+
+int nbss_adam_hyper(int step, float lr, float beta1, float beta2, float* hyper_host) { return adam_hyper_impl(step, lr, beta1, beta2, hyper_host); }
 
 static bool nb_dtype_ok(int dtype) { return dtype == NBSS_F32 || dtype == NBSS_BF16; }
 int64_t nbss_nb_ws_bytes(int Cout, int Cin, int groups, int taps) {

@@ -210,6 +210,48 @@ __global__ void adam_kernel(size_t n, float* __restrict__ p, float* __restrict__
     }
 }
 
+// the same update with the per-step scalars read from device memory: hyper = [lr, 1 - beta1^step, sqrt(1 - beta2^step)] (adam_hyper_impl) — a launch
+// without per-step arguments, replayable from a HIP graph (engine.py: TrainStep.graph_step)
+__global__ void adam_dev_kernel(size_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                const float* __restrict__ scal, const float* __restrict__ hyper, float beta1, float beta2, float eps, float wd, int flags) {
+    const float coef = scal[1], lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2];
+    const bool zero_grad = flags & 1, decoupled = flags & 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * coef;
+        float pi = p[i];
+        if (decoupled) pi -= lr * wd * pi;
+        else if (wd != 0.f) gi += wd * pi;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// host side of the pair: the three floats exactly as clip_adam_impl computes them (same powf / sqrtf), so that a replayed step is bitwise the eager one
+int adam_hyper_impl(int step, float lr, float beta1, float beta2, float* out) {
+    if (step < 1 || !out) return NBSS_EINVAL;
+    out[0] = lr;
+    out[1] = 1.f - powf(beta1, (float)step);
+    out[2] = sqrtf(1.f - powf(beta2, (float)step));
+    return NBSS_OK;
+}
+
+int clip_adam_dev_impl(size_t n, float* p, float* g, float* m, float* v, float* scal, const float* hyper, float max_norm, float grad_scale, float beta1,
+                       float beta2, float eps, float wd, int flags, hipStream_t st) {
+    float* part = scal + 2;
+    ProfScope ps(PK_ADAM, st);
+    NBSS_LAUNCH(sumsq_kernel, dim3(OP_BLOCKS), dim3(256), 64, st, n, (const float*)g, part);
+    int e = NBSS_CHECK_LAUNCH();
+    if (e) return e;
+    NBSS_LAUNCH(clip_coef_kernel, dim3(1), dim3(64), 0, st, OP_BLOCKS, (const float*)part, max_norm, grad_scale, scal);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH(adam_dev_kernel, dim3(1024), dim3(256), 0, st, n, p, g, m, v, (const float*)scal, hyper, beta1, beta2, eps, wd, flags);
+    return NBSS_CHECK_LAUNCH();
+}
+
 int clip_adam_impl(size_t n, float* p, float* g, float* m, float* v, float* scal /* >= 2 + OP_BLOCKS floats */, float max_norm, float grad_scale,
                    float lr, float beta1, float beta2, float eps, float wd, int step, int flags, hipStream_t st) {
     if (step < 1) return NBSS_EINVAL;

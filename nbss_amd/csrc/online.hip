@@ -164,13 +164,14 @@ NBSS_DEV float on_conv3(const float* __restrict__ wrow, float bias, const float*
 }
 
 // first half of the T-ConvFFN (up to the GroupNorm input).  w1_t [96][192]; conv weights [192][24][3] (the module's own layout);
-// s1, s2 [B*F][2][192]: the last two input frames of conv1 / conv2; a3 [B*F][C][192]; gn_sums [B][C][8][2], zeroed before the launch.
+// s1, s2 [B*F][2][192]: the last two input frames of conv1 / conv2; a3 [B*F][C][192]; gn_part [B*F][C][8][2]: per-frequency partial sums /
+// sums of squares of the GroupNorm input (no atomics: an inference path has to be bitwise repeatable).
 __global__ __launch_bounds__(ON_FFN) void online_tconv_a_kernel(int F, int C, const float* __restrict__ lw, const float* __restrict__ lb,
                                                                const float* __restrict__ w1_t, const float* __restrict__ b1,
                                                                const float* __restrict__ c1w, const float* __restrict__ c1b,
                                                                const float* __restrict__ c2w, const float* __restrict__ c2b, float* __restrict__ s1,
                                                                float* __restrict__ s2, const float* __restrict__ x, float* __restrict__ a3,
-                                                               float* __restrict__ gn_sums) {
+                                                               float* __restrict__ gn_part) {
     NBSS_LDS(smem);
     float* u = reinterpret_cast<float*>(smem);   // [C][96]
     float* h1 = u + C * ON_H;                    // [C + 2][192]
@@ -213,10 +214,20 @@ __global__ __launch_bounds__(ON_FFN) void online_tconv_a_kernel(int F, int C, co
             const int gg = j & 7, kind = j >> 3;
             float s = 0.f;
             for (int i = 0; i < ON_CG; ++i) s += red[kind * ON_FFN + gg * ON_CG + i];
-            atomicAdd(gn_sums + (((size_t)b * C + c) * ON_G + gg) * 2 + kind, s);
+            gn_part[(((size_t)bf * C + c) * ON_G + gg) * 2 + kind] = s;  // this frequency's partial: folded in a fixed order by online_gn_fold_kernel
         }
         __syncthreads();
     }
+}
+
+// GroupNorm statistics of a frame span all F frequencies of a batch item: the per-frequency partials are summed in frequency order (one thread
+// per (batch, frame, group, kind)), so the result does not depend on the order in which the first kernel's workgroups finished
+__global__ __launch_bounds__(64) void online_gn_fold_kernel(int F, int n_per_b, const float* __restrict__ gn_part, float* __restrict__ gn_sums) {
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;  // i over C * 8 * 2
+    if (i >= n_per_b) return;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += gn_part[((size_t)b * F + f) * n_per_b + i];
+    gn_sums[(size_t)b * n_per_b + i] = s;
 }
 
 // second half: GroupNorm of each frame over (24 channels x F frequencies), SiLU, causal conv3 + SiLU, 1x1 (192 -> 96), residual
@@ -389,11 +400,13 @@ int nbss_online_tconvffn_step(int B, int F, int C, const float* ln_w, const floa
         !s1 || !s2 || !s3 || !a3 || !gn_sums || !x)
         return NBSS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    int e = memset_async_impl(gn_sums, (size_t)B * C * ON_G * 2 * sizeof(float), st);
-    if (e) return e;
+    int e;
+    float* gn_part = gn_sums + (size_t)B * C * ON_G * 2;  // [B*F][C][8][2] behind the sums
     const size_t lds_a = ((size_t)C * ON_H + 2 * (size_t)(C + 2) * ON_FFN + 2 * ON_FFN) * sizeof(float);
     if ((e = NBSS_SET_MAX_LDS(online_tconv_a_kernel, lds_a))) return e;
-    NBSS_LAUNCH(online_tconv_a_kernel, dim3(B * F), dim3(ON_FFN), lds_a, st, F, C, ln_w, ln_b, w1_t, b1, c1w, c1b, c2w, c2b, s1, s2, (const float*)x, a3, gn_sums);
+    NBSS_LAUNCH(online_tconv_a_kernel, dim3(B * F), dim3(ON_FFN), lds_a, st, F, C, ln_w, ln_b, w1_t, b1, c1w, c1b, c2w, c2b, s1, s2, (const float*)x, a3, gn_part);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH(online_gn_fold_kernel, dim3((C * ON_G * 2 + 63) / 64, B), dim3(64), 0, st, F, C * ON_G * 2, (const float*)gn_part, gn_sums);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     const size_t lds_b = ((size_t)(C + 2) * ON_FFN + (size_t)C * ON_FFN) * sizeof(float);
     if ((e = NBSS_SET_MAX_LDS(online_tconv_b_kernel, lds_b))) return e;

@@ -28,10 +28,16 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+// a stream under graph capture takes no timing events (recording one there invalidates the capture): a captured step is simply not profiled
+static bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 void prof_begin(int id, hipStream_t st) {
     if (!((g_mask >> id) & 1)) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_pairs.size() >= kMaxPairs) { t_open[id] = nullptr; return; }
+    if (g_pairs.size() >= kMaxPairs || capturing(st)) { t_open[id] = nullptr; return; }
     hipEvent_t e = get_event();
     t_open[id] = e;
     if (e) (void)hipEventRecord(e, st);

@@ -11,6 +11,7 @@ behind include/nbss_hip.h.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -164,7 +165,7 @@ class TrainStep:
 
     def __init__(self, engine: SpatialNetEngine, *, n_fft: int = 256, ref_channel: int = 0, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, clip: float = 5.0, process_group=None, bucketed: bool = True, force_collectives: bool = False,
-                 decoupled_weight_decay: bool = False, window: int = 0):
+                 decoupled_weight_decay: bool = False, window: int = 0, graph: Optional[bool] = None):
         self.e = engine
         self.lib = engine.lib
         self.n_fft, self.ref = n_fft, ref_channel
@@ -183,6 +184,12 @@ class TrainStep:
         # collectives run when world > 1; tests force them on a 1-rank RCCL group to exercise the stream ordering on hardware
         self.collectives = self.world > 1 or force_collectives
         self.comm_wait_ms = None  # set to 0.0 by a caller that wants the host-visible time of the bucket waits accumulated (bench.py)
+        # HIP-graph replay of the step (graph_step below): opt-in.  Measured on MI355X / ROCm 7.2 (profiles/README.md round 4): the eager
+        # two-stream step is FASTER at every batch — batch 2: 5.77 ms eager, 6.09 ms replayed in order, 13.6 ms replayed with the walks'
+        # forks and joins captured (~45 us per kernel node of a branched graph); batch 8: 14.6 vs 15.2 ms — so None (the default) means off;
+        # NBSS_GRAPH=1 or graph=True turns it on (correct: tests/test_graph_step.py)
+        self.graph = graph
+        self._graphs = {}
 
     # ---- replica consistency (what Lightning's DDP does at fit start: broadcast of the module state from rank 0) --------
     def sync_replicas(self, src: int = 0) -> None:
@@ -231,10 +238,82 @@ class TrainStep:
 
     def step(self, x: Tensor, yr: Tensor) -> Tensor:
         """forward + backward + (all-reduce) + clip + Adam + re-pack; returns the loss (device tensor [1])"""
+        if self._use_graph(x):
+            return self.graph_step(x, yr)
         e = self.e
         loss, _, dout, xin, _ = self.forward_loss(x, yr, need_grad=True)
         self.backward_and_update(xin, dout)
         return loss
+
+    # ---- HIP-graph replay ---------------------------------------------------------------------------------------------------------------
+    # The step is a fixed launch sequence per input shape: STFT / network walk (its two library-owned streams fork and join inside the walk
+    # calls) / loss / walk back, then clip + Adam + re-pack.  It is captured as TWO graphs around the gradient exchange — A: forward + loss +
+    # backward into engine.grads; B: the optimizer — so that with world > 1 the RCCL all-reduce (one collective, outside any capture) sits
+    # between two replays.  Per-step scalars (learning rate, Adam bias corrections) travel through a 3-float device buffer, everything else
+    # is baked in; a change of shape, hyper-parameter or parameter storage captures afresh.
+    def _use_graph(self, x: Tensor) -> bool:
+        if not x.is_cuda or self.comm_wait_ms is not None:
+            return False
+        if self.graph is None:
+            return os.environ.get("NBSS_GRAPH") == "1"  # A/B knob of the tools
+        return bool(self.graph)
+
+    def graph_step(self, x: Tensor, yr: Tensor) -> Tensor:
+        e = self.e
+        key = (tuple(x.shape), tuple(yr.shape), e.dtype, self.betas, self.eps, self.wd, self.clip, self.decoupled_wd, self.world, e.params.data_ptr())
+        g = self._graphs.get(key)
+        if g is None or g["state"] == 0:
+            # first call with this key: one eager step (lazy one-time work — workspace allocation, kernel attributes, the library's streams —
+            # must not happen under capture); second call: capture, then replay
+            if g is None:
+                self._graphs[key] = {"state": 0}
+                e = self.e
+                loss, _, dout, xin, _ = self.forward_loss(x, yr, need_grad=True)
+                self.backward_and_update(xin, dout)
+                return loss
+            g = self._capture(key, x, yr)
+        if e.packed.get(e.dtype) is not g["packed"] or e._packed_version != e.version:
+            # something else re-packed in between (an eager step of another shape, load_params): bring the graph's own buffer up to date
+            ops.pack_params(self.lib, e.cfg_for(1, 16, e.dtype), e.params, out=g["packed"])
+            e.packed.clear()
+            e.packed[e.dtype] = g["packed"]
+            e._packed_version = e.version
+        g["x"].copy_(x, non_blocking=True)
+        g["yr"].copy_(yr, non_blocking=True)
+        g["a"].replay()
+        if self.collectives:
+            torch.distributed.all_reduce(e.grads, group=self.pg)
+        self.step_count += 1
+        self.lib.call("nbss_adam_hyper", int(self.step_count), float(self.lr), float(self.betas[0]), float(self.betas[1]), g["hyper_host"].data_ptr())
+        g["hyper"].copy_(g["hyper_host"], non_blocking=True)
+        g["b"].replay()
+        e.version += 1
+        e._packed_version = e.version  # the replayed re-pack refreshed the fragments in place
+        return g["loss"].clone()
+
+    def _capture(self, key, x: Tensor, yr: Tensor) -> dict:
+        e = self.e
+        g = {"state": 1, "x": torch.empty_like(x), "yr": torch.empty_like(yr), "hyper": torch.zeros(4, dtype=torch.float32, device=x.device),
+             "hyper_host": torch.zeros(4, dtype=torch.float32).pin_memory()}
+        g["x"].copy_(x)
+        g["yr"].copy_(yr)
+        g["packed"] = e.packed_for(e.dtype)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            loss, _, dout, xin, _ = self.forward_loss(g["x"], g["yr"], need_grad=True)
+            e.backward(xin, dout)
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            ops.clip_adam_step_dev(self.lib, e.params, e.grads, self.m, self.v, self.scratch, g["hyper"], betas=self.betas, eps=self.eps, weight_decay=self.wd,
+                                   max_norm=self.clip, grad_scale=1.0 / self.world, zero_grad=True, decoupled_weight_decay=self.decoupled_wd)
+            # re-pack IN PLACE: graph A reads this very buffer (a fresh one per step, as the eager path allocates, would leave the replayed
+            # forward on the fragments of the capture step)
+            ops.pack_params(self.lib, e.cfg_for(1, 16, e.dtype), e.params, out=g["packed"])
+        e.version += 1
+        e._packed_version = e.version
+        g.update(a=ga, b=gb, loss=loss)
+        self._graphs[key] = g
+        return g
 
     def backward_and_update(self, xin: Tensor, dout: Tensor) -> None:
         """network backward + gradient exchange + clip/Adam/re-pack"""

@@ -96,7 +96,7 @@ class NativeOnlineStreamer:
         BF, z = batch * self.F, lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)  # noqa: E731
         self.x, self.y = z(batch, self.F, chunk, self.din), z(batch, self.F, chunk, self.dout)
         self.h = [z(batch, self.F, chunk, 96), z(batch, self.F, chunk, 96)]
-        self.a3, self.gn_sums = z(BF, chunk, 192), z(batch, chunk, 8, 2)
+        self.a3, self.gn_sums = z(BF, chunk, 192), z(batch + BF, chunk, 8, 2)  # GroupNorm sums [B] + per-frequency partials [B*F] (fixed-order fold)
         self.state = {"enc": z(BF, 4, self.din), "s": [[z(BF, 2, 192) for _ in range(3)] for _ in range(self.L)]}
         if self.windowed:  # K / V rings of the last scope - 1 + chunk frames per layer, one device-side frame counter for the stream
             self.state["kring"] = [z(BF, self.ring, 96) for _ in range(self.L)]

@@ -258,6 +258,15 @@ def clip_adam_step(lib, params, grads, exp_avg, exp_avg_sq, scratch, step, lr=1e
              float(betas[1]), float(eps), float(weight_decay), int(step), int(bool(zero_grad)) | (2 if decoupled_weight_decay else 0), _stream(lib, params))
 
 
+def clip_adam_step_dev(lib, params, grads, exp_avg, exp_avg_sq, scratch, hyper, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=5.0,
+                       grad_scale=1.0, zero_grad=True, decoupled_weight_decay=False):
+    """clip_adam_step with the per-step scalars read from the DEVICE buffer `hyper` = [lr, 1 - beta1^step, sqrt(1 - beta2^step)] (filled by
+    nbss_adam_hyper on the host): the launch sequence has no per-step arguments and can be replayed from a HIP graph"""
+    lib.call("nbss_clip_adam_step_dev", params.numel(), _ptr(lib, params, torch.float32), _ptr(lib, grads, torch.float32), _ptr(lib, exp_avg, torch.float32),
+             _ptr(lib, exp_avg_sq, torch.float32), _ptr(lib, scratch, torch.float32), _ptr(lib, hyper, torch.float32), float(max_norm), float(grad_scale),
+             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(bool(zero_grad)) | (2 if decoupled_weight_decay else 0), _stream(lib, params))
+
+
 def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:
     D = torch.empty(16, 16, dtype=torch.float32, device=A.device)
     lib.call("nbss_selftest_mma", dtype, kperm, _ptr(lib, A, torch.float32), _ptr(lib, B, torch.float32), _ptr(lib, D), _stream(lib, A))

@@ -79,9 +79,10 @@ def bf16_reference_errors():
         a, b = a.double(), b.double()
         return float((a - b).norm() / b.norm()) if float(b.norm()) > 0 else float(a.norm())
 
-    def run(F, T, L, sd, x, r):
+    def run(F, T, L, sd, x, r, **geo):
         kw = dict(dim_input=12, dim_output=4, num_layers=L, dim_hidden=96, dim_ffn=192, kernel_size=(5, 3), conv_groups=(8, 8),
                   norms=("LN", "LN", "GN", "LN", "LN", "LN"), dim_squeeze=8, num_freqs=F, num_heads=4, full_share=0)
+        kw.update(geo)
         res = {}
         for mode in ("fp64", "bf16"):
             net = SpatialNet(**kw).eval()
@@ -114,6 +115,24 @@ def bf16_reference_errors():
     c["seeds"] = {"init_params": 5, "x_r": 6}
     c["checksum"] = [float(flat.sum()), float(flat.abs().sum()), float(x.double().sum()), float(r.double().sum())]
     out["F129_T64_L8"] = c
+    # SpatialNet-large (configs/SpatialNet.yaml "for large" comments: 192 / 384 / squeeze 16, 12 layers) at the headline grid 129 x 251:
+    # what tests/test_large.py's bf16 bars for the large train step are set from (`bf16ref large` regenerates only this case)
+    if "large" in sys.argv[2:] or "all" in sys.argv[2:]:
+        geo = dict(dim_hidden=192, dim_ffn=384, dim_squeeze=16)
+        pl = oref.init_params(num_layers=12, num_freqs=129, seed=7, **geo)
+        g = torch.Generator().manual_seed(8)
+        xl = torch.randn(1, 129, 251, 12, generator=g)
+        rl = torch.randn(1, 129, 251, 4, generator=g)
+        cl = run(129, 251, 12, pl, xl, rl, **geo)
+        flat = torch.cat([v.double().reshape(-1) for v in pl.values()])
+        cl["seeds"] = {"init_params": 7, "x_r": 8}
+        cl["checksum"] = [float(flat.sum()), float(flat.abs().sum()), float(xl.double().sum()), float(rl.double().sum())]
+        out["large_F129_T251_L12"] = cl
+        print("large: y", cl["y"], "worst grads", sorted(cl["grads"].items(), key=lambda kv: -kv[1])[:6])
+    else:
+        prev = json.loads((HERE / "bf16_reference_errors.json").read_text())
+        if "large_F129_T251_L12" in prev:
+            out["large_F129_T251_L12"] = prev["large_F129_T251_L12"]
     (HERE / "bf16_reference_errors.json").write_text(json.dumps(out, indent=1))
     worst = sorted(c["grads"].items(), key=lambda kv: -kv[1])[:6]
     print("written: bf16_reference_errors.json; L8 case: y", c["y"], "worst grads", worst)
@@ -123,6 +142,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "bf16ref":
         assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
         return bf16_reference_errors()
+    if len(sys.argv) > 1 and sys.argv[1] == "online96":
+        assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
+        return online_native_width()
     if len(sys.argv) > 1 and sys.argv[1] == "large16k":
         assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
         return large_16k()
@@ -203,6 +225,37 @@ def online_models():
         for k, p in net.named_parameters():
             out[f"{name}/grad/{k}"] = p.grad.numpy()
     np.savez_compressed(HERE / "online_tiny.npz", **out)
+    online_native_width()
+
+
+def online_native_width():
+    """`python tests/golden/make_golden.py online96`: the reference's OnlineSpatialNet at the width the NATIVE streaming step serves (dim_hidden 96,
+    dim_ffn 192, 4 heads; 9 frequencies, 24 frames, 2 layers, batch 2), ret(2) and a banded mhsa whose window covers the sequence: input, state_dict
+    and the whole-utterance output — tests/test_online.py runs the HIP step chunk by chunk against THIS output (one hop from the reference)."""
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[m]
+    if str(REF) not in sys.path or sys.path[0] != str(REF):
+        sys.path.insert(0, str(REF))
+    from models.arch.OnlineSpatialNet import OnlineSpatialNet  # noqa: E402  (reference)
+    assert "/root/reference" in sys.modules["models.arch.OnlineSpatialNet"].__file__
+    sys.modules["models.arch.OnlineSpatialNet"].Mamba = type("Mamba", (), {})
+    torch.manual_seed(13)
+    out = {}
+    for name, kw in (("ret2", dict(attention="ret(2)", decay=[4, 5, 9, 10], rope=False)), ("mhsa31", dict(attention="mhsa(31)"))):
+        net = OnlineSpatialNet(dim_input=4, dim_output=4, num_layers=2, dim_squeeze=8, num_freqs=9, encoder_kernel_size=5, dim_hidden=96, dim_ffn=192,
+                               num_heads=4, dropout=(0, 0, 0), kernel_size=(5, 3), conv_groups=(8, 8), norms=["LN", "LN", "GN", "LN", "LN", "LN"],
+                               full_share=0, **kw).eval()
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+            x = torch.randn(2, 9, 24, 4)
+            y = net(x)
+        out[f"{name}/x"], out[f"{name}/y"] = x.numpy(), y.numpy()
+        for k, v in net.state_dict().items():
+            out[f"{name}/param/{k}"] = v.numpy().astype(np.float32)
+    np.savez_compressed(HERE / "online_w96.npz", **out)
+    print("written: online_w96.npz")
 
 
 def nb_models():

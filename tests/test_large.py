@@ -2,6 +2,7 @@
 the forward (inference) kernels against the fp64 oracle, block by block and as a whole network, both stream dtypes; plus the generalised
 T-ConvFFN tiling instantiated at the SMALL geometry against the same oracle (it is the same template).  Backward: the geometry-generic path
 (csrc/gbwd.hip) block by block against autograd of the oracle, and a train step of the whole network."""
+import numpy as np
 import pytest
 import torch
 
@@ -189,6 +190,46 @@ def test_large_network_train_step(backend, dtype):
         if err > (3 * tol if dtype == NBSS_F32 and ".fconv" in k else tol):
             bad[k] = err
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_large_train_step_at_the_headline_grid_vs_the_references_bf16(hip_lib):
+    """SpatialNet-large, 12 layers, ONE 4-s utterance at the real grid (129 x 251), bf16 stream: output and every parameter gradient against autograd of
+    the fp64 oracle (evaluated on the device in fp64 — on the host this case is five minutes), with bars set from what the REFERENCE's own bf16-mixed
+    computation loses on the same parameters and inputs (tests/golden/bf16_reference_errors.json, case large_F129_T251_L12, made by
+    tests/golden/make_golden.py bf16ref large): no tensor worse than 1.5 x the reference's own deviation (floor 5e-3)."""
+    import json
+    from pathlib import Path
+    from nbss_amd.engine import SpatialNetEngine
+    want = json.loads((Path(__file__).resolve().parent / "golden" / "bf16_reference_errors.json").read_text()).get("large_F129_T251_L12")
+    assert want is not None, "regenerate tests/golden/bf16_reference_errors.json with `python tests/golden/make_golden.py bf16ref large`"
+    dev = torch.device("cuda:0")
+    kw = dict(dim_hidden=192, dim_ffn=384, dim_squeeze=16)
+    F, T, L = 129, 251, 12
+    p = ref.init_params(num_layers=L, num_freqs=F, seed=want["seeds"]["init_params"], **kw)
+    g = torch.Generator().manual_seed(want["seeds"]["x_r"])
+    x = torch.randn(1, F, T, 12, generator=g)
+    r = torch.randn(1, F, T, 4, generator=g)
+    flat = torch.cat([v.double().reshape(-1) for v in p.values()])
+    got = [float(flat.sum()), float(flat.abs().sum()), float(x.double().sum()), float(r.double().sum())]
+    assert np.allclose(got, want["checksum"], rtol=1e-9), "the seeded parameters differ from the ones the reference errors were measured on"
+    eng = SpatialNetEngine(hip_lib, dev, dim_input=12, dim_output=4, num_freqs=F, num_layers=L, dtype=NBSS_BF16, **kw)
+    eng.load_params(p)
+    xs = x.to(torch.bfloat16).to(dev)
+    y = eng.forward(xs, train=True)
+    eng.grads.zero_()
+    eng.backward(xs, r.to(dev))
+    views = eng.param_views(eng.grads)
+    leaves = {}
+    p64 = {k: leaves.setdefault(id(v), v.double().to(dev).requires_grad_(True)) for k, v in p.items()}
+    wy = ref.spatialnet(xs.double(), p64, L)  # (the oracle sees the bf16-rounded input, as the stream does)
+    (wy * r.double().to(dev)).sum().backward()
+    ey = rel_l2(y, wy.detach())
+    errs = {k: rel_l2(views[k], v.grad) for k, v in p64.items() if k in want["grads"]}
+    worse = {k: (round(e, 4), round(want["grads"][k], 4)) for k, e in errs.items() if e > max(1.5 * want["grads"][k], 5e-3)}
+    print(f"large 129 x 251 x 12: y {ey:.3e} (reference bf16 {want['y']:.3e}); worst gradient {max(errs.values()):.3e} (reference {max(want['grads'].values()):.3e})")
+    assert ey <= max(1.5 * want["y"], 5e-3), (ey, want["y"])
+    assert not worse, worse
 
 
 @pytest.mark.gpu

@@ -63,6 +63,64 @@ def test_plateau_rule_matches_torch():
         assert abs(lr - opt.param_groups[0]["lr"]) < 1e-12, (m, lr, opt.param_groups[0]["lr"])
 
 
+def test_plateau_fuzz_and_state_round_trip_with_torch():
+    """random metric walks, every option (threshold_mode abs / rel, max mode, eps, cooldown, min_lr): the same learning rates as torch's
+    ReduceLROnPlateau; the state_dict loads INTO torch's scheduler (what a Lightning resume does) and torch's state loads into ours"""
+    import random
+    from SharedTrainer import _Plateau
+    rng = random.Random(0)
+    for trial in range(40):
+        kw = dict(mode=rng.choice(["min", "max"]), factor=rng.choice([0.1, 0.5, 0.9]), patience=rng.randint(0, 3), threshold=rng.choice([1e-4, 1e-2, 0.3]),
+                  threshold_mode=rng.choice(["rel", "abs"]), cooldown=rng.randint(0, 2), min_lr=rng.choice([0.0, 1e-9, 1e-3]), eps=rng.choice([1e-8, 1e-3]))
+        lr0 = rng.choice([1.0, 1e-3, 3e-8])
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=lr0)
+        ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, **kw)
+        mine, lr = _Plateau(**kw), lr0
+        metrics = [rng.choice([1.0, 2.0, 0.5, 1.001, 0.999]) * rng.random() for _ in range(30)]
+        for i, m in enumerate(metrics):
+            ref.step(m)
+            lr = mine.step(m, lr)
+            assert lr == opt.param_groups[0]["lr"], (trial, i, kw, lr, opt.param_groups[0]["lr"])
+            if i == 14:  # resume both ways mid-run
+                opt2 = torch.optim.SGD([p], lr=lr)
+                ref2 = torch.optim.lr_scheduler.ReduceLROnPlateau(opt2, **kw)
+                ref2.load_state_dict(mine.state_dict(lr))
+                mine2 = _Plateau(**kw)
+                mine2.load_state_dict(ref.state_dict())
+                assert (ref2.best, ref2.num_bad_epochs, ref2.cooldown_counter) == (ref.best, ref.num_bad_epochs, ref.cooldown_counter)
+                ref, opt, mine = ref2, opt2, mine2
+    with pytest.raises(NotImplementedError):
+        _Plateau(mode="min", monitor="x")
+
+
+def test_streamer_cache_follows_the_weights():
+    """forward_streaming caches its streamer (packed weight copies, a captured graph): an in-place weight update must rebuild it"""
+    from SharedTrainer import TrainModule
+    from models.arch.OnlineSpatialNet import OnlineSpatialNet
+    torch.manual_seed(0)
+    arch = OnlineSpatialNet(dim_input=4, dim_output=4, num_layers=1, dim_squeeze=8, num_freqs=9, encoder_kernel_size=5, dim_hidden=32, dim_ffn=64, num_heads=4,
+                            dropout=(0, 0, 0), kernel_size=(5, 3), conv_groups=(8, 8), norms=["LN", "LN", "GN", "LN", "LN", "LN"], full_share=0,
+                            attention="ret(2)", decay=[4, 5, 9, 10], rope=False).eval()
+    from models.io.norm import Norm
+    from models.io.stft import STFT
+    from models.io.loss import Loss
+    m = TrainModule(arch=arch, channels=[0, 1], ref_channel=0, stft=STFT(n_fft=16, n_hop=8), norm=Norm(mode="frequency", online=True),
+                    loss=Loss(loss_func="models.io.loss.neg_si_sdr", pit=True))
+    x = torch.randn(1, 2, 400)
+    y0, _ = m.forward_streaming(x, chunk=4, use_graph=False)
+    k0 = m._streamer_key
+    y1, _ = m.forward_streaming(x, chunk=4, use_graph=False)
+    assert m._streamer_key == k0 and torch.equal(y0, y1)  # unchanged weights: same streamer
+    with torch.no_grad():
+        for p in arch.parameters():
+            p.mul_(1.5)
+    y2, _ = m.forward_streaming(x, chunk=4, use_graph=False)
+    assert m._streamer_key != k0
+    want = m.forward(x)[0]
+    assert torch.allclose(y2, want, atol=1e-4, rtol=1e-3), float((y2 - want).abs().max())
+
+
 @pytest.mark.gpu
 def test_validate_test_predict_on_gpu(tmp_path):
     """the forward-only path behind the reference's validate / test / predict subcommands"""
