@@ -12,6 +12,14 @@ import torch.nn.functional as F
 from torch import Tensor
 
 
+class _GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm (same parameters / state_dict keys) through models.arch.base.norm.group_norm: exact gradients beyond 128 samples on the HIP device"""
+
+    def forward(self, input: Tensor) -> Tensor:
+        from models.arch.base.norm import group_norm
+        return group_norm(input, self.num_groups, self.weight, self.bias, self.eps)
+
+
 class Linear(nn.Linear):
     """nn.Linear with Xavier-uniform weights and a zero bias"""
 
@@ -98,7 +106,7 @@ class NBCBlock(nn.Module):
             if conv_mid_norm is not None:
                 if conv_mid_norm != "GN":
                     raise ValueError("unsupported mid norm " + str(conv_mid_norm))
-                mods.append(nn.GroupNorm(8, dim_ffn))
+                mods.append(_GroupNorm(8, dim_ffn))
             mods.append(nn.SiLU())
         self.conv = nn.Sequential(*mods)
 

@@ -7,7 +7,25 @@ and only serves stand-alone use of the class.  Only the types configs/SpatialNet
 "GN") are provided: the reference's other branches are broken upstream and no shipped
 config selects them.
 """
+import torch
 from torch import Tensor, nn
+
+
+def group_norm(input: Tensor, num_groups: int, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    """torch.nn.functional.group_norm, except on a HIP device with more than 128 samples, where torch 2.10+rocm7.0's native backward
+    returns wrong weight / bias gradients in every dtype (tests/diag/torch_group_norm_check.py: rel. error ~1 from 129 samples on, exact
+    up to 128) — every training batch of the narrow-band / online models is far beyond that (one sample per frequency or frame).
+    The written-out form below runs on plain elementwise / reduction kernels and is exact everywhere."""
+    if not (input.is_cuda and input.shape[0] > 128 and torch.is_grad_enabled()):
+        return nn.functional.group_norm(input, num_groups, weight, bias, eps)
+    N, C = input.shape[0], input.shape[1]
+    hg = input.reshape(N, num_groups, -1).float()
+    mean = hg.mean(-1, keepdim=True)
+    var = hg.var(-1, unbiased=False, keepdim=True)
+    xhat = ((hg - mean) * torch.rsqrt(var + eps)).reshape(input.shape)
+    shape = (1, C) + (1,) * (input.dim() - 2)
+    out = xhat * weight.float().reshape(shape) + bias.float().reshape(shape) if weight is not None else xhat
+    return out.to(input.dtype)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -30,7 +48,7 @@ class GroupNorm(nn.GroupNorm):
     def forward(self, input: Tensor) -> Tensor:
         if not self.seq_last:
             input = input.transpose(-1, 1)
-        o = super().forward(input)
+        o = group_norm(input, self.num_groups, self.weight, self.bias, self.eps)
         return o if self.seq_last else o.transpose(-1, 1)
 
 

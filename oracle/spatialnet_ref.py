@@ -80,6 +80,19 @@ def mhsa(x: Tensor, p: Dict[str, Tensor], pre: str, heads: int = 4, return_saved
     return x + y.reshape(B, F, T, H)
 
 
+def group_norm(h: Tensor, groups: int, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    """nn.GroupNorm on [N, C, T] written out (base/norm.py:55-57 -> torch.nn.GroupNorm: per sample and group, biased variance over (C/groups, T)).
+    Explicit on purpose: the tests also evaluate this oracle in fp64 on the HIP device, where torch 2.10+rocm7.0's native group_norm BACKWARD
+    returns wrong weight / bias gradients for more than 128 samples (found by tests/diag/large_tcf_block.py: the per-sample sums of the same
+    oracle add up to the HIP kernel's result, the batched call does not); on the CPU both forms agree to rounding."""
+    N, C, T = h.shape
+    hg = h.reshape(N, groups, (C // groups) * T)
+    mean = hg.mean(-1, keepdim=True)
+    var = hg.var(-1, unbiased=False, keepdim=True)
+    xhat = ((hg - mean) / torch.sqrt(var + eps)).reshape(N, C, T)
+    return xhat * weight[None, :, None] + bias[None, :, None]
+
+
 def tconvffn(x: Tensor, p: Dict[str, Tensor], pre: str, groups: int = 8) -> Tensor:
     """x + _tconvffn (SpatialNet.py:90,102-114,61-73): on [B*F,H,T]:
     LN(H) -> 1x1 H->FFN -> SiLU -> gconv(k=3) -> SiLU -> gconv -> GroupNorm(groups,FFN) -> SiLU -> gconv -> SiLU -> 1x1 FFN->H."""
@@ -90,7 +103,7 @@ def tconvffn(x: Tensor, p: Dict[str, Tensor], pre: str, groups: int = 8) -> Tens
     h = Fn.silu(Fn.conv1d(h, p[q + ".1.weight"], p[q + ".1.bias"]))
     h = Fn.silu(Fn.conv1d(h, p[q + ".3.weight"], p[q + ".3.bias"], padding="same", groups=groups))
     h = Fn.conv1d(h, p[q + ".5.weight"], p[q + ".5.bias"], padding="same", groups=groups)
-    h = Fn.silu(Fn.group_norm(h, groups, p[q + ".6.weight"], p[q + ".6.bias"], 1e-5))
+    h = Fn.silu(group_norm(h, groups, p[q + ".6.weight"], p[q + ".6.bias"], 1e-5))
     h = Fn.silu(Fn.conv1d(h, p[q + ".8.weight"], p[q + ".8.bias"], padding="same", groups=groups))
     h = Fn.conv1d(h, p[q + ".10.weight"], p[q + ".10.bias"])
     return x + h.transpose(1, 2).reshape(B, F, T, H)

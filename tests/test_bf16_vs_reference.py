@@ -4,8 +4,9 @@ tests/golden/bf16_reference_errors.json (tests/golden/make_golden.py bf16ref) ho
 SpatialNet under torch.autocast(bfloat16) — Lightning's bf16-mixed, the precision the headline metric is quoted at — against the same
 module in fp64.  The bf16 stream of this repo, on the same inputs and parameters, against the fp64 oracle, must be no worse than 1.5x
 that per tensor (with a small floor for tensors where both are at rounding level) and inside this repo's absolute bars.
-Stated bf16 tolerances: output <= 1.5e-2 rel-L2 (the reference's own: 6.1e-3 .. 8.5e-3); parameter gradients <= 0.12 absolute (the
-reference's own worst: 0.115), median <= 6e-2 (the reference's: 2.9e-2 at 2 layers, 5.7e-2 at 8)."""
+Stated bf16 tolerances: output <= 1.5e-2 rel-L2 (the reference's own: 6.1e-3 .. 8.5e-3); parameter gradients: every tensor <= 1.5 x the
+reference's own bf16 deviation on that tensor, the worst tensor and the median <= 1.1 x the reference's own worst (0.115) / median
+(2.9e-2 at 2 layers, 5.7e-2 at 8)."""
 import json
 import statistics
 from pathlib import Path
@@ -51,7 +52,10 @@ def _check(case, backend, p, x, r, F, L):
           f"{statistics.median(want['grads'].values()):.3e}), max {max(errs.values()):.3e} (reference {max(want['grads'].values()):.3e})")
     assert ey <= max(1.5 * want["y"], FLOOR) and ey <= 1.5e-2, (ey, want["y"])
     assert not worse, worse
-    assert max(errs.values()) <= 0.12 and statistics.median(errs.values()) <= max(6e-2 if len(errs) > 100 else 4e-2, 0.0)
+    # worst tensor / median pinned to the REFERENCE's own worst / median on this case (x 1.1: two bf16 computations of the same network differ by
+    # that much in their noisiest tensor), not to an absolute figure tuned to the current kernels
+    assert max(errs.values()) <= 1.1 * max(want["grads"].values()), (max(errs.values()), max(want["grads"].values()))
+    assert statistics.median(errs.values()) <= 1.1 * statistics.median(want["grads"].values())
 
 
 def test_bf16_stream_is_within_the_references_own_bf16_error_small(backend):

@@ -126,3 +126,27 @@ def test_reference_configs_build(cfg):
         with torch.no_grad():
             y, _ = m(torch.randn(1, 6, 2048))
         assert y.shape == (1, 2, 2048)
+
+
+@pytest.mark.gpu
+def test_group_norm_gradients_beyond_128_samples_on_the_device():
+    """torch 2.10+rocm7.0: torch.nn.functional.group_norm's backward returns wrong weight / bias gradients on the HIP device once the batch exceeds
+    128 samples (tests/diag/torch_group_norm_check.py) — models.arch.base.norm.group_norm, which every GroupNorm of the torch.nn archs here goes
+    through, must give the CPU result at the batch sizes training uses (one sample per (batch, frequency) sequence: 258 at batch 2)"""
+    from models.arch.base.norm import GroupNorm
+    torch.manual_seed(0)
+    for N in (64, 129, 1032):
+        h = torch.randn(N, 48, 16)
+        r = torch.randn_like(h)
+        grads = []
+        for dev in ("cpu", "cuda"):
+            gn = GroupNorm(seq_last=True, num_groups=8, num_channels=48)
+            with torch.no_grad():
+                gn.weight.copy_(torch.linspace(0.5, 1.5, 48))
+                gn.bias.copy_(torch.linspace(-0.2, 0.2, 48))
+            gn = gn.to(dev)
+            x = h.to(dev).requires_grad_(True)
+            (gn(x) * r.to(dev)).sum().backward()
+            grads.append([gn.weight.grad.cpu(), gn.bias.grad.cpu(), x.grad.cpu()])
+        for a, b in zip(*grads):
+            assert float((a - b).norm() / b.norm()) < 1e-5, N
