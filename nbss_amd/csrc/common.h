@@ -117,6 +117,24 @@ NBSS_DEV void wave_lds_sync() {
 #endif
 }
 
+// Asynchronous global -> LDS copy of 16 bytes per lane without a register stop (global_load_lds_dwordx4): lane l's piece lands at
+// `lds_wave_base + 16 l` (the destination is wave-uniform base + lane x 16, not a scatter; inactive lanes write nothing), `g` is per lane.
+// In flight like any global load (vmcnt): dma_wait_all() — then a barrier before other waves read the image.
+NBSS_DEV void dma16_to_lds(void* lds_wave_base, const void* g) {
+#ifdef NBSS_EMU
+    uint32_t* d = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_wave_base) + 16 * (threadIdx.x & 63));
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(g);
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+NBSS_DEV void dma_wait_all() {
+#ifndef NBSS_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); lgkmcnt / expcnt untouched
+#endif
+}
+
 NBSS_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 NBSS_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
 // same value, but known to the compiler as wave-uniform: index arithmetic derived from it stays in SGPRs

@@ -118,6 +118,32 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
 
     // ---- phase 1: stage x (raw) into LDS rows f+2, zero halo / tail rows -------------------
+#ifdef NBSS_FCONV_NO_DMA  // (A/B flavour)
+    constexpr bool DMA = false;
+#else
+    constexpr bool DMA = sizeof(T) == 2;
+#endif
+    if constexpr (DMA) {
+        // bf16 stream: the slab comes in as one burst of global -> LDS copies (16-byte pieces, no register stop; the copy loop below is a chain
+        // of load -> store round trips, seven per thread).  Piece q: row q / CPR (= f TT + tt), 16-byte column q % CPR (the last one is padding).
+        constexpr int CPR = HHP / 8, DPR = HH / 8;
+        const int wu = wave_id_u(), Q = F * TT * CPR, nw = nthr / 64;
+        for (int i = wu; i * 64 < Q; i += nw) {
+            const int q = i * 64 + lane, r = q / CPR, cc = q - r * CPR, f = r / TT, tt = r - f * TT;
+            if (q < Q && cc < DPR && t0 + tt < T_)
+                dma16_to_lds(reinterpret_cast<char*>(u + 2 * ROW) + (size_t)i * 1024, x + (((size_t)b * F + f) * T_ + t0 + tt) * HH + cc * 8);
+        }
+        for (int i = tid; i < (FP - F) * VPR; i += nthr) {  // halo rows (f = -2, -1) and the rows behind the last frequency
+            const int k = i / VPR, rr = k < 2 ? k : F + k, off = (i % VPR) * VN, tt = off / HH;
+            vec_zero(u + (size_t)rr * ROW + tt * HHP + (off - tt * HH));
+        }
+        if (t0 + TT > T_)  // a slab that ends the sequence: its missing frames are zero rows
+            for (int i = tid; i < F * VPR; i += nthr) {
+                const int f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
+                if (t0 + tt >= T_) vec_zero(u + (size_t)(f + 2) * ROW + tt * HHP + (off - tt * HH));
+            }
+        dma_wait_all();
+    } else {
     for (int i = tid; i < FP * VPR; i += nthr) {
         const int rr = i / VPR, off = (i % VPR) * VN, f = rr - 2, tt = off / HH;
         T* d = u + (size_t)rr * ROW + tt * HHP + (off - tt * HH);
@@ -125,6 +151,7 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
             vec_copy(d, x + (((size_t)b * F + f) * T_ + t0) * HH + off);
         else
             vec_zero(d);
+    }
     }
     lds_barrier();
     for (int base = 0; base < 2 * F * TT; base += nthr) {  // two adjacent lanes per (frequency, frame) row; whole waves take part
@@ -209,6 +236,34 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
     lds_barrier();
 
     // ---- phase 4: residual add + coalesced store -------------------------------------------------
+    if constexpr (DMA) {  // (VN == 8) the residual rows of up to eight iterations are requested together: one round trip per batch instead of one per row
+        constexpr int NB4 = 8;
+        for (int i0 = tid; i0 < F * VPR; i0 += NB4 * nthr) {
+            u32x4 xr4[NB4];
+#pragma unroll
+            for (int k = 0; k < NB4; ++k) {
+                const int i = i0 + k * nthr, ic = i < F * VPR ? i : F * VPR - 1, f = ic / VPR, off = (ic % VPR) * VN, tt = off / HH;
+                const int ttc = t0 + tt < T_ ? tt : 0;  // (clamped address: the value is not used)
+                xr4[k] = *reinterpret_cast<const u32x4*>(x + (((size_t)b * F + f) * T_ + t0 + ttc) * HH + (off - tt * HH));
+            }
+#pragma unroll
+            for (int k = 0; k < NB4; ++k) {
+                const int i = i0 + k * nthr;
+                if (i >= F * VPR) continue;
+                const int f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
+                if (t0 + tt >= T_) continue;
+                const size_t go = (((size_t)b * F + f) * T_ + t0) * HH + off;
+                float yv[8], o[8];
+                load8(u + (size_t)f * ROW + tt * HHP + (off - tt * HH), yv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[2 * j] = bf2f((bf16_t)(xr4[k][j] & 0xFFFF)) + yv[2 * j];
+                    o[2 * j + 1] = bf2f((bf16_t)(xr4[k][j] >> 16)) + yv[2 * j + 1];
+                }
+                store8(reinterpret_cast<bf16_t*>(y) + go, o);
+            }
+        }
+    } else
     for (int i = tid; i < F * VPR; i += nthr) {
         const int f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
         if (t0 + tt >= T_) continue;
@@ -274,6 +329,11 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     float* lnp = aff + 3 * FC_H;                 // [2H] gamma | beta
     PHASE_BEGIN(lnp + 2 * FC_H);
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+#ifdef NBSS_FCONV_NO_DMA  // (A/B flavour)
+    constexpr bool DMA = false;
+#else
+    constexpr bool DMA = sizeof(T) == 2;  // bf16 stream: the slab arrives through global -> LDS copies (phase 0)
+#endif
 
     Frag<T> af[FC_KS], at[FC_KS];
 #pragma unroll
@@ -284,10 +344,11 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     const bool gwave = NW == FC_G || w < FC_G;  // this wave owns a conv group in the group phases
     for (int i = tid; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
     for (int i = tid; i < 2 * FC_H; i += blockDim.x) lnp[i] = i < FC_H ? lnw[i] : lnb[i - FC_H];
-    for (int i = tid; i < 4 * ROW; i += blockDim.x) {  // halo rows (f = -2, -1, 16 mtf, 16 mtf + 1) of both images
-        const int hr = i / ROW, rr = hr < 2 ? hr : mtf * 16 + hr, off = i % ROW;
-        store1(u + (size_t)rr * ROW + off, 0.f);
-        store1(dvb + (size_t)rr * ROW + off, 0.f);
+    constexpr int VZ = VecOf<T>::N;  // elements per 16-byte store (ROW is a multiple of 8)
+    for (int i = tid; i < 4 * ROW / VZ; i += blockDim.x) {  // halo rows (f = -2, -1, 16 mtf, 16 mtf + 1) of both images
+        const int e = i * VZ, hr = e / ROW, rr = hr < 2 ? hr : mtf * 16 + hr, off = e % ROW;
+        vec_zero(u + (size_t)rr * ROW + off);
+        vec_zero(dvb + (size_t)rr * ROW + off);
     }
 
     // ---- phase 0 (rows): x, dy -> registers; LayerNorm -> u; dy -> dvb; row statistics out ----
@@ -347,16 +408,66 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
                 d[j] = frag_get(dq[ks], j);
             }
             store8(ur + c0, o);
-            store8(dr_ + c0, d);
+            if (!DMA) store8(dr_ + c0, d);
         }
     };
     Frag<T> xr[BK_KS], dr[BK_KS];
     float rmean = 0.f, rrstd = 0.f;
+    constexpr bool PF = false;
+    Frag<T> xr2[BK_KS], dr2[BK_KS];
+    if constexpr (DMA) {
+        // bf16 stream: the whole slab of x and dy comes in as ONE burst of global -> LDS copies (16-byte pieces, no register stop), raw x into the
+        // u image and dy into the dvb image — one memory round trip per workgroup instead of one per unit of a wave (a wave walks its two units
+        // serially and the images leave room for one workgroup per CU).  Piece q of an image: row q / 13 (= f TT + tt), 16-byte column q % 13
+        // (column 12 = the row padding, never written, never read).
+        const int wu = wave_id_u(), Q = F * TT * 13;
+        for (int i = wu; i * 64 < Q; i += NW) {
+            const int q = i * 64 + lane, r = q / 13, cc = q - r * 13, f = r / TT, tt = r - f * TT;
+            if (q < Q && cc < 12 && t0 + tt < T_) {
+                const size_t n = ((size_t)b * F + f) * T_ + t0 + tt;
+                dma16_to_lds(reinterpret_cast<char*>(u + 2 * ROW) + (size_t)i * 1024, x + n * FC_H + cc * 8);
+                dma16_to_lds(reinterpret_cast<char*>(dvb + 2 * ROW) + (size_t)i * 1024, dy + n * FC_H + cc * 8);
+            }
+        }
+        // rows the copies do not reach: the padding frequencies of the last tile, and the missing frame of a slab that ends the sequence
+        for (int i = tid; i < (mtf * 16 - F) * ROW / VZ; i += blockDim.x) {
+            vec_zero(u + (size_t)(F + 2) * ROW + i * VZ);
+            vec_zero(dvb + (size_t)(F + 2) * ROW + i * VZ);
+        }
+        if (t0 + TT > T_)
+            for (int i = tid; i < F * FC_LD / VZ; i += blockDim.x) {
+                const int f = i / (FC_LD / VZ), e = (i % (FC_LD / VZ)) * VZ;
+                for (int tt = T_ - t0; tt < TT; ++tt) {
+                    vec_zero(u + (size_t)(f + 2) * ROW + tt * FC_LD + e);
+                    vec_zero(dvb + (size_t)(f + 2) * ROW + tt * FC_LD + e);
+                }
+            }
+        dma_wait_all();
+        lds_barrier();  // images, lnp
+        auto row_load_lds = [&](int ti, Frag<T> (&xq)[BK_KS], Frag<T> (&dq)[BK_KS]) {
+            const int ft = ti / TT, tt = ti % TT, f = ft * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < BK_KS; ++ks) {
+                frag_load(xq[ks], u + (size_t)(f + 2) * ROW + tt * FC_LD + ks * 32 + 8 * g4);
+                frag_load(dq[ks], dvb + (size_t)(f + 2) * ROW + tt * FC_LD + ks * 32 + 8 * g4);
+            }
+        };
+        if (w < ntile) {
+            row_load_lds(w, xr, dr);
+            row_stats(xr, rmean, rrstd);
+            row_fwd(w, xr, dr, rmean, rrstd);
+        }
+        for (int ti = w + NW; ti < ntile; ti += NW) {
+            Frag<T> xq[BK_KS], dq[BK_KS];
+            float mean, rstd;
+            row_load_lds(ti, xq, dq);
+            row_stats(xq, mean, rstd);
+            row_fwd(ti, xq, dq, mean, rstd);
+        }
+    } else {
     if (w < ntile) row_load(w, xr, dr);
     // the wave's second unit is requested together with the first (bf16 stream: the row phases are bound by exposed HBM latency)
     // (measured: 6.69 -> 7.18 ms/step with the prefetch on — 168 VGPRs and twice the loads in flight ahead of the LN phase; kept off)
-    constexpr bool PF = false;
-    Frag<T> xr2[BK_KS], dr2[BK_KS];
     if (PF && w + NW < ntile) row_load(w + NW, xr2, dr2);
     lds_barrier();  // lnp
     if (w < ntile) {
@@ -374,6 +485,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
         row_load(ti, xq, dq);
         row_stats(xq, mean, rstd);
         row_fwd(ti, xq, dq, mean, rstd);
+    }
     }
     PHASE(0);
     lds_barrier();

@@ -145,7 +145,7 @@ def test_group_norm_gradients_beyond_128_samples_on_the_device():
                 gn.weight.copy_(torch.linspace(0.5, 1.5, 48))
                 gn.bias.copy_(torch.linspace(-0.2, 0.2, 48))
             gn = gn.to(dev)
-            x = h.to(dev).requires_grad_(True)
+            x = h.detach().clone().to(dev).requires_grad_(True)
             (gn(x) * r.to(dev)).sum().backward()
             grads.append([gn.weight.grad.cpu(), gn.bias.grad.cpu(), x.grad.cpu()])
         for a, b in zip(*grads):
