@@ -235,6 +235,27 @@ int nbss_nb_group_batch_norm(int dtype, int B, int F, int T, int C, const void* 
 /* softmax(q k^T / sqrt(dh)) v per (sequence, head): qkv [nseq][T][3H] (q | k | v; head h at columns h dh), o [nseq][T][H]; T <= 256, dh in {24, 48} */
 int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, void* o, void* stream);
 
+/* ---- the same building blocks for TRAINING (autograd of the reference's torch.nn NBC2: NBC2.py:152-238; sequenced by nbss_amd/nbc2.py) ---------------
+ * conv_t_train: conv_t without fused input / output activations, plus an optional second output y_silu = SiLU(y) (pre-activation and activation of a
+ *   feed-forward step in one pass).
+ * conv_t_bwd: gradients of y = conv_t(x): dx [nseq][T][ldx] = conv^T(dy) — multiplied by SiLU'(x_pre) when x_pre (the pre-activation x = SiLU(x_pre) was made
+ *   from, same layout as dx) is given — and dw [Cout][Cin / groups][taps] += dy^T x, dbias [Cout] += colsum(dy) (fp32, ACCUMULATED; either of dx / dw may be
+ *   NULL).  ws: nbss_nb_bwd_ws_bytes(Cout, Cin, groups, taps) bytes (the re-laid transposed weights + partial tiles of the weight gradient).
+ * layernorm_bwd: dx = dres + LayerNorm'(dy) with the forward's stats; dgamma / dbeta accumulated.
+ * group_batch_norm_bwd: gradient through y = act(GroupBatchNorm(x)) (statistics recomputed from x); dgamma / dbeta accumulated (NULL when not affine).
+ * attention_bwd: dqkv [nseq][T][3H] from qkv and d_o = gradient w.r.t. the attention output; ws: nbss_nb_attention_bwd_ws_bytes() bytes. */
+int64_t nbss_nb_bwd_ws_bytes(int Cout, int Cin, int groups, int taps);
+int nbss_nb_conv_t_train(int dtype, int64_t nseq, int T, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                         void* y_silu, const void* residual, void* ws, void* stream);
+int nbss_nb_conv_t_bwd(int dtype, int64_t nseq, int T, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const void* dy,
+                       const void* x_pre, void* dx, float* dw, float* dbias, void* ws, void* stream);
+int nbss_nb_layernorm_bwd(int dtype, int64_t rows, int C, const void* x, const float* stats, const float* gamma, const void* dy, const void* dres, void* dx,
+                          float* dgamma, float* dbeta, void* stream);
+int nbss_nb_group_batch_norm_bwd(int dtype, int B, int F, int T, int C, const void* x, const float* gamma, const float* beta, float eps, int act_out, const void* dy,
+                                 void* dx, float* dgamma, float* dbeta, void* stream);
+int64_t nbss_nb_attention_bwd_ws_bytes(int dtype, int64_t nseq, int T, int H, int heads);
+int nbss_nb_attention_bwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* d_o, void* dqkv, void* ws, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */

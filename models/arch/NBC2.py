@@ -13,6 +13,11 @@ from torch import Tensor
 from torch.nn import MultiheadAttention
 
 
+import weakref
+
+_NATIVE = weakref.WeakKeyDictionary()  # NBC2 module -> nbss_amd.nbc2.NativeNBC2 (or None)
+
+
 class LayerNorm(nn.LayerNorm):
     """LayerNorm over the feature axis of [B,T,H] (transpose=False) or [B,H,T] (transpose=True)"""
 
@@ -137,19 +142,31 @@ class NBC2(nn.Module):
         self.decoder = nn.Linear(dim_hidden, dim_output)
 
     def _native(self):
-        """the HIP forward (nbss_amd/nbc2.py) when this configuration is one its kernels are built for, else None"""
-        if not hasattr(self, "_native_fwd"):
-            from nbss_amd._lib import hip
-            from nbss_amd.nbc2 import NativeNBC2, supported
-            object.__setattr__(self, "_native_fwd", NativeNBC2(self, hip()) if supported(self) is None else None)
-        return self._native_fwd
+        """the HIP path (nbss_amd/nbc2.py) when this configuration is one its kernels are built for, else None.  The handle lives in a module-level
+        WeakKeyDictionary (a ctypes library handle as a module attribute would break deepcopy / pickle of the module); a library that cannot be
+        loaded means the torch.nn path, not an exception."""
+        if self not in _NATIVE:
+            runner = None
+            try:
+                from nbss_amd._lib import hip
+                from nbss_amd.nbc2 import NativeNBC2, supported
+                if supported(self) is None:
+                    runner = NativeNBC2(self, hip())
+            except Exception:  # (no library / no HIP runtime: torch.nn below)
+                runner = None
+            _NATIVE[self] = runner
+        return _NATIVE[self]
 
     def forward(self, x: Tensor) -> Tensor:
         B, F, T, _ = x.shape
-        # inference on a HIP device (validate / test / predict, torch.no_grad()): the native forward; training and CPU: the torch.nn modules below
-        if (x.is_cuda and not torch.is_grad_enabled() and T <= 256 and x.dtype in (torch.float32, torch.bfloat16) and self._native() is not None
-                and F == self.sa_layers[0].norm2.group_size):  # (groups of the GroupBatchNorm = the utterances)
-            return self._native().forward(x.contiguous())
+        # on a HIP device: the native forward (torch.no_grad(): validate / test / predict) or the native training path (autograd.Function whose backward
+        # runs the nbss_nb_*_bwd building blocks); CPU and configurations the kernels are not built for: the torch.nn modules below
+        if (x.is_cuda and T <= 256 and x.dtype in (torch.float32, torch.bfloat16) and F == self.sa_layers[0].norm2.group_size and self._native() is not None):
+            if not torch.is_grad_enabled():
+                return self._native().forward(x.contiguous())
+            from nbss_amd.nbc2 import _train_supported
+            if _train_supported(self) is None and not x.requires_grad:
+                return self._native().forward_train(x.contiguous())
         h = self.encoder(x.reshape(B * F, T, -1).transpose(1, 2)).transpose(1, 2)
         for block in self.sa_layers:
             h, _ = block(h)

@@ -47,6 +47,17 @@ int nb_conv_t_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int
 int nb_layernorm_impl(int dtype, long rows, int C, const void* x, const float* gamma, const float* beta, void* y, float* stats, hipStream_t st);
 int nb_gbn_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, void* y, hipStream_t st);
 int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st);
+size_t nb_bwd_ws_bytes_impl(int M, int K, int groups, int taps);
+int nb_conv_t_train_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                         void* y2, const void* residual, void* ws, hipStream_t st);
+int nb_conv_t_bwd_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const void* dy, const void* dact,
+                       void* dx, float* dw, float* dbias, void* ws, hipStream_t st);
+int nb_layernorm_bwd_impl(int dtype, long rows, int C, const void* x, const float* stats, const float* gamma, const void* du, const void* dres, void* dx, float* dgamma,
+                          float* dbeta, hipStream_t st);
+int nb_gbn_bwd_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, const void* dy, void* dx,
+                    float* dgamma, float* dbeta, hipStream_t st);
+size_t nb_attn_bwd_ws_bytes_impl(long N, int H, int heads, int dtype);
+int nb_attention_bwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* dO, void* dqkv, void* ws, hipStream_t st);
 
 #define CHECK_CFG(cfg)                         \
     if (!(cfg)) return NBSS_EINVAL;            \
@@ -497,6 +508,42 @@ int nbss_nb_group_batch_norm(int dtype, int B, int F, int T, int C, const void* 
 int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, void* o, void* stream) {
     if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !o) return NBSS_EINVAL;
     return nb_attention_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, o, (hipStream_t)stream);
+}
+
+int64_t nbss_nb_bwd_ws_bytes(int Cout, int Cin, int groups, int taps) {
+    if (Cout <= 0 || Cin <= 0 || groups <= 0 || taps <= 0 || Cout % groups || Cin % groups) return -1;
+    return (int64_t)nb_bwd_ws_bytes_impl(Cout, Cin, groups, taps);
+}
+int nbss_nb_conv_t_train(int dtype, int64_t nseq, int T, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                         void* y_silu, const void* residual, void* ws, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || taps <= 0 || !(taps & 1) || !x || !w || !y || !ws || x == y) return NBSS_EINVAL;
+    if (nseq * T >= ((int64_t)1 << 31)) return NBSS_EUNSUPPORTED;
+    return nb_conv_t_train_impl(dtype, (long)nseq, T, Cin, ldx, Cout, groups, taps, x, w, bias, y, y_silu, residual, ws, (hipStream_t)stream);
+}
+int nbss_nb_conv_t_bwd(int dtype, int64_t nseq, int T, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const void* dy,
+                       const void* x_pre, void* dx, float* dw, float* dbias, void* ws, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || T <= 0 || Cin <= 0 || Cout <= 0 || taps <= 0 || !(taps & 1) || !x || !w || !dy || !ws || (!dx && !dw) || dx == dy)
+        return NBSS_EINVAL;
+    if (nseq * T >= ((int64_t)1 << 31)) return NBSS_EUNSUPPORTED;
+    return nb_conv_t_bwd_impl(dtype, (long)nseq, T, Cin, ldx, Cout, groups, taps, x, w, dy, x_pre, dx, dw, dbias, ws, (hipStream_t)stream);
+}
+int nbss_nb_layernorm_bwd(int dtype, int64_t rows, int C, const void* x, const float* stats, const float* gamma, const void* dy, const void* dres, void* dx,
+                          float* dgamma, float* dbeta, void* stream) {
+    if (!nb_dtype_ok(dtype) || rows <= 0 || C <= 0 || !x || !stats || !gamma || !dy || !dres || !dx || !dgamma || !dbeta) return NBSS_EINVAL;
+    return nb_layernorm_bwd_impl(dtype, (long)rows, C, x, stats, gamma, dy, dres, dx, dgamma, dbeta, (hipStream_t)stream);
+}
+int nbss_nb_group_batch_norm_bwd(int dtype, int B, int F, int T, int C, const void* x, const float* gamma, const float* beta, float eps, int act_out, const void* dy,
+                                 void* dx, float* dgamma, float* dbeta, void* stream) {
+    if (!nb_dtype_ok(dtype) || B <= 0 || F <= 0 || T <= 0 || C <= 0 || !x || !dy || !dx || (!gamma) != (!beta) || (!dgamma) != (!dbeta) || (gamma && !dgamma)) return NBSS_EINVAL;
+    return nb_gbn_bwd_impl(dtype, B, F, T, C, x, gamma, beta, eps, act_out, dy, dx, dgamma, dbeta, (hipStream_t)stream);
+}
+int64_t nbss_nb_attention_bwd_ws_bytes(int dtype, int64_t nseq, int T, int H, int heads) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || T <= 0 || H <= 0 || heads <= 0) return -1;
+    return (int64_t)nb_attn_bwd_ws_bytes_impl((long)nseq * T, H, heads, dtype);
+}
+int nbss_nb_attention_bwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* d_o, void* dqkv, void* ws, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !d_o || !dqkv || !ws) return NBSS_EINVAL;
+    return nb_attention_bwd_impl(dtype, (long)nseq, T, H, heads, qkv, d_o, dqkv, ws, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

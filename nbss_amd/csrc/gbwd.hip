@@ -677,6 +677,77 @@ __global__ __launch_bounds__(GB_THREADS) void gb_gbn_kernel(const T* __restrict_
     }
 }
 
+// Backward of the GroupBatchNorm above (+ its optional SiLU): one workgroup per (b, t), statistics recomputed from x.
+//   a = xhat gamma + beta, y = act ? SiLU(a) : a;  d4 = dy (act ? SiLU'(a) : 1);  g = d4 gamma
+//   dx = rstd (g - mean(g) - xhat mean(g xhat))  over the F x C elements of the frame;  dgamma[c] += sum_f d4 xhat, dbeta[c] += sum_f d4
+// dy and dx may alias.  Per-channel sums: registers over the frequencies, one LDS atomic per thread, C global atomics per workgroup.
+template <class T>
+__global__ __launch_bounds__(GB_THREADS) void gb_gbn_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const T* dy, T* dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int F, int Tn, int C,
+                                                                float eps, int act) {
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [8]
+    float *cw = red + 8, *cb = cw + C;            // [C] each
+    const int b = blockIdx.x / Tn, t = blockIdx.x % Tn;
+    const size_t base = ((size_t)b * F * Tn + t) * C, fs = (size_t)Tn * C;
+    const int M = F * C;
+    for (int i = threadIdx.x; i < 2 * C; i += GB_THREADS) cw[i] = 0.f;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum64(v);
+        __syncthreads();
+        if (lane_id() == 0) red[wave_id()] = v;
+        __syncthreads();
+        float s = 0.f;
+        for (int i = 0; i < GB_THREADS / 64; ++i) s += red[i];
+        return s;
+    };
+    float s = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) s += load1(x + base + (size_t)(e / C) * fs + e % C);
+    const float mean = block_sum(s) / M;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const float d = load1(x + base + (size_t)(e / C) * fs + e % C) - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(q) / M + eps);
+    // thread = (frequency lane fl, channel c): C <= GB_THREADS is not required — channels are walked in rounds of GB_THREADS
+    float s1 = 0.f, s2 = 0.f;
+    for (int c0 = 0; c0 < C; c0 += GB_THREADS) {
+        const int c = c0 + threadIdx.x;
+        if (c < C) {
+            const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+            float dw = 0.f, dbv = 0.f;
+            for (int f = 0; f < F; ++f) {
+                const size_t o = base + (size_t)f * fs + c;
+                const float xh = (load1(x + o) - mean) * rstd;
+                const float d4 = load1(dy + o) * (act ? dsilu_f(xh * gm + bt) : 1.f);
+                dw += d4 * xh;
+                dbv += d4;
+                s1 += d4 * gm;
+                s2 += d4 * gm * xh;
+            }
+            cw[c] = dw;  // (one thread per channel in this round: plain stores)
+            cb[c] = dbv;
+        }
+    }
+    const float m1 = block_sum(s1) / M;
+    const float m2 = block_sum(s2) / M;
+    for (int e = threadIdx.x; e < M; e += GB_THREADS) {
+        const int c = e % C;
+        const size_t o = base + (size_t)(e / C) * fs + c;
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float xh = (load1(x + o) - mean) * rstd;
+        const float d4 = load1(dy + o) * (act ? dsilu_f(xh * gm + bt) : 1.f);
+        store1(dx + o, rstd * (d4 * gm - m1 - xh * m2));
+    }
+    __syncthreads();
+    if (dgamma)
+        for (int c = threadIdx.x; c < C; c += GB_THREADS) {
+            atomicAdd(dgamma + c, cw[c]);
+            atomicAdd(dbeta + c, cb[c]);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Attention backward for one (sequence, head), T <= 256, any head width DH % 8 == 0 (<= 64).  qkv [N][3H] (q | k | v, head h at columns h DH),
 // scores = q k^T / sqrt(DH), softmax over the keys, O = P V.
@@ -1405,5 +1476,118 @@ int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const 
     const int dh = H / heads;
     if (dh == 48) return dtype == NBSS_BF16 ? nb_attn_fwd<bf16_t, 48>(nseq, Tn, H, heads, qkv, o, st) : nb_attn_fwd<float, 48>(nseq, Tn, H, heads, qkv, o, st);
     if (dh == 24) return dtype == NBSS_BF16 ? nb_attn_fwd<bf16_t, 24>(nseq, Tn, H, heads, qkv, o, st) : nb_attn_fwd<float, 24>(nseq, Tn, H, heads, qkv, o, st);
+    return NBSS_EUNSUPPORTED;
+}
+
+// ---- training-mode building blocks (nbss_nb_*_train / _bwd: include/nbss_hip.h) ------------------------------------------------------------
+// ws layout of the backward calls: [re-laid weights: nb_ws_bytes_impl()] [WGPART_BYTES of weight-gradient partial tiles]
+size_t nb_bwd_ws_bytes_impl(int M, int K, int groups, int taps) {
+    const size_t a = nb_ws_bytes_impl(M, K, groups, taps), b = nb_ws_bytes_impl(K, M, groups, taps);
+    return (a > b ? a : b) + ws_align(WGPART_BYTES);
+}
+template <class T>
+static int nb_conv_t_train(long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y, void* y2,
+                           const void* residual, void* ws, hipStream_t st) {
+    if (groups <= 0 || Cin % groups || Cout % groups || (groups > 1 && ldx != Cin)) return NBSS_EINVAL;
+    const int Kv = Cin / groups, Kg = groups > 1 ? Kv : pad8(Kv), Mg = Cout / groups;
+    if (Kg % 8 || ldx < (groups > 1 ? Cin : Kg)) return NBSS_EUNSUPPORTED;
+    int e = gb_wprep<T>(w, ws, taps > 1 || groups > 1 ? WP_CONV_FWD : WP_LIN_FWD, groups, taps, Mg, Kv, pad16(Mg), pad32(Kg), st);
+    if (e) return e;
+    TapGemm p = gb_lin(x, ldx, ws, bias, y, Cout, nseq * Tn, Mg, Kg);
+    p.groups = groups; p.xgs = groups > 1 ? Kv : 0; p.ygs = groups > 1 ? Mg : 0; p.bgs = Mg;
+    p.taps = taps; p.center = taps / 2; p.shift = 1; p.pos_div = 1; p.pos_len = Tn;
+    p.R = residual; p.ldr = Cout;
+    p.Y2 = y2;
+    return gb_gemm<T>(p, st);
+}
+int nb_conv_t_train_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
+                         void* y2, const void* residual, void* ws, hipStream_t st) {
+    return dtype == NBSS_BF16 ? nb_conv_t_train<bf16_t>(nseq, Tn, Cin, ldx, Cout, groups, taps, x, w, bias, y, y2, residual, ws, st)
+                              : nb_conv_t_train<float>(nseq, Tn, Cin, ldx, Cout, groups, taps, x, w, bias, y, y2, residual, ws, st);
+}
+// data gradient (dx [N][Cin] = conv^T(dy), optionally times SiLU'(dact)) and weight / bias gradient (dw [Cout][Cin / groups][taps] += dy^T x) of
+// y = conv(x): x [N][ldx] is the tensor the forward call read (valid columns Cin), dy [N][Cout]
+template <class T>
+static int nb_conv_t_bwd(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const void* dy, const void* dact,
+                         void* dx, float* dw, float* dbias, void* ws, hipStream_t st) {
+    if (groups <= 0 || Cin % groups || Cout % groups || (groups > 1 && ldx != Cin)) return NBSS_EINVAL;
+    const long N = nseq * Tn;
+    const int Kv = Cin / groups, Mg = Cout / groups;
+    int e;
+    if (dx) {
+        // the transposed map: outputs = the forward's inputs (Cin, written ldx wide: padding columns get zero weight rows), K = Cout
+        if (Mg % 8 || (groups == 1 && ldx % 4)) return NBSS_EUNSUPPORTED;
+        const int Mo = groups > 1 ? Kv : ldx;  // rows of the re-laid weight per group: valid Kv, the rest zero
+        if ((e = gb_wprep<T>(w, ws, taps > 1 || groups > 1 ? WP_CONV_DGRAD : WP_LIN_DGRAD, groups, taps, Kv, Mg, pad16(Mo), pad32(Mg), st))) return e;
+        TapGemm p = gb_lin(dy, Cout, ws, nullptr, dx, ldx, N, Mo, Mg);
+        p.groups = groups; p.xgs = groups > 1 ? Mg : 0; p.ygs = groups > 1 ? Kv : 0; p.bgs = 0;
+        p.taps = taps; p.center = taps / 2; p.shift = 1; p.pos_div = 1; p.pos_len = Tn;
+        p.Dact = dact;
+        if ((e = gb_gemm<T>(p, st))) return e;
+    }
+    if (dw) {
+        if (Kv % 4 || Mg % 4) return NBSS_EUNSUPPORTED;
+        float* part = (float*)((char*)ws + nb_bwd_ws_bytes_impl(Cout, Cin, groups, taps) - ws_align(WGPART_BYTES));
+        const size_t esz = sizeof(T);
+        // dense problems in row slices that fit one workgroup of the transposing-read kernel (gb_wgrad_dense's rule); grouped convs as one problem
+        int mt = groups > 1 ? Cout / 16 + 1 : 112 / cdiv(Cin, 16);
+        if (groups == 1) {
+            if (mt > 12) mt = 12;
+            while (mt > 1 && cdiv(mt * 16, 64) + cdiv(Cin, 64) > 7) --mt;
+            if (mt < 1) mt = 1;
+        }
+        const int ms = groups > 1 ? Cout : mt * 16;
+        for (int m0 = 0; m0 < Cout; m0 += ms) {
+            const int mm = Cout - m0 < ms ? Cout - m0 : ms;
+            WgradArgs a;
+            a.part = part;
+            a.mvalid = 0; a.nvalid = 0;
+            a.Ntok = (int)N; a.F = (int)nseq; a.T = Tn; a.shift_stride = 1; a.shift_dim = 0;
+            a.groups = groups; a.taps = taps;
+            a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+            a.A = (const char*)dy + (size_t)m0 * esz; a.lda = Cout; a.MA = mm;
+            a.B = x; a.ldb = ldx; a.NB = Cin;
+            a.dW = dw + (size_t)m0 * Kv * taps; a.dbias = dbias ? dbias + m0 : nullptr;
+            if ((e = wgrad_launch(a, dtype, st))) return e;
+        }
+    }
+    return NBSS_OK;
+}
+int nb_conv_t_bwd_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const void* dy, const void* dact,
+                       void* dx, float* dw, float* dbias, void* ws, hipStream_t st) {
+    return dtype == NBSS_BF16 ? nb_conv_t_bwd<bf16_t>(dtype, nseq, Tn, Cin, ldx, Cout, groups, taps, x, w, dy, dact, dx, dw, dbias, ws, st)
+                              : nb_conv_t_bwd<float>(dtype, nseq, Tn, Cin, ldx, Cout, groups, taps, x, w, dy, dact, dx, dw, dbias, ws, st);
+}
+int nb_layernorm_bwd_impl(int dtype, long rows, int C, const void* x, const float* stats, const float* gamma, const void* du, const void* dres, void* dx, float* dgamma,
+                          float* dbeta, hipStream_t st) {
+    return dtype == NBSS_BF16 ? gb_ln_bwd<bf16_t>(du, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, st)
+                              : gb_ln_bwd<float>(du, x, stats, gamma, dres, dx, dgamma, dbeta, rows, C, st);
+}
+int nb_gbn_bwd_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, const void* dy, void* dx,
+                    float* dgamma, float* dbeta, hipStream_t st) {
+    const size_t lds = (8 + 2 * (size_t)C) * sizeof(float);
+    if (dtype == NBSS_BF16)
+        NBSS_LAUNCH((gb_gbn_bwd_kernel<bf16_t>), dim3(B * Tn), dim3(GB_THREADS), lds, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)dy, (bf16_t*)dx, dgamma, dbeta, F, Tn,
+                    C, eps, act);
+    else
+        NBSS_LAUNCH((gb_gbn_bwd_kernel<float>), dim3(B * Tn), dim3(GB_THREADS), lds, st, (const float*)x, gamma, beta, (const float*)dy, (float*)dx, dgamma, dbeta, F, Tn, C,
+                    eps, act);
+    return NBSS_CHECK_LAUNCH();
+}
+// attention backward from the packed projections: qkv [N][3H] (q | k | v), dO [N][H] -> dqkv [N][3H].  ws: O [N][H] (recomputed) | lse, D [N][heads] fp32
+size_t nb_attn_bwd_ws_bytes_impl(long N, int H, int heads, int dtype) {
+    return ws_align((size_t)N * H * (dtype == NBSS_BF16 ? 2 : 4)) + 2 * ws_align((size_t)N * heads * sizeof(float));
+}
+int nb_attention_bwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* dO, void* dqkv, void* ws, hipStream_t st) {
+    if (heads <= 0 || H % heads) return NBSS_EINVAL;
+    nbss_cfg c = {};
+    c.B = 1; c.F = (int)nseq; c.T = Tn; c.H = H; c.heads = heads; c.dtype = dtype;
+    const long N = nseq * Tn;
+    void* O = ws;
+    float* lse = (float*)((char*)ws + ws_align((size_t)N * H * (dtype == NBSS_BF16 ? 2 : 4)));
+    float* Dv = (float*)((char*)lse + ws_align((size_t)N * heads * sizeof(float)));
+    const int dh = H / heads;
+    if (dh == 48) return dtype == NBSS_BF16 ? gb_attn_launch<bf16_t, 48>(c, qkv, dO, O, dqkv, lse, Dv, st) : gb_attn_launch<float, 48>(c, qkv, dO, O, dqkv, lse, Dv, st);
+    if (dh == 24) return dtype == NBSS_BF16 ? gb_attn_launch<bf16_t, 24>(c, qkv, dO, O, dqkv, lse, Dv, st) : gb_attn_launch<float, 24>(c, qkv, dO, O, dqkv, lse, Dv, st);
     return NBSS_EUNSUPPORTED;
 }

@@ -97,6 +97,42 @@ def test_native_nbc2_forward_equals_the_module(backend, dtype):
     assert rel_l2(y, want) < (1e-4 if dtype == NBSS_F32 else 4e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_native_nbc2_training_gradients_equal_autograd(backend, dtype):
+    """NativeNBC2.forward_train (one autograd.Function; backward over the nbss_nb_*_bwd building blocks): output and EVERY parameter gradient against
+    torch.autograd through the torch.nn module in fp64 (the module is pinned to the reference's NBC2 by tests/test_nb_models.py) — 8 channels -> 3
+    speakers (BASELINE config 4's interface), per-frame GroupBatchNorm over the utterance's frequencies"""
+    from models.arch.NBC2 import NBC2
+    from nbss_amd.nbc2 import NativeNBC2
+    torch.manual_seed(5)
+    B, F, T, L = (2, 5, 21, 2) if backend.name == "emu" else (2, 129, 251, 4)
+    net = NBC2(dim_input=16, dim_output=6, n_layers=L, dim_hidden=96, dim_ffn=192, num_freqs=F)
+    with torch.no_grad():  # non-trivial norm affines / biases everywhere
+        for p in net.parameters():
+            if p.dim() <= 2 and p.shape[-1] in (1, 96, 192, 288, 6) and p.dim() == 1 or p.dim() == 2 and p.shape[-1] == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(B, F, T, 16)
+    r = torch.randn(B, F, T, 6)
+    ref = NBC2(dim_input=16, dim_output=6, n_layers=L, dim_hidden=96, dim_ffn=192, num_freqs=F).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    xs = x.to(_td(dtype))
+    (ref(xs.double()) * r.double()).sum().backward()  # (the reference sees the same rounded input as the stream)
+    want_y = ref(xs.double()).detach()
+    net = net.float().to(backend.device).train()
+    y = NativeNBC2(net, backend.lib).forward_train(xs.to(backend.device))
+    assert y.requires_grad and y.shape == (B, F, T, 6)
+    (y.float() * r.to(backend.device)).sum().backward()
+    assert rel_l2(y, want_y) < (1e-4 if dtype == NBSS_F32 else 4e-2)
+    tol = 2e-4 if dtype == NBSS_F32 else 6e-2
+    bad = {}
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n
+        e = rel_l2(p.grad, q.grad)
+        if e > tol:
+            bad[n] = e
+    assert not bad, bad
+
+
 def test_supported_names_the_reason():
     from models.arch.NBC2 import NBC2
     from nbss_amd.nbc2 import supported
