@@ -142,6 +142,9 @@ int nbss_spatialnet_bwd(const nbss_cfg* cfg, const float* params, float* grads, 
  * buckets): layers [layer_lo, layer_hi), plus the decoder when layer_hi == L (dout needed only then) and the
  * encoder when layer_lo == 0.  Calls must cover L..0 in descending, adjacent ranges; after a call the gradients of the layers
  * it covered are final, except the LinearGroup shared through full_share, which is final after layer 0. */
+/* Threading: the walks share ONE set of library-owned streams and events per process (csrc/capi.hip: SideState) — one walk at a time per
+ * process (the one-process-per-GPU model of this library); concurrent walks from several host threads or engines are not supported.  Under
+ * HIP-graph capture of `stream` the walks stay in order on it. */
 int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* grads, const void* packed, const void* xin, const void* acts,
                               const float* dout, void* ws, int layer_hi, int layer_lo, void* stream);
 

@@ -45,6 +45,7 @@ class SpatialNetEngine:
         self.version = 0  # bump whenever params change
         self._geom: Optional[Tuple[int, int, int]] = None
         self.acts = self.ws = None
+        self._slots: Dict[bool, Optional[tuple]] = {}  # train? -> (geometry key, workspace, saved activations)
 
     # ---- configuration / buffers -------------------------------------------------------------
     def cfg_for(self, B: int, T: int, dtype: Optional[int] = None) -> Cfg:
@@ -75,11 +76,18 @@ class SpatialNetEngine:
                             "sequence per workgroup in LDS — cut training segments to <= 256 frames (the reference trains on 4 s = 251)")
         key = (B, T, dtype, train)
         if self._geom != key:
-            # (inference: one workspace + the two ping-pong stream buffers behind it; training: the backward walk's per-sub-block copies)
-            esz = 2 if dtype == NBSS_BF16 else 4
-            infer = self.lib.nbss_workspace_bytes(C.byref(cfg)) + 2 * ((B * cfg.F * T * cfg.H * esz + 255) // 256 * 256)
-            self.ws = ops.scratch(self.lib.nbss_train_ws_bytes(C.byref(cfg)) if train else infer, self.device)
-            self.acts = ops.scratch(self.lib.nbss_acts_bytes(C.byref(cfg)), self.device) if train else None
+            # one buffer set per mode (training / inference), kept across switches: fit() alternates between a training epoch and a validation pass,
+            # and reallocating GBs of workspace at every switch was pure overhead (training: the backward walk's per-sub-block workspace copies +
+            # the saved activations; inference: one workspace + the two ping-pong stream buffers behind it)
+            slot = self._slots.get(train)
+            if slot is None or slot[0] != key:
+                esz = 2 if dtype == NBSS_BF16 else 4
+                infer = self.lib.nbss_workspace_bytes(C.byref(cfg)) + 2 * ((B * cfg.F * T * cfg.H * esz + 255) // 256 * 256)
+                self._slots[train] = None  # (release the old set of this mode before allocating the new one)
+                ws = ops.scratch(self.lib.nbss_train_ws_bytes(C.byref(cfg)) if train else infer, self.device)
+                acts = ops.scratch(self.lib.nbss_acts_bytes(C.byref(cfg)), self.device) if train else None
+                slot = self._slots[train] = (key, ws, acts)
+            _, self.ws, self.acts = slot
             self._geom = key
         return cfg
 
