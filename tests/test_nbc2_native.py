@@ -105,7 +105,7 @@ def test_native_nbc2_training_gradients_equal_autograd(backend, dtype):
     from models.arch.NBC2 import NBC2
     from nbss_amd.nbc2 import NativeNBC2
     torch.manual_seed(5)
-    B, F, T, L = (2, 5, 21, 2) if backend.name == "emu" else (2, 129, 251, 4)
+    B, F, T, L = (2, 5, 21, 2) if backend.name == "emu" else (1, 129, 251, 2)  # (the fp64 torch reference of the GPU case runs on the host: kept to ~20 s)
     net = NBC2(dim_input=16, dim_output=6, n_layers=L, dim_hidden=96, dim_ffn=192, num_freqs=F)
     with torch.no_grad():  # non-trivial norm affines / biases everywhere
         for p in net.parameters():
