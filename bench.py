@@ -19,6 +19,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -407,6 +408,21 @@ def main():
         base = None
         sweep = None
         large = None
+        if world == 1 and not args.no_cpu_baseline and roof is not None:
+            # the same kernels with the walks IN ORDER (NBSS_SIDE_STREAM=0 is read once per process: a short child run): the live figures above
+            # include whatever the gradient stream's launches cost the dominant kernel while they overlap it
+            try:
+                env = dict(os.environ, NBSS_SIDE_STREAM="0")
+                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "3", "--batch", str(B), "--no-cpu-baseline"], env=env,
+                                   capture_output=True, text=True, timeout=240)
+                child = json.loads(r.stdout.strip().splitlines()[-1])
+                io = child["roofline"]["all_kernels"][dominant]
+                roof["frac_in_order"] = io["frac"]
+                roof["avg_launch_us_in_order"] = io["avg_launch_us"]
+                roof["utt_per_s_in_order"] = round(child["value"], 1)
+            except Exception as e:  # reported, never fatal
+                roof["frac_in_order"] = None
+                roof["in_order_error"] = str(e)[:200]
         if world == 1 and not args.no_cpu_baseline:
             # utterances/s at the other per-GPU batches of SURVEY.md §8(d) (short runs: 1 warm-up + 3 timed steps each)
             sweep = {str(B): round(B * args.steps / dt, 1)}

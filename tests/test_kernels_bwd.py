@@ -122,6 +122,21 @@ def test_mhsa_bwd(backend, dtype):
         run_block_bwd(backend, dtype, B, F, T, lambda x, p: ref.mhsa(x, p, "layers.0"), bwd, MH_NAMES, seed=30)
 
 
+def test_mhsa_bwd_sequence_lengths(emu_lib):
+    """the single-sweep attention backward (bf16) across the sequence-length cases of its loops: one frame, partial / odd numbers of 16-frame strips,
+    odd numbers of query pairs and of 64-query dS chunks, the boundaries of the full-length specialisation (240 | 241) and its last frame counts"""
+    from conftest import Backend
+    be = Backend("emu", emu_lib, torch.device("cpu"))
+
+    def bwd(cs, G, x, dy, ws):
+        o = ops.mhsa_save(cs.lib, cs.cfg, x.device)
+        ops.mhsa_fwd(cs.lib, cs.cfg, cs.flat, cs.packed, 0, x, o_save=o)
+        return ops.mhsa_bwd(cs.lib, cs.cfg, cs.flat, G, cs.packed, 0, x, dy, o, ws)
+
+    for T in (1, 17, 33, 65, 129, 240, 241, 256):
+        run_block_bwd(be, NBSS_BF16, 1, 2 if T < 64 else 1, T, lambda x, p: ref.mhsa(x, p, "layers.0"), bwd, MH_NAMES, seed=30 + T)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("which", [0, 1])
 def test_fconv_bwd(backend, dtype, which):

@@ -225,3 +225,77 @@ def test_attention_layernorm_gbn_random_shapes(emu_lib):
     attn()
     ln()
     gbn()
+
+
+def test_training_blocks_random_shapes(emu_lib):
+    """the backward building blocks (nbss_nb_conv_t_bwd with and without the SiLU' factor, group_batch_norm_bwd, layernorm_bwd, attention_bwd) against torch
+    autograd on random shapes (emulator, fp32): group counts / widths, taps, padded dense inputs, partial tiles of the sequence axis"""
+    import ctypes as C
+    from hypothesis import given, settings, strategies as st
+    from models.arch.NBC2 import GroupBatchNorm
+    lib = emu_lib
+    P = lambda t: ops._ptr(lib, t)  # noqa: E731
+
+    @settings(max_examples=25, deadline=None)
+    @given(nseq=st.integers(1, 3), T=st.sampled_from([1, 2, 7, 16, 33]), groups=st.sampled_from([1, 1, 2, 4]), cgi=st.sampled_from([8, 16, 24]), cgo=st.sampled_from([8, 24, 40]),
+           taps=st.sampled_from([1, 3, 5]), pre=st.booleans(), pad=st.booleans(), seed=st.integers(0, 1000))
+    def conv(nseq, T, groups, cgi, cgo, taps, pre, pad, seed):
+        g = torch.Generator().manual_seed(seed)
+        cin, cout = groups * cgi, groups * cgo
+        valid = cin - 4 if (pad and groups == 1) else cin  # dense: the last stored columns may be padding (zero in x, no gradient wanted there)
+        a = torch.randn(nseq, T, cin, generator=g)           # pre-activation of the input
+        x = (Fn.silu(a) if pre else a.clone())
+        x[..., valid:] = 0
+        w = torch.randn(cout, valid // groups, taps, generator=g) * 0.3
+        dy = torch.randn(nseq, T, cout, generator=g)
+        dx = torch.full((nseq, T, cin), float("nan"))
+        dw, db = torch.zeros(w.numel()), torch.zeros(cout)
+        ws = torch.empty(lib._dll.nbss_nb_bwd_ws_bytes(cout, cin, groups, taps), dtype=torch.uint8)
+        wk = w.reshape(cout, -1).contiguous() if taps == 1 else w
+        lib.call("nbss_nb_conv_t_bwd", NBSS_F32, nseq, T, valid, cin, cout, groups, taps, P(x), P(wk), P(dy), P(a) if pre else None, P(dx), P(dw), P(db), P(ws), None)
+        a64 = a.double().requires_grad_(True)
+        w64 = w.double().requires_grad_(True)
+        xin = (Fn.silu(a64) if pre else a64)[..., :valid]
+        y = Fn.conv1d(xin.transpose(1, 2), w64, None, padding="same", groups=groups).transpose(1, 2)
+        (y * dy.double()).sum().backward()
+        assert rel_l2(dx[..., :valid], a64.grad[..., :valid]) < 2e-5, "dx"
+        assert rel_l2(dw.reshape(w.shape), w64.grad) < 2e-5, "dw"
+        assert rel_l2(db, dy.double().sum((0, 1))) < 2e-5, "db"
+
+    @settings(max_examples=15, deadline=None)
+    @given(B=st.integers(1, 2), F=st.integers(1, 5), T=st.integers(1, 9), Cc=st.sampled_from([8, 96, 192, 384]), act=st.integers(0, 1), seed=st.integers(0, 99))
+    def gbn(B, F, T, Cc, act, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B * F, T, Cc, generator=g) * 2 + 0.3
+        dy = torch.randn(B * F, T, Cc, generator=g)
+        m = GroupBatchNorm(Cc, F).double()
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(Cc, generator=g).double() + 0.5)
+            m.bias.copy_(torch.randn(Cc, generator=g).double())
+        gw, gb = m.weight.detach().float().contiguous(), m.bias.detach().float().contiguous()
+        dx, dg, dbt = torch.empty_like(x), torch.zeros(Cc), torch.zeros(Cc)
+        lib.call("nbss_nb_group_batch_norm_bwd", NBSS_F32, B, F, T, Cc, P(x), P(gw), P(gb), C.c_float(1e-5), act, P(dy), P(dx), P(dg), P(dbt), None)
+        x64 = x.double().requires_grad_(True)
+        y = m(x64)
+        ((Fn.silu(y) if act else y) * dy.double()).sum().backward()
+        assert rel_l2(dx, x64.grad) < 5e-5 and rel_l2(dg, m.weight.grad) < 5e-5 and rel_l2(dbt, m.bias.grad) < 5e-5, (B, F, T, Cc, act)
+
+    @settings(max_examples=12, deadline=None)
+    @given(nseq=st.integers(1, 2), T=st.sampled_from([1, 2, 15, 16, 17, 33, 100, 256]), dh=st.sampled_from([24, 48]), heads=st.integers(1, 2), seed=st.integers(0, 99))
+    def attn(nseq, T, dh, heads, seed):
+        g = torch.Generator().manual_seed(seed)
+        H = dh * heads
+        qkv = torch.randn(nseq, T, 3 * H, generator=g)
+        do = torch.randn(nseq, T, H, generator=g)
+        dqkv = torch.empty_like(qkv)
+        ws = torch.empty(lib._dll.nbss_nb_attention_bwd_ws_bytes(NBSS_F32, nseq, T, H, heads), dtype=torch.uint8)
+        lib.call("nbss_nb_attention_bwd", NBSS_F32, nseq, T, H, heads, P(qkv), P(do), P(dqkv), P(ws), None)
+        q64 = qkv.double().requires_grad_(True)
+        q, k, v = [t.reshape(nseq, T, heads, dh).transpose(1, 2) for t in q64.split(H, dim=-1)]
+        o = (torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, -1) @ v).transpose(1, 2).reshape(nseq, T, H)
+        (o * do.double()).sum().backward()
+        assert rel_l2(dqkv, q64.grad) < 5e-5, (nseq, T, dh, heads)
+
+    conv()
+    gbn()
+    attn()
