@@ -18,6 +18,7 @@
 #include "prof.h"
 #include "wgrad.h"
 #include "side.h"
+#include "tapgemm.h"
 
 #define GB_THREADS 256
 
@@ -53,23 +54,6 @@ __global__ void gb_wprep_kernel(WPrep p) {
     }
 }
 
-struct TapGemm {
-    const void* X;
-    const void* W;      // prepared weights
-    const float* bias;  // [groups][bgs] or null
-    const void* R;      // optional residual, rows of ldr elements, columns as Y
-    void* Y;
-    int rows;
-    int ldx, xcol, xgs;  // X row stride, first column, column stride between groups
-    int ldy, ycol, ygs;
-    int ldr;
-    int groups, Mg, Kg, Mp, Kp, bgs;
-    int taps, center, shift;  // tap reads row n + (tap - center) * shift ...
-    int pos_div, pos_len;     // ... valid while 0 <= (n / pos_div) % pos_len + tap - center < pos_len
-    int xact, yact;           // SiLU on the loaded X / on the result
-    void* Y2;                 // optional second output, layout of Y: SiLU(result) next to the pre-activation (a and h of a forward step in one pass)
-    const void* Dact;         // optional pre-activation tensor, layout of Y: the result is multiplied by SiLU'(Dact) (dh -> da of a backward step)
-};
 
 // epilogue of one row: 4 output tiles in C layout (lane: outputs 16 i + 4 g4 + r of its row)
 template <class T>
@@ -1034,6 +1018,7 @@ static int pad8(int v) { return (v + 7) & ~7; }
 template <class T>
 static int gb_gemm(const TapGemm& p, hipStream_t st) {
     if (p.Kg % 8 || p.ldx % 8 || p.xcol % 8 || p.xgs % 8 || p.ycol % 4 || p.ygs % 4 || p.ldy % 4) return NBSS_EUNSUPPORTED;
+    if (sizeof(T) == 2 && gl_gemm_takes(p)) return gl_gemm_bf16(p, st);
     const size_t lds = (size_t)p.taps * 64 * (p.Kp + 8) * sizeof(T);
     if (lds <= 150 * 1024) {
         int e = NBSS_SET_MAX_LDS((gb_tap_gemm_lds_kernel<T>), lds);

@@ -1,0 +1,167 @@
+// gemm_g.hip — dense per-token linear maps of the geometry-generic path (SpatialNet-large: in_proj 192 -> 576, out_proj, the two FFN maps
+// 192 <-> 384 and their data gradients; models/arch/SpatialNet.py:93-114 at the widths of configs/SpatialNet.yaml "for large").
+//
+//   Y[n][o] = epilogue(sum_i X[n][i] W[o][i])      bf16 stream, fp32 accumulation, weights = MFMA A operand, tokens = N dimension
+//
+// Workgroup = 4 waves on a 128-row x 192-output tile (wave: 64 rows x 96 outputs = 24 accumulator tiles), persistent over its share of
+// the tiles.  Both operands reach the LDS by DMA (global_load_lds_dwordx4, no register stop) in K-slabs of 32 through a 3-stage ring; a
+// DMA instruction writes one FRAGMENT BLOCK: the 16 rows x 32 k of one MFMA operand in reader-lane order (lane l's 16-byte piece at 16 l),
+// so the fragment read is one conflict-free ds_read_b128 at base + 16 lane and the global side fetches 64 contiguous bytes per row.
+// Two workgroups share a CU (60 KB of LDS each): one computes while the other waits for its slab or stores a tile.
+// gb_tap_gemm_lds_kernel (gbwd.hip) fed the MFMA from global memory one 16-row tile at a time: 102 TF/s over the large train step.
+#include "tapgemm.h"
+#include "layout.h"
+#include <cstdlib>
+
+#define GL_ROWS 128
+#define GL_OUTS 192
+#define GL_FB 1024                                 // bytes of a fragment block
+#define GL_AFB (GL_OUTS / 16)                      // 12 weight blocks ...
+#define GL_NFB (GL_AFB + GL_ROWS / 16)             // ... + 8 token blocks per stage
+#define GL_PER_WAVE (GL_NFB / 4)                   // DMA instructions per wave and stage
+#define GL_STAGE (GL_NFB * GL_FB)
+#define GL_NST 3
+
+// vmcnt(n): the wave's n most recent vector-memory operations may still be in flight
+template <int N>
+NBSS_DEV void dma_wait_but() {
+#ifndef NBSS_EMU
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+#endif
+}
+
+struct GlTile {
+    int rt, mc;
+};
+
+__global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int nmc) {
+    NBSS_LDS(smem);
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id_u();
+    const int wr = w & 1, wm = w >> 1;
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(p.X) + p.xcol;
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
+    const int nk = p.Kp / 32;
+    // tiles of this workgroup: XCD x = blockIdx % 8 owns the row tiles rt % 8 == x (every output chunk of a row tile goes through the same L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int nu = nmc * ((nrt - xcd + 7) / 8);  // tiles of this XCD
+    const int mine = nu > slot ? (nu - slot + slots - 1) / slots : 0;
+    auto tile_at = [&](int i) {
+        const int u = slot + i * slots;
+        GlTile t = {(u / nmc) * 8 + xcd, u % nmc};
+        return t;
+    };
+    auto issue = [&](int s) {  // stage s = (tile s / nk, K-slab s % nk) into ring slot s % 3
+        const GlTile t = tile_at(s / nk);
+        const int k0 = (s % nk) * 32 + 8 * g4;
+        char* sb = smem + (s % GL_NST) * GL_STAGE;
+#pragma unroll
+        for (int q = 0; q < GL_PER_WAVE; ++q) {
+            const int f = w * GL_PER_WAVE + q;  // wave-uniform
+            const bf16_t* src;
+            if (f < GL_AFB) {
+                int m = t.mc * GL_OUTS + f * 16 + l15;
+                m = m < p.Mp ? m : p.Mp - 1;
+                src = W + (size_t)m * p.Kp + k0;
+            } else {
+                long r = (long)t.rt * GL_ROWS + (f - GL_AFB) * 16 + l15;
+                r = r < p.rows ? r : p.rows - 1;
+                src = X + (size_t)r * p.ldx + k0;
+            }
+            dma16_to_lds(sb + f * GL_FB, src);
+        }
+    };
+    const int S = mine * nk;
+    if (S == 0) return;
+    issue(0);
+    if (S > 1) issue(1);
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = F32X4_ZERO;
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) dma_wait_but<GL_PER_WAVE>();
+        else dma_wait_all();
+        lds_barrier();
+        if (s + 2 < S) issue(s + 2);
+        const char* sb = smem + (s % GL_NST) * GL_STAGE + lane * 16;
+        Frag<bf16_t> a[6], b[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) frag_load(a[i], reinterpret_cast<const bf16_t*>(sb + (wm * 6 + i) * GL_FB));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) frag_load(b[t], reinterpret_cast<const bf16_t*>(sb + (GL_AFB + wr * 4 + t) * GL_FB));
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][t] = mma(a[i], b[t], acc[i][t]);
+        if (s % nk != nk - 1) continue;
+        // epilogue of the tile (C layout: lane = outputs 16 i + 4 g4 + r of its row)
+        const GlTile tl = tile_at(s / nk);
+        const int mbase = tl.mc * GL_OUTS + wm * 96 + 4 * g4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long row = (long)tl.rt * GL_ROWS + wr * 64 + t * 16 + l15;
+            const bool rv = row < p.rows;
+            const size_t ro = (size_t)row * p.ldy + p.ycol;
+            bf16_t* yr = reinterpret_cast<bf16_t*>(p.Y) + ro;
+            bf16_t* y2 = reinterpret_cast<bf16_t*>(p.Y2) + ro;
+            const bf16_t* da = reinterpret_cast<const bf16_t*>(p.Dact) + ro;
+            const bf16_t* rr = reinterpret_cast<const bf16_t*>(p.R) + (size_t)row * p.ldr + p.ycol;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int m0 = mbase + 16 * i;
+                if (rv && m0 < p.Mg) {  // (Mg % 4 == 0: a lane's four outputs are valid together)
+                    float o[4] = {acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]};
+                    if (p.bias) {
+                        float bv[4];
+                        load4(p.bias + m0, bv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += bv[r];
+                    }
+                    if (p.yact) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r]);
+                    }
+                    if (p.Dact) {
+                        float dv[4];
+                        load4(da + m0, dv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] *= dsilu_f(dv[r]);
+                    }
+                    if (p.R) {
+                        float rv4[4];
+                        load4(rr + m0, rv4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = rv4[r] + round_to(o[r], yr);
+                    }
+                    store4(yr + m0, o[0], o[1], o[2], o[3]);
+                    if (p.Y2) store4(y2 + m0, silu_f(round_to(o[0], yr)), silu_f(round_to(o[1], yr)), silu_f(round_to(o[2], yr)), silu_f(round_to(o[3], yr)));
+                }
+                acc[i][t] = F32X4_ZERO;
+            }
+        }
+    }
+}
+
+static bool gl_disabled() {
+    static const bool off = [] {
+        const char* e = getenv("NBSS_GEMM_V1");
+        return e && e[0] == '1';
+    }();
+    return off;
+}
+bool gl_gemm_takes(const TapGemm& p) {
+    return !gl_disabled() && p.taps == 1 && p.groups == 1 && !p.xact && p.Kg == p.Kp && p.Kg >= 64 && p.Mg >= 64 && p.Mg % 4 == 0 && p.ldx % 8 == 0 && p.xcol % 8 == 0 &&
+           p.ldy % 4 == 0 && p.ycol % 4 == 0 && (!p.R || p.ldr % 4 == 0);
+}
+int gl_gemm_bf16(const TapGemm& p, hipStream_t st) {
+    const int nrt = cdiv(p.rows, GL_ROWS), nmc = cdiv(p.Mg, GL_OUTS);
+    const size_t lds = (size_t)GL_NST * GL_STAGE;
+    int e = NBSS_SET_MAX_LDS(gl_gemm_kernel, lds);
+    if (e) return e;
+    const long ntiles = (long)nrt * nmc;
+    int grid = 512;  // two workgroups on each of the 256 CUs; a multiple of 8 (the XCD mapping above)
+    if (ntiles < grid) grid = (int)((ntiles + 7) / 8 * 8);
+    NBSS_LAUNCH(gl_gemm_kernel, dim3(grid), dim3(256), lds, st, p, nrt, nmc);
+    return NBSS_CHECK_LAUNCH();
+}
