@@ -15,6 +15,7 @@ int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int lay
 int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* osave,
                   void* dx, void* ws, hipStream_t st, const Side* sd);
 int tconvffn_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int layer, const void* x, void* y, void* tsave, hipStream_t st, const SeqTail* tl);
+int gb_tconvffn_fwd(const nbss_cfg& c, const float* P, int layer, const void* x, void* y, void* ws, hipStream_t st);
 size_t tconvffn_save_bytes(const nbss_cfg& c);
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,
@@ -330,7 +331,10 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
 #endif
         if ((e = mhsa_fwd_impl(c, params, packed, l, buf(k + 3), buf(k + 4), osave, st, tlp))) return e;
         void* tsave = acts && tcf_save_bytes(c) ? (void*)((char*)acts + acts_tcf_offset(c) + (size_t)l * tcf_save_bytes(c)) : nullptr;
-        if ((e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), tsave, st, tlp))) return e;
+        // SpatialNet-large, bf16, T <= 256: the idle workspace carries the block's intermediates (gbwd.hip: gb_tconvffn_fwd)
+        e = c.H != 96 && ws ? gb_tconvffn_fwd(c, params, l, buf(k + 4), buf(k + 5), ws, st) : NBSS_EUNSUPPORTED;
+        if (e == NBSS_EUNSUPPORTED) e = tconvffn_fwd_impl(c, params, packed, l, buf(k + 4), buf(k + 5), tsave, st, tlp);
+        if (e) return e;
 #ifndef NBSS_EMU
         if (tlp && (hipEventRecord(ss->join, tl.ts) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess)) return NBSS_ELAUNCH;
 #endif

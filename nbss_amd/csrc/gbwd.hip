@@ -19,6 +19,7 @@
 #include "wgrad.h"
 #include "side.h"
 #include "tapgemm.h"
+#include "tchain.h"
 
 #define GB_THREADS 256
 
@@ -1318,34 +1319,61 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
     if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
     if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1T, WP_LIN_DGRAD, 1, 1, H, FFN, pad16(H), pad32(FFN), st))) return e;
     if ((e = gb_wprep<T>(lp.p[P_TF_W2], w2T, WP_LIN_DGRAD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
-    for (int k = 0; k < 3; ++k) {
-        if ((e = gb_wprep<T>(lp.p[convW[k]], cw[k], WP_CONV_FWD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
-        if ((e = gb_wprep<T>(lp.p[convW[k]], cwT[k], WP_CONV_DGRAD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
-    }
-    auto tconv = [&](const void* X, const void* Wp, const float* bias, void* Y) {  // along T: rows 1 apart, position t = n % T
-        return gb_conv(X, Wp, bias, Y, N, FFN, c.t_groups, c.t_ks, 1, 1, c.T);
-    };
-    // forward chain, every pre-activation and activation kept
-    if ((e = gb_ln_fwd<T>(x, lp.p[P_TF_LN_W], lp.p[P_TF_LN_B], u, stats, N, H, st))) return e;
     auto with = [](TapGemm p, void* y2, const void* dact) {  // second output SiLU(Y) / result times SiLU'(dact): the activation passes ride along
         p.Y2 = y2;
         p.Dact = dact;
         return p;
     };
-    if ((e = gb_gemm<T>(with(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), h1, nullptr), st))) return e;
-    if ((e = gb_gemm<T>(with(tconv(h1, cw[0], lp.p[convB[0]], a2), h2, nullptr), st))) return e;
-    if ((e = gb_gemm<T>(tconv(h2, cw[1], lp.p[convB[1]], a3), st))) return e;
-    NBSS_LAUNCH((gb_gn_fwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), 8 * sizeof(float), st, (const T*)a3, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)h4, gstats, c.T, FFN, CG);
-    if ((e = NBSS_CHECK_LAUNCH())) return e;
-    if ((e = gb_gemm<T>(with(tconv(h4, cw[2], lp.p[convB[2]], a5), h5, nullptr), st))) return e;
-    // backward chain: g5 = da5, g3 = da3 (through the GroupNorm), g2 = da2, g1 = da1
-    if ((e = gb_gemm<T>(with(gb_lin(dy, H, w2T, nullptr, g5, FFN, N, FFN, H), nullptr, a5), st))) return e;
-    if ((e = gb_gemm<T>(tconv(g5, cwT[2], nullptr, g3), st))) return e;
-    NBSS_LAUNCH((gb_gn_bwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), (8 + 128) * sizeof(float), st, (const T*)a3, (const float*)gstats, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)g3,
-                G + param_off(c, layer, P_TF_GN_W), G + param_off(c, layer, P_TF_GN_B), c.T, FFN, CG);
-    if ((e = NBSS_CHECK_LAUNCH())) return e;
-    if ((e = gb_gemm<T>(with(tconv(g3, cwT[1], nullptr, g2), nullptr, a2), st))) return e;
-    if ((e = gb_gemm<T>(with(tconv(g2, cwT[0], nullptr, g1), nullptr, a1), st))) return e;
+    if ((e = gb_ln_fwd<T>(x, lp.p[P_TF_LN_W], lp.p[P_TF_LN_B], u, stats, N, H, st))) return e;
+    if (tc_chain_takes(c.dtype, CG, c.t_ks, c.T)) {
+        // the conv chain between the two dense maps in ONE kernel per layer (tchain.hip): a1 and dh5 in, every operand of the weight gradients out
+        void* dh5 = a2;  // (the buffers of the pre-activations the chain keeps in registers)
+        TChain tc;
+        const float* wsrc[3];
+        for (int k = 0; k < 3; ++k) {
+            wsrc[k] = lp.p[convW[k]];
+            tc.wf[k] = cw[k];
+            tc.wd[k] = cwT[k];
+            tc.cb[k] = lp.p[convB[k]];
+        }
+        if (tc_wfrag_elems(c.t_groups, CG, c.t_ks) > (size_t)c.t_groups * c.t_ks * Mp * Kp) return NBSS_EUNSUPPORTED;
+        {
+            void* wfv[3] = {cw[0], cw[1], cw[2]};
+            void* wdv[3] = {cwT[0], cwT[1], cwT[2]};
+            if ((e = tc_wprep(wsrc, wfv, wdv, c.t_groups, CG, c.t_ks, st))) return e;
+        }
+        if ((e = gb_gemm<T>(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), st))) return e;
+        if ((e = gb_gemm<T>(gb_lin(dy, H, w2T, nullptr, dh5, FFN, N, FFN, H), st))) return e;
+        tc.a1 = a1; tc.dh5 = dh5;
+        tc.gn_w = lp.p[P_TF_GN_W]; tc.gn_b = lp.p[P_TF_GN_B];
+        tc.h1 = h1; tc.h2 = h2; tc.h4 = h4; tc.h5 = h5; tc.g5 = g5; tc.g3 = g3; tc.g2 = g2; tc.g1 = g1;
+        tc.dgn_w = G + param_off(c, layer, P_TF_GN_W); tc.dgn_b = G + param_off(c, layer, P_TF_GN_B);
+        tc.nseq = nseq; tc.T = c.T; tc.FFN = FFN; tc.groups = c.t_groups;
+        if ((e = tc_chain_launch(tc, CG, c.t_ks, true, st))) return e;
+    } else {
+        for (int k = 0; k < 3; ++k) {
+            if ((e = gb_wprep<T>(lp.p[convW[k]], cw[k], WP_CONV_FWD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
+            if ((e = gb_wprep<T>(lp.p[convW[k]], cwT[k], WP_CONV_DGRAD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
+        }
+        auto tconv = [&](const void* X, const void* Wp, const float* bias, void* Y) {  // along T: rows 1 apart, position t = n % T
+            return gb_conv(X, Wp, bias, Y, N, FFN, c.t_groups, c.t_ks, 1, 1, c.T);
+        };
+        // forward chain, every pre-activation and activation kept
+        if ((e = gb_gemm<T>(with(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), h1, nullptr), st))) return e;
+        if ((e = gb_gemm<T>(with(tconv(h1, cw[0], lp.p[convB[0]], a2), h2, nullptr), st))) return e;
+        if ((e = gb_gemm<T>(tconv(h2, cw[1], lp.p[convB[1]], a3), st))) return e;
+        NBSS_LAUNCH((gb_gn_fwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), 8 * sizeof(float), st, (const T*)a3, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)h4, gstats, c.T, FFN, CG);
+        if ((e = NBSS_CHECK_LAUNCH())) return e;
+        if ((e = gb_gemm<T>(with(tconv(h4, cw[2], lp.p[convB[2]], a5), h5, nullptr), st))) return e;
+        // backward chain: g5 = da5, g3 = da3 (through the GroupNorm), g2 = da2, g1 = da1
+        if ((e = gb_gemm<T>(with(gb_lin(dy, H, w2T, nullptr, g5, FFN, N, FFN, H), nullptr, a5), st))) return e;
+        if ((e = gb_gemm<T>(tconv(g5, cwT[2], nullptr, g3), st))) return e;
+        NBSS_LAUNCH((gb_gn_bwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), (8 + 128) * sizeof(float), st, (const T*)a3, (const float*)gstats, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)g3,
+                    G + param_off(c, layer, P_TF_GN_W), G + param_off(c, layer, P_TF_GN_B), c.T, FFN, CG);
+        if ((e = NBSS_CHECK_LAUNCH())) return e;
+        if ((e = gb_gemm<T>(with(tconv(g3, cwT[1], nullptr, g2), nullptr, a2), st))) return e;
+        if ((e = gb_gemm<T>(with(tconv(g2, cwT[0], nullptr, g1), nullptr, a1), st))) return e;
+    }
     if ((e = gb_gemm<T>(gb_lin(g1, FFN, w1T, nullptr, du, H, N, H, FFN), st))) return e;
     if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_TF_LN_W], dy, dx, G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), N, H, st))) return e;
     // weight gradients (every operand above is still in place: nothing was overwritten)
@@ -1362,6 +1390,46 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
         if ((e = wgrad_launch(wa, c.dtype, gs))) return e;
     }
     return gb_wgrad_dense(c, ws, g1, FFN, FFN, u, H, H, G + param_off(c, layer, P_TF_W1), G + param_off(c, layer, P_TF_B1), N, gs);
+}
+
+// ---- T-ConvFFN forward on the same pieces (bf16 stream): LN -> dense map -> conv chain -> dense map + residual.  tconvffn_g.hip's one-kernel
+// forward walks a sequence's 8 groups serially with every weight fragment from L2 (1.1 ms per layer at batch 4); these four launches take a third.
+int gb_tconvffn_fwd(const nbss_cfg& c, const float* P, int layer, const void* x, void* y, void* ws, hipStream_t st) {
+    typedef bf16_t T;
+    const LayerPtrs lp = layer_ptrs(c, P, layer);
+    const long N = (long)c.B * c.F * c.T;
+    const int H = c.H, FFN = c.FFN, CG = FFN / c.t_groups;
+    if (!ws || !tc_chain_takes(c.dtype, CG, c.t_ks, c.T)) return NBSS_EUNSUPPORTED;
+    ProfScope ps(PK_TCF_F, st);
+    float* stats = (float*)ws;
+    GbArena ar = gb_arena(c, ws);
+    void* u = ar.take(N * H * sizeof(T));
+    void* a1 = ar.take(N * FFN * sizeof(T));
+    void* h5 = ar.take(N * FFN * sizeof(T));
+    void* w1 = ar.take((size_t)pad16(FFN) * pad32(H) * sizeof(T));
+    void* w2 = ar.take((size_t)pad16(H) * pad32(FFN) * sizeof(T));
+    void* cw[3];
+    for (int k = 0; k < 3; ++k) cw[k] = ar.take(tc_wfrag_elems(c.t_groups, CG, c.t_ks) * sizeof(T));
+    if (!cw[2]) return NBSS_EUNSUPPORTED;
+    int e;
+    if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
+    if ((e = gb_wprep<T>(lp.p[P_TF_W2], w2, WP_LIN_FWD, 1, 1, H, FFN, pad16(H), pad32(FFN), st))) return e;
+    const float* wsrc[3] = {lp.p[P_TF_C1W], lp.p[P_TF_C2W], lp.p[P_TF_C3W]};
+    void* none[3] = {nullptr, nullptr, nullptr};
+    if ((e = tc_wprep(wsrc, cw, none, c.t_groups, CG, c.t_ks, st))) return e;
+    if ((e = gb_ln_fwd<T>(x, lp.p[P_TF_LN_W], lp.p[P_TF_LN_B], u, stats, N, H, st))) return e;
+    if ((e = gb_gemm<T>(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), st))) return e;
+    TChain tc = {};
+    tc.a1 = a1;
+    for (int k = 0; k < 3; ++k) tc.wf[k] = cw[k];
+    tc.cb[0] = lp.p[P_TF_C1B]; tc.cb[1] = lp.p[P_TF_C2B]; tc.cb[2] = lp.p[P_TF_C3B];
+    tc.gn_w = lp.p[P_TF_GN_W]; tc.gn_b = lp.p[P_TF_GN_B];
+    tc.h5 = h5;
+    tc.nseq = c.B * c.F; tc.T = c.T; tc.FFN = FFN; tc.groups = c.t_groups;
+    if ((e = tc_chain_launch(tc, CG, c.t_ks, false, st))) return e;
+    TapGemm p2 = gb_lin(h5, FFN, w2, lp.p[P_TF_B2], y, H, N, H, FFN);
+    p2.R = x; p2.ldr = H;
+    return gb_gemm<T>(p2, st);
 }
 
 // ---- decoder (SpatialNet.py:200,216): out = Wd x + bd; dx = Wd^T dout ---------------------------------------------------------------------
