@@ -85,6 +85,28 @@ NBSS_DEV float dsilu_f(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
+// SiLU and its derivative through ONE v_exp_f32 + ONE v_rcp_f32 (1 ulp) instead of __expf + an IEEE division (~10 more full-rate instructions
+// per element): for kernels whose time is these element passes (tchain.hip: 8 of them per token and channel, VALU-bound on the division)
+// and whose results are rounded to bf16 anyway.  silu_pair() shares the sigmoid between value and derivative.
+NBSS_DEV float fast_rcp(float x) {
+#ifdef NBSS_EMU
+    return 1.0f / x;
+#else
+    return __builtin_amdgcn_rcpf(x);
+#endif
+}
+NBSS_DEV float sigmoid_fast(float x) { return fast_rcp(1.0f + fast_exp2(-1.44269504f * x)); }
+NBSS_DEV float silu_fast(float x) { return x * sigmoid_fast(x); }
+NBSS_DEV float dsilu_fast(float x) {
+    const float s = sigmoid_fast(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+NBSS_DEV void silu_pair(float x, float& y, float& dy) {
+    const float s = sigmoid_fast(x);
+    y = x * s;
+    dy = s * (1.0f + x * (1.0f - s));
+}
+
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) but NOT for its global loads /
 // stores (vmcnt) — __syncthreads() drains both, which exposed the full global-store latency at each of the ~80 barriers
 // of the narrow-band backward kernels.  Use __syncthreads() wherever global memory written by another wave is read.

@@ -1122,6 +1122,23 @@ static int gb_fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer
               pA = which ? P_FC2_PRELU : P_FC1_PRELU;
     float* stats = (float*)ws;
     GbArena ar = gb_arena(c, ws);
+    if (sizeof(T) == 2 && fconv_g_takes(c)) {  // the whole block in one kernel per (b, t) slab (fconv_g.hip)
+        void* dv = ar.take(N * H * sizeof(T));
+        void* wfr = ar.take(fconv_g_wfrag_elems() * sizeof(T));
+        void* wdr = ar.take(fconv_g_wfrag_elems() * sizeof(T));
+        if (!wdr) return NBSS_EUNSUPPORTED;
+        int e = fconv_g_bwd(c, P, G, layer, which, x, dy, dx, dv, stats, wfr, wdr, st);
+        if (e) return e;
+        // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap - 2) T][i] (LayerNorm applied on the fly from the statistics), bias = colsum(dv)
+        const hipStream_t gs = side_fork(sd, st);
+        WgradArgs wa;
+        gb_wgrad_base(wa, c, ws, N);
+        wa.shift_stride = c.T; wa.shift_dim = 1; wa.groups = c.f_groups; wa.taps = c.f_ks;
+        wa.A = dv; wa.lda = H; wa.MA = H; wa.B = x; wa.ldb = H; wa.NB = H;
+        wa.stats = stats; wa.gamma = lp.p[pLW]; wa.beta = lp.p[pLB];
+        wa.dW = G + param_off(c, layer, pW); wa.dbias = G + param_off(c, layer, pB);
+        return wgrad_launch(wa, c.dtype, gs);
+    }
     void* u = ar.take(N * H * sizeof(T));
     void* a = ar.take(N * H * sizeof(T));
     void* da = ar.take(N * H * sizeof(T));

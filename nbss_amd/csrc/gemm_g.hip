@@ -7,7 +7,7 @@
 // the tiles.  Both operands reach the LDS by DMA (global_load_lds_dwordx4, no register stop) in K-slabs of 32 through a 3-stage ring; a
 // DMA instruction writes one FRAGMENT BLOCK: the 16 rows x 32 k of one MFMA operand in reader-lane order (lane l's 16-byte piece at 16 l),
 // so the fragment read is one conflict-free ds_read_b128 at base + 16 lane and the global side fetches 64 contiguous bytes per row.
-// Two workgroups share a CU (60 KB of LDS each): one computes while the other waits for its slab or stores a tile.
+// Two workgroups share a CU (62 KB of LDS each): one computes while the other waits for its slab or stores a tile.
 // gb_tap_gemm_lds_kernel (gbwd.hip) fed the MFMA from global memory one 16-row tile at a time: 102 TF/s over the large train step.
 #include "tapgemm.h"
 #include "layout.h"
@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
     };
     const int S = mine * nk;
     if (S == 0) return;
+    // bias of every output in LDS: a global load in the tile epilogue would wait (vmcnt is one in-order counter) for the stores of the previous row
+    // tile ahead of it — 24 serialised store round trips per tile, 16 us per tile against 1 us of MFMA work in the first version
+    float* bl = reinterpret_cast<float*>(smem + GL_NST * GL_STAGE);
+    for (int i = threadIdx.x; i < p.Mp; i += 256) bl[i] = p.bias && i < p.Mg ? p.bias[i] : 0.f;
     issue(0);
     if (S > 1) issue(1);
     f32x4 acc[6][4];
@@ -79,10 +83,30 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[i][t] = F32X4_ZERO;
+    const bf16_t* ext = reinterpret_cast<const bf16_t*>(p.Dact ? p.Dact : p.R);  // per-element operand of the epilogue (at most one of the two)
+    const int lde = p.Dact ? p.ldy : p.ldr;
     for (int s = 0; s < S; ++s) {
         if (s + 1 < S) dma_wait_but<GL_PER_WAVE>();
         else dma_wait_all();
         lds_barrier();
+        const bool last = s % nk == nk - 1;
+        const GlTile tl = tile_at(s / nk);
+        const int mbase = tl.mc * GL_OUTS + wm * 96 + 4 * g4;
+        // the tile's per-element operand is requested BEFORE the next slab's copies (in-order counter: its wait then leaves the copies in flight)
+        u32x2 ex[4][6];
+        if (last && ext) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                long row = (long)tl.rt * GL_ROWS + wr * 64 + t * 16 + l15;
+                row = row < p.rows ? row : p.rows - 1;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    int m0 = mbase + 16 * i;
+                    m0 = m0 < p.Mg ? m0 : 0;
+                    ex[t][i] = *reinterpret_cast<const u32x2*>(ext + (size_t)row * lde + p.ycol + m0);
+                }
+            }
+        }
         if (s + 2 < S) issue(s + 2);
         const char* sb = smem + (s % GL_NST) * GL_STAGE + lane * 16;
         Frag<bf16_t> a[6], b[4];
@@ -94,50 +118,66 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[i][t] = mma(a[i], b[t], acc[i][t]);
-        if (s % nk != nk - 1) continue;
-        // epilogue of the tile (C layout: lane = outputs 16 i + 4 g4 + r of its row)
-        const GlTile tl = tile_at(s / nk);
-        const int mbase = tl.mc * GL_OUTS + wm * 96 + 4 * g4;
+        if (!last) continue;
+        // epilogue of the tile (C layout: lane = outputs 16 i + 4 g4 + r of its row): every value first, then the stores back to back — a load or a
+        // conditional block between two stores makes the compiler wait for the earlier store (vmcnt(0) per block)
+        u32x2 outp[4][6];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16_t* yr = reinterpret_cast<const bf16_t*>(p.Y);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int m0 = mbase + 16 * i;
+                m0 = m0 < p.Mg ? m0 : 0;
+                float o[4] = {acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]};
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bl + m0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += bv[r];
+                if (p.yact) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r]);
+                }
+                if (ext) {
+                    const float ev[4] = {bf2f((bf16_t)(ex[t][i][0] & 0xFFFF)), bf2f((bf16_t)(ex[t][i][0] >> 16)), bf2f((bf16_t)(ex[t][i][1] & 0xFFFF)),
+                                         bf2f((bf16_t)(ex[t][i][1] >> 16))};
+                    if (p.Dact) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] *= dsilu_f(ev[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = ev[r] + round_to(o[r], yr);
+                    }
+                }
+                outp[t][i] = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                acc[i][t] = F32X4_ZERO;
+            }
+        }
+        sched_fence();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const long row = (long)tl.rt * GL_ROWS + wr * 64 + t * 16 + l15;
             const bool rv = row < p.rows;
             const size_t ro = (size_t)row * p.ldy + p.ycol;
             bf16_t* yr = reinterpret_cast<bf16_t*>(p.Y) + ro;
-            bf16_t* y2 = reinterpret_cast<bf16_t*>(p.Y2) + ro;
-            const bf16_t* da = reinterpret_cast<const bf16_t*>(p.Dact) + ro;
-            const bf16_t* rr = reinterpret_cast<const bf16_t*>(p.R) + (size_t)row * p.ldr + p.ycol;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int m0 = mbase + 16 * i;
-                if (rv && m0 < p.Mg) {  // (Mg % 4 == 0: a lane's four outputs are valid together)
-                    float o[4] = {acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]};
-                    if (p.bias) {
-                        float bv[4];
-                        load4(p.bias + m0, bv);
+                if (rv && m0 < p.Mg) *reinterpret_cast<u32x2*>(yr + m0) = outp[t][i];
+            }
+        }
+        if (p.Y2) {  // SiLU of the STORED value next to it (a and h of a forward step in one pass)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] += bv[r];
-                    }
-                    if (p.yact) {
+            for (int t = 0; t < 4; ++t) {
+                const long row = (long)tl.rt * GL_ROWS + wr * 64 + t * 16 + l15;
+                const bool rv = row < p.rows;
+                bf16_t* y2 = reinterpret_cast<bf16_t*>(p.Y2) + (size_t)row * p.ldy + p.ycol;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = silu_f(o[r]);
-                    }
-                    if (p.Dact) {
-                        float dv[4];
-                        load4(da + m0, dv);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] *= dsilu_f(dv[r]);
-                    }
-                    if (p.R) {
-                        float rv4[4];
-                        load4(rr + m0, rv4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = rv4[r] + round_to(o[r], yr);
-                    }
-                    store4(yr + m0, o[0], o[1], o[2], o[3]);
-                    if (p.Y2) store4(y2 + m0, silu_f(round_to(o[0], yr)), silu_f(round_to(o[1], yr)), silu_f(round_to(o[2], yr)), silu_f(round_to(o[3], yr)));
+                for (int i = 0; i < 6; ++i) {
+                    const int m0 = mbase + 16 * i;
+                    const uint32_t v0 = outp[t][i][0], v1 = outp[t][i][1];
+                    if (rv && m0 < p.Mg)
+                        store4(y2 + m0, silu_f(bf2f((bf16_t)(v0 & 0xFFFF))), silu_f(bf2f((bf16_t)(v0 >> 16))), silu_f(bf2f((bf16_t)(v1 & 0xFFFF))), silu_f(bf2f((bf16_t)(v1 >> 16))));
                 }
-                acc[i][t] = F32X4_ZERO;
             }
         }
     }
@@ -152,11 +192,11 @@ static bool gl_disabled() {
 }
 bool gl_gemm_takes(const TapGemm& p) {
     return !gl_disabled() && p.taps == 1 && p.groups == 1 && !p.xact && p.Kg == p.Kp && p.Kg >= 64 && p.Mg >= 64 && p.Mg % 4 == 0 && p.ldx % 8 == 0 && p.xcol % 8 == 0 &&
-           p.ldy % 4 == 0 && p.ycol % 4 == 0 && (!p.R || p.ldr % 4 == 0);
+           p.ldy % 4 == 0 && p.ycol % 4 == 0 && (!p.R || p.ldr % 4 == 0) && !(p.R && p.Dact) && p.Mp <= 1024;
 }
 int gl_gemm_bf16(const TapGemm& p, hipStream_t st) {
     const int nrt = cdiv(p.rows, GL_ROWS), nmc = cdiv(p.Mg, GL_OUTS);
-    const size_t lds = (size_t)GL_NST * GL_STAGE;
+    const size_t lds = (size_t)GL_NST * GL_STAGE + (size_t)p.Mp * sizeof(float);
     int e = NBSS_SET_MAX_LDS(gl_gemm_kernel, lds);
     if (e) return e;
     const long ntiles = (long)nrt * nmc;

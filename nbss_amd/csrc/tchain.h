@@ -27,4 +27,13 @@ bool tc_chain_takes(int dtype, int CG, int KS, int T);
 size_t tc_wfrag_elems(int groups, int CG, int KS);  // elements of ONE of the six fragment-ordered weight sets
 // re-lay the three conv weights [FFN][CG][KS] (fp32) into wf[0..2] / wd[0..2] (one launch)
 int tc_wprep(const float* const w[3], void* const wf[3], void* const wd[3], int groups, int CG, int KS, hipStream_t st);
+// ... and one conv weight [groups CG][CG][KS] alone (fconv_g.hip)
+int tc_wprep_one(const float* w, void* wf, void* wd, int groups, int CG, int KS, hipStream_t st);
 int tc_chain_launch(const TChain& p, int CG, int KS, bool bwd, hipStream_t st);
+
+// fconv_g.hip: the F-conv block's backward of the geometry-generic path in one kernel (bf16, 192 channels)
+struct nbss_cfg;
+bool fconv_g_takes(const nbss_cfg& c);
+size_t fconv_g_wfrag_elems();
+int fconv_g_bwd(const nbss_cfg& c, const float* P, float* G, int layer, int which, const void* x, const void* dy, void* dx, void* dv, float* stats, void* wf,
+                void* wd, hipStream_t st);

@@ -7,8 +7,8 @@
 // Everything between the two dense maps of the block is local to one (sequence, conv group): the convolutions are grouped, GroupNorm's groups
 // ARE the conv groups, its statistics run over the sequence.  One workgroup (4 waves) = one (sequence, group): the [T + halo][48] row image
 // of the current conv input lives in LDS (overwritten in place by the next one between two barriers), a wave owns 64 frames x 48 channels
-// (12 accumulator tiles; weights = MFMA A operand, fragment-ordered, double-buffered in LDS; tokens = N), the pre-activations the backward
-// needs again stay in registers as packed bf16.  59 KB of LDS: two workgroups per CU.
+// (12 accumulator tiles; weights = MFMA A operand, fragment-ordered in LDS; tokens = N), the pre-activations the backward
+// needs again stay in registers (a3) or in LDS (a2) as packed bf16.  69 KB of LDS: two workgroups per CU.
 // A tap is a row offset into the image: (tap, channel) is ONE contraction axis of 3 x 48 = 144 (4.5 k-steps instead of 3 x 2).
 // The unfused path (gbwd.hip) ran six tap-GEMM launches + GroupNorm forward / backward per layer through ~40 [N][FFN] tensor passes.
 #include "tchain.h"
@@ -32,11 +32,12 @@ struct TcGeo {
 //   data gradient:  W[g CG + i][m][KS - 1 - tap]   (the transposed, tap-flipped kernel: the same conv form with zero padding)
 struct TcWPrep {
     const float* src[3];
-    bf16_t* dst[6];
+    bf16_t* dst[6];  // [direction][conv]
     int groups, CG, KS, NKS, OT;
+    int nconv;  // 3 (the T-conv chain) or 1
 };
 __global__ void tc_wprep_kernel(TcWPrep p) {
-    const int which = blockIdx.y, conv = which % 3, dgrad = which / 3;
+    const int conv = blockIdx.y % p.nconv, dgrad = blockIdx.y / p.nconv, which = 3 * dgrad + conv;
     const long per_g = (long)p.NKS * p.OT * 512, total = per_g * p.groups;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int j = (int)(e & 7), l = (int)((e >> 3) & 63);
@@ -62,9 +63,11 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     constexpr int WPC = G::WSET / 8, NW = (WPC + TC_THREADS - 1) / TC_THREADS;  // 16-byte pieces of a weight set, per thread
     NBSS_LDS(smem);
     bf16_t* img = reinterpret_cast<bf16_t*>(smem);           // [T + 2 halo][RS]: the current conv's input, overwritten in place by its successor's
-    bf16_t* wl = img + G::IMG;                               // [2][WSET] weights of the current / next conv in fragment order
-    float* red = reinterpret_cast<float*>(wl + 2 * G::WSET);  // [4 reductions][8]
+    bf16_t* wl = img + G::IMG;                               // [WSET] weights of the current conv in fragment order
+    float* red = reinterpret_cast<float*>(wl + G::WSET);     // [4 reductions][8]
     float* cgs = red + 32;                                   // [2][CG] per-channel GroupNorm affine sums
+    uint32_t* park = reinterpret_cast<uint32_t*>(cgs + 2 * CG);  // [8 OT][256 threads] a2 between its forward and its backward use (the compiler spilled it
+                                                             // to scratch, whose reloads then waited — one in-order vmcnt — for the stores around them)
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id_u();
     // the groups of a sequence run on one XCD (they read neighbouring 96-byte slices of the same rows)
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     const size_t base = (size_t)seq * T * FFN + (size_t)g * CG;  // element (t = 0, channel 0 of the group)
     const float invM = 1.f / (float)(T * CG);
 
-    // weights: requested from L2 into registers before a conv starts, stashed into the other LDS buffer after it (one copy per workgroup,
-    // latency under the conv's MFMAs; as per-wave register fragments for the whole conv the kernel spilled 77 registers)
+    // weights: requested from L2 into registers before a conv starts, stashed into the LDS buffer after it — behind the barrier that ends the
+    // conv's reads — (one copy per workgroup, latency under the conv's MFMAs; as per-wave register fragments for the whole conv: 77 spills)
     u32x4 wq[NW];
     auto w_fetch = [&](const void* wbase) {
         const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(wbase) + (size_t)g * G::WSET);
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
             wq[k] = src[e < WPC ? e : WPC - 1];
         }
     };
-    auto w_stash = [&](int buf) {
-        u32x4* dst = reinterpret_cast<u32x4*>(wl + buf * G::WSET);
+    auto w_stash = [&]() {
+        u32x4* dst = reinterpret_cast<u32x4*>(wl);
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             const int e = tid + k * TC_THREADS;
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
         boff[ks] = ((pk / PPR) + TC_HALO - KS / 2) * RS + (pk % PPR) * 8;
     }
     f32x4 acc[4][OT];
-    auto conv = [&](int buf) {
+    auto conv = [&]() {
         const bf16_t* rowp = img + (size_t)(64 * w + l15) * RS;
-        const bf16_t* wp = wl + buf * G::WSET + lane * 8;
+        const bf16_t* wp = wl + lane * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -133,7 +136,19 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     auto put_glb = [&](void* dst, int j, int i, const float (&v)[4]) {
         if (dst && frame(j) < T) store4(reinterpret_cast<bf16_t*>(dst) + base + goff(j, i), v[0], v[1], v[2], v[3]);
     };
-    auto chan4 = [&](const float* prm, int i, float (&o)[4]) { load4(prm + (size_t)g * CG + 16 * i + 4 * g4, o); };
+    // the lane's 4 OT channels of a per-channel parameter, requested BEFORE the phase's stores (a load between two stores waits for the first)
+    auto chan = [&](const float* prm, float (&o)[OT][4]) {
+#pragma unroll
+        for (int i = 0; i < OT; ++i) load4(prm + (size_t)g * CG + 16 * i + 4 * g4, o[i]);
+    };
+    auto tile_in = [&](const void* src, u32x2 (&o)[4][OT]) {  // a [N][FFN] tensor's values of the lane's 12 tiles (clamped rows)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int fr = frame(j) < T ? frame(j) : T - 1;
+#pragma unroll
+            for (int i = 0; i < OT; ++i) o[j][i] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(src) + base + (unsigned)(fr * FFN + 16 * i + 4 * g4));
+        }
+    };
     int nred = 0;
     auto wg_sum2 = [&](float& a, float& b) {  // sums over the workgroup; every reduction has its own slots (no second barrier)
         a = wave_sum64(a);
@@ -165,65 +180,69 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = tid + q * TC_THREADS, t = e / PPR, pc = e % PPR;
-            if (t < T) load8(a1 + (unsigned)(t * FFN + pc * 8), v[q]);
-            else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[q][k] = 0.f;
-            }
+            load8(a1 + (unsigned)((t < T ? t : T - 1) * FFN + pc * 8), v[q]);  // (clamped, not branched: six requests in flight, not six round trips)
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = tid + q * TC_THREADS, t = e / PPR, pc = e % PPR;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[q][k] = t < T ? silu_f(v[q][k]) : 0.f;
+            for (int k = 0; k < 8; ++k) v[q][k] = t < T ? silu_fast(v[q][k]) : 0.f;
             store8(img + (size_t)(t + TC_HALO) * RS + pc * 8, v[q]);
             if (p.h1 && t < T) store8(reinterpret_cast<bf16_t*>(p.h1) + base + (unsigned)(t * FFN + pc * 8), v[q]);
         }
     }
-    w_stash(0);
+    w_stash();
     lds_barrier();
 
     // ---- forward ----
-    uint32_t A2[4][OT][2], A3[4][OT][2];  // pre-activations as stored by the unfused path (bf16), packed
+    uint32_t A2[4][OT][2], A3[4][OT][2];  // pre-activations as stored by the unfused path (bf16), packed (a2 only until it is parked)
+    float cbv[OT][4];
     w_fetch(p.wf[1]);
-    conv(0);
+    chan(p.cb[0], cbv);
+    conv();
     lds_barrier();
-    w_stash(1);
+    w_stash();
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
-        float bs[4];
-        chan4(p.cb[0], i, bs);
+        const float (&bs)[4] = cbv[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = frame(j) < T;
             float h[4];
             A2[j][i][0] = pack2bf(acc[j][i][0] + bs[0], acc[j][i][1] + bs[1]);
             A2[j][i][1] = pack2bf(acc[j][i][2] + bs[2], acc[j][i][3] + bs[3]);
-            h[0] = keep_if(ok, silu_f(bf_lo(A2[j][i][0])));
-            h[1] = keep_if(ok, silu_f(bf_hi(A2[j][i][0])));
-            h[2] = keep_if(ok, silu_f(bf_lo(A2[j][i][1])));
-            h[3] = keep_if(ok, silu_f(bf_hi(A2[j][i][1])));
+            park[(2 * (j * OT + i)) * TC_THREADS + tid] = A2[j][i][0];
+            park[(2 * (j * OT + i) + 1) * TC_THREADS + tid] = A2[j][i][1];
+            h[0] = keep_if(ok, silu_fast(bf_lo(A2[j][i][0])));
+            h[1] = keep_if(ok, silu_fast(bf_hi(A2[j][i][0])));
+            h[2] = keep_if(ok, silu_fast(bf_lo(A2[j][i][1])));
+            h[3] = keep_if(ok, silu_fast(bf_hi(A2[j][i][1])));
             put_img(j, i, h);
             put_glb(p.h2, j, i, h);
+            sched_fence();
         }
     }
     lds_barrier();
+    float gmv[OT][4], btv[OT][4];
     w_fetch(p.wf[2]);
-    conv(1);
+    chan(p.cb[1], cbv);
+    chan(p.gn_w, gmv);
+    chan(p.gn_b, btv);
+    conv();
     lds_barrier();
-    w_stash(0);
+    w_stash();
     float mean, rstd;
     {
         float s = 0.f, dummy = 0.f;
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
-            float bs[4];
-            chan4(p.cb[1], i, bs);
+            const float (&bs)[4] = cbv[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 A3[j][i][0] = pack2bf(acc[j][i][0] + bs[0], acc[j][i][1] + bs[1]);
                 A3[j][i][1] = pack2bf(acc[j][i][2] + bs[2], acc[j][i][3] + bs[3]);
                 if (frame(j) < T) s += (bf_lo(A3[j][i][0]) + bf_hi(A3[j][i][0])) + (bf_lo(A3[j][i][1]) + bf_hi(A3[j][i][1]));
+                sched_fence();
             }
         }
         wg_sum2(s, dummy);
@@ -242,47 +261,50 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     }
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
-        float gm[4], bt[4];
-        chan4(p.gn_w, i, gm);
-        chan4(p.gn_b, i, bt);
+        const float (&gm)[4] = gmv[i];
+        const float (&bt)[4] = btv[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = frame(j) < T;
             const float a[4] = {bf_lo(A3[j][i][0]), bf_hi(A3[j][i][0]), bf_lo(A3[j][i][1]), bf_hi(A3[j][i][1])};
             float h[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = keep_if(ok, silu_f((a[r] - mean) * rstd * gm[r] + bt[r]));
+            for (int r = 0; r < 4; ++r) h[r] = keep_if(ok, silu_fast((a[r] - mean) * rstd * gm[r] + bt[r]));
             put_img(j, i, h);
             put_glb(p.h4, j, i, h);
+            sched_fence();
         }
     }
     lds_barrier();
+    u32x2 tin[4][OT];
     if (BWD) w_fetch(p.wd[2]);
-    conv(0);
+    chan(p.cb[2], cbv);
+    if (BWD) tile_in(p.dh5, tin);
+    conv();
     if (BWD) {
         lds_barrier();
-        w_stash(1);
+        w_stash();
     }
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
-        float bs[4];
-        chan4(p.cb[2], i, bs);
+        const float (&bs)[4] = cbv[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = frame(j) < T;
             const uint32_t a0 = pack2bf(acc[j][i][0] + bs[0], acc[j][i][1] + bs[1]), a1 = pack2bf(acc[j][i][2] + bs[2], acc[j][i][3] + bs[3]);
             const float a[4] = {bf_lo(a0), bf_hi(a0), bf_lo(a1), bf_hi(a1)};
-            float h[4];
+            float h[4], dh[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = silu_f(a[r]);
+            for (int r = 0; r < 4; ++r) silu_pair(a[r], h[r], dh[r]);
             put_glb(p.h5, j, i, h);
             if (BWD) {
-                float d[4] = {0.f, 0.f, 0.f, 0.f}, gq[4];
-                if (ok) load4(reinterpret_cast<const bf16_t*>(p.dh5) + base + goff(j, i), d);
+                const float d[4] = {bf_lo(tin[j][i][0]), bf_hi(tin[j][i][0]), bf_lo(tin[j][i][1]), bf_hi(tin[j][i][1])};
+                float gq[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, d[r] * dsilu_f(a[r]));
+                for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, d[r] * dh[r]);
                 put_img(j, i, gq);
                 put_glb(p.g5, j, i, gq);
+            sched_fence();
             }
         }
     }
@@ -291,17 +313,18 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 
     // ---- backward ----
     w_fetch(p.wd[1]);
-    conv(1);  // dh4
+    chan(p.gn_w, gmv);
+    chan(p.gn_b, btv);
+    conv();  // dh4
     lds_barrier();
-    w_stash(0);
+    w_stash();
     {
         float s1 = 0.f, s2 = 0.f;
         float dwc[OT][4], dbc[OT][4];
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
-            float gm[4], bt[4];
-            chan4(p.gn_w, i, gm);
-            chan4(p.gn_b, i, bt);
+            const float (&gm)[4] = gmv[i];
+            const float (&bt)[4] = btv[i];
 #pragma unroll
             for (int r = 0; r < 4; ++r) dwc[i][r] = dbc[i][r] = 0.f;
 #pragma unroll
@@ -311,13 +334,14 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xh = (a[r] - mean) * rstd;
-                    const float d4 = keep_if(ok, round_to(acc[j][i][r], img) * dsilu_f(xh * gm[r] + bt[r]));
+                    const float d4 = keep_if(ok, round_to(acc[j][i][r], img) * dsilu_fast(xh * gm[r] + bt[r]));
                     dwc[i][r] += d4 * xh;
                     dbc[i][r] += d4;
                     s1 += d4 * gm[r];
                     s2 += d4 * gm[r] * xh;
                     acc[j][i][r] = d4 * gm[r];
                 }
+                sched_fence();
             }
         }
         wg_sum2(s1, s2);
@@ -333,6 +357,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
                 for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, rstd * (acc[j][i][r] - m1 - (a[r] - mean) * rstd * m2));
                 put_img(j, i, gq);
                 put_glb(p.g3, j, i, gq);
+            sched_fence();
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // affine gradients: sum over the 16 frames of the lane row, then one LDS atomic per (wave, channel)
@@ -348,33 +373,37 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     if (tid < CG) atomicAdd(p.dgn_w + (size_t)g * CG + tid, cgs[tid]);
     else if (tid < 2 * CG) atomicAdd(p.dgn_b + (size_t)g * CG + tid - CG, cgs[tid]);
     w_fetch(p.wd[0]);
-    conv(0);  // dh2
+    conv();  // dh2
     lds_barrier();
-    w_stash(1);
+    w_stash();
 #pragma unroll
     for (int i = 0; i < OT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool ok = frame(j) < T;
-            const float a[4] = {bf_lo(A2[j][i][0]), bf_hi(A2[j][i][0]), bf_lo(A2[j][i][1]), bf_hi(A2[j][i][1])};
+            const uint32_t q0 = park[(2 * (j * OT + i)) * TC_THREADS + tid], q1 = park[(2 * (j * OT + i) + 1) * TC_THREADS + tid];
+            const float a[4] = {bf_lo(q0), bf_hi(q0), bf_lo(q1), bf_hi(q1)};
             float gq[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, acc[j][i][r] * dsilu_f(a[r]));
+            for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, acc[j][i][r] * dsilu_fast(a[r]));
             put_img(j, i, gq);
             put_glb(p.g2, j, i, gq);
+            sched_fence();
         }
     lds_barrier();
-    conv(1);  // dh1
+    tile_in(p.a1, tin);
+    conv();  // dh1
 #pragma unroll
     for (int i = 0; i < OT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (frame(j) < T) {
-                float a[4], gq[4];
-                load4(reinterpret_cast<const bf16_t*>(p.a1) + base + goff(j, i), a);
+                const float a[4] = {bf_lo(tin[j][i][0]), bf_hi(tin[j][i][0]), bf_lo(tin[j][i][1]), bf_hi(tin[j][i][1])};
+                float gq[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gq[r] = acc[j][i][r] * dsilu_f(a[r]);
+                for (int r = 0; r < 4; ++r) gq[r] = acc[j][i][r] * dsilu_fast(a[r]);
                 put_glb(p.g1, j, i, gq);
+            sched_fence();
             }
         }
 }
@@ -386,7 +415,7 @@ bool tc_chain_takes(int dtype, int CG, int KS, int T) {
     }();
     return !off && dtype == NBSS_BF16 && CG == 48 && KS == 3 && T <= TC_T;
 }
-size_t tc_wfrag_elems(int groups, int CG, int KS) { return (size_t)groups * ((KS * CG + 31) / 32) * (CG / 16) * 512; }
+size_t tc_wfrag_elems(int groups, int CG, int KS) { return (size_t)groups * ((KS * CG + 31) / 32) * ((CG + 15) / 16) * 512; }
 
 int tc_wprep(const float* const w[3], void* const wf[3], void* const wd[3], int groups, int CG, int KS, hipStream_t st) {
     TcWPrep p;
@@ -395,16 +424,26 @@ int tc_wprep(const float* const w[3], void* const wf[3], void* const wd[3], int 
         p.dst[k] = reinterpret_cast<bf16_t*>(wf[k]);
         p.dst[3 + k] = reinterpret_cast<bf16_t*>(wd[k]);
     }
-    p.groups = groups; p.CG = CG; p.KS = KS; p.NKS = (KS * CG + 31) / 32; p.OT = CG / 16;
+    p.groups = groups; p.CG = CG; p.KS = KS; p.NKS = (KS * CG + 31) / 32; p.OT = (CG + 15) / 16; p.nconv = 3;
     const long total = (long)tc_wfrag_elems(groups, CG, KS);
     NBSS_LAUNCH(tc_wprep_kernel, dim3((unsigned)((total + 255) / 256), wd[0] ? 6 : 3), dim3(256), 0, st, p);
+    return NBSS_CHECK_LAUNCH();
+}
+int tc_wprep_one(const float* w, void* wf, void* wd, int groups, int CG, int KS, hipStream_t st) {
+    TcWPrep p = {};
+    p.src[0] = w;
+    p.dst[0] = reinterpret_cast<bf16_t*>(wf);
+    p.dst[3] = reinterpret_cast<bf16_t*>(wd);
+    p.groups = groups; p.CG = CG; p.KS = KS; p.NKS = (KS * CG + 31) / 32; p.OT = (CG + 15) / 16; p.nconv = 1;
+    const long total = (long)tc_wfrag_elems(groups, CG, KS);
+    NBSS_LAUNCH(tc_wprep_kernel, dim3((unsigned)((total + 255) / 256), wd ? 2 : 1), dim3(256), 0, st, p);
     return NBSS_CHECK_LAUNCH();
 }
 
 template <int CG, int KS>
 static int tc_launch_t(const TChain& p, bool bwd, hipStream_t st) {
     using G = TcGeo<CG, KS>;
-    const size_t lds = ((size_t)G::IMG + 2 * G::WSET) * sizeof(bf16_t) + (32 + 2 * CG) * sizeof(float);
+    const size_t lds = ((size_t)G::IMG + G::WSET) * sizeof(bf16_t) + (32 + 2 * CG) * sizeof(float) + (size_t)8 * (CG / 16) * TC_THREADS * sizeof(uint32_t);
     const int grid = 8 * p.groups * cdiv(p.nseq, 8);
     int e;
     if (bwd) {
