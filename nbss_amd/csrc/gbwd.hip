@@ -742,6 +742,31 @@ __global__ __launch_bounds__(GB_THREADS) void gb_gbn_bwd_kernel(const T* __restr
 #define GA_TMAX 256
 NBSS_DEV int ga_perm_k(int g4, int j) { return j < 4 ? 4 * g4 + j : 16 + 4 * g4 + (j - 4); }
 
+// A fragment whose K dimension is the token axis (permuted order: two stacked C tiles), rows = channels 16 mt + l15, from a row-major
+// [token][DH] LDS image: bf16 through two transposing reads (ds_read_b64_tr_b16), fp32 element by element
+template <class T, int DH>
+NBSS_DEV void ga_frag_t(Frag<T>& f, const T* img, int tok0, int mt) {
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    if constexpr (sizeof(T) == 2) {
+        frag_load_tr(f, img + (size_t)(tok0 + 4 * g4 + (l15 >> 2)) * DH + 16 * mt + 4 * (l15 & 3), DH);
+    } else {
+        const int d = 16 * mt + l15;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frag_set(f, j, d < DH ? load1(img + (size_t)(tok0 + ga_perm_k(g4, j)) * DH + d) : 0.f);
+    }
+}
+// rows of the head's [Tn][DH] slice of a [N][ld] tensor into a row-major image, zero rows up to TP: 16-byte pieces
+template <class T, int DH>
+NBSS_DEV void ga_stage(T* img, const T* src, int ld, int Tn, int TP) {
+    constexpr int VE = 16 / sizeof(T), PR = DH / VE;
+    for (int e = threadIdx.x; e < TP * PR; e += GB_THREADS) {
+        const int t = e / PR, pc = e % PR;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < Tn) v = *reinterpret_cast<const u32x4*>(src + (size_t)t * ld + pc * VE);
+        *reinterpret_cast<u32x4*>(img + (size_t)t * DH + pc * VE) = v;
+    }
+}
+
 // BWD = false: the forward alone (O; dO / dqkv / lse / Dv are not touched) — the attention of the narrow-band building blocks (nbss_nb_attention_fwd)
 template <class T, int DH, bool BWD>
 __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restrict__ qkv, const T* __restrict__ dO, T* __restrict__ O, T* __restrict__ dqkv,
@@ -755,11 +780,8 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)seq * Tn;
     const int ld = 3 * H;
-    for (int e = threadIdx.x; e < TP * DH; e += GB_THREADS) {
-        const int t = e / DH, d = e % DH;
-        store1(Ks + e, t < Tn ? load1(qkv + (n0 + t) * ld + H + head * DH + d) : 0.f);
-        store1(Vs + e, t < Tn ? load1(qkv + (n0 + t) * ld + 2 * H + head * DH + d) : 0.f);
-    }
+    ga_stage<T, DH>(Ks, qkv + n0 * ld + H + head * DH, ld, Tn, TP);
+    ga_stage<T, DH>(Vs, qkv + n0 * ld + 2 * H + head * DH, ld, Tn, TP);
     __syncthreads();
     const float scale = rsqrtf((float)DH);
     for (int qt = w; qt < NT; qt += GB_THREADS / 64) {
@@ -851,16 +873,13 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_q_kernel(const T* __restri
                 frag_from_c2(dsf, ds0, ds1);
 #pragma unroll
                 for (int mt = 0; mt < MTD; ++mt) {
-                    const int d = 16 * mt + l15;
                     Frag<T> vt, kt;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int key = 32 * kk + ga_perm_k(g4, j);
-                        frag_set(vt, j, d < DH ? load1(Vs + (size_t)key * DH + d) : 0.f);
-                        frag_set(kt, j, d < DH ? load1(Ks + (size_t)key * DH + d) : 0.f);
-                    }
+                    ga_frag_t<T, DH>(vt, Vs, 32 * kk, mt);
                     oacc[mt] = mma(vt, pf, oacc[mt]);
-                    if (BWD) qacc[mt] = mma(kt, dsf, qacc[mt]);
+                    if (BWD) {
+                        ga_frag_t<T, DH>(kt, Ks, 32 * kk, mt);
+                        qacc[mt] = mma(kt, dsf, qacc[mt]);
+                    }
                 }
             }
         }
@@ -891,11 +910,8 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_k_kernel(const T* __restri
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const size_t n0 = (size_t)seq * Tn;
     const int ld = 3 * H;
-    for (int e = threadIdx.x; e < TP * DH; e += GB_THREADS) {
-        const int t = e / DH, d = e % DH;
-        store1(Qs + e, t < Tn ? load1(qkv + (n0 + t) * ld + head * DH + d) : 0.f);
-        store1(dOs + e, t < Tn ? load1(dO + (n0 + t) * H + head * DH + d) : 0.f);
-    }
+    ga_stage<T, DH>(Qs, qkv + n0 * ld + head * DH, ld, Tn, TP);
+    ga_stage<T, DH>(dOs, dO + n0 * H + head * DH, H, Tn, TP);
     for (int t = threadIdx.x; t < TP; t += GB_THREADS) {
         ls[t] = t < Tn ? lse[(n0 + t) * heads + head] : 0.f;
         Ds[t] = t < Tn ? Dv[(n0 + t) * heads + head] : 0.f;
@@ -956,14 +972,9 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_k_kernel(const T* __restri
             frag_from_c2(dsf, dst[0], dst[1]);
 #pragma unroll
             for (int mt = 0; mt < MTD; ++mt) {
-                const int d = 16 * mt + l15;
                 Frag<T> dot, qt;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = 32 * kk + ga_perm_k(g4, j);
-                    frag_set(dot, j, d < DH ? load1(dOs + (size_t)q * DH + d) : 0.f);
-                    frag_set(qt, j, d < DH ? load1(Qs + (size_t)q * DH + d) : 0.f);
-                }
+                ga_frag_t<T, DH>(dot, dOs, 32 * kk, mt);
+                ga_frag_t<T, DH>(qt, Qs, 32 * kk, mt);
                 vacc[mt] = mma(dot, pf, vacc[mt]);
                 kacc[mt] = mma(qt, dsf, kacc[mt]);
             }
@@ -1256,7 +1267,7 @@ static int gb_full_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer,
 template <class T, int DH>
 static int gb_attn_launch(const nbss_cfg& c, const void* qkv, const void* dO, void* O, void* dqkv, float* lse, float* Dv, hipStream_t st) {
     const int TP = 32 * cdiv(c.T, 32);
-    const size_t ldsq = (size_t)2 * TP * DH * sizeof(T), ldsk = ldsq + (size_t)2 * TP * sizeof(float);
+    const size_t ldsq = (size_t)2 * TP * DH * sizeof(T) + 64, ldsk = ldsq + (size_t)2 * TP * sizeof(float);  // (+64: the transposing reads of a 24-wide head's second channel tile run 16 bytes past the last row)
     if (c.T > GA_TMAX || ldsk > 160 * 1024) return NBSS_EUNSUPPORTED;
     int e;
     if ((e = NBSS_SET_MAX_LDS((gb_attn_q_kernel<T, DH, true>), ldsq))) return e;
@@ -1533,7 +1544,7 @@ int nb_gbn_impl(int dtype, int B, int F, int Tn, int C, const void* x, const flo
 template <class T, int DH>
 static int nb_attn_fwd(long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st) {
     const int TP = 32 * cdiv(Tn, 32);
-    const size_t lds = (size_t)2 * TP * DH * sizeof(T);
+    const size_t lds = (size_t)2 * TP * DH * sizeof(T) + 64;
     if (Tn > GA_TMAX || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     int e = NBSS_SET_MAX_LDS((gb_attn_q_kernel<T, DH, false>), lds);
     if (e) return e;

@@ -7,7 +7,7 @@
 // the tiles.  Both operands reach the LDS by DMA (global_load_lds_dwordx4, no register stop) in K-slabs of 32 through a 3-stage ring; a
 // DMA instruction writes one FRAGMENT BLOCK: the 16 rows x 32 k of one MFMA operand in reader-lane order (lane l's 16-byte piece at 16 l),
 // so the fragment read is one conflict-free ds_read_b128 at base + 16 lane and the global side fetches 64 contiguous bytes per row.
-// Two workgroups share a CU (62 KB of LDS each): one computes while the other waits for its slab or stores a tile.
+// Two workgroups share a CU (76 KB of LDS each): one computes while the other waits for its slab or stores a tile.
 // gb_tap_gemm_lds_kernel (gbwd.hip) fed the MFMA from global memory one 16-row tile at a time: 102 TF/s over the large train step.
 #include "tapgemm.h"
 #include "layout.h"
@@ -21,6 +21,7 @@
 #define GL_PER_WAVE (GL_NFB / 4)                   // DMA instructions per wave and stage
 #define GL_STAGE (GL_NFB * GL_FB)
 #define GL_NST 3
+#define GL_SLD 104                                 // row stride (elements) of a wave's store-staging tile: 16 rows x 96 outputs, 208-byte rows
 
 // vmcnt(n): the wave's n most recent vector-memory operations may still be in flight
 template <int N>
@@ -153,31 +154,32 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
             }
         }
         sched_fence();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const long row = (long)tl.rt * GL_ROWS + wr * 64 + t * 16 + l15;
-            const bool rv = row < p.rows;
-            const size_t ro = (size_t)row * p.ldy + p.ycol;
-            bf16_t* yr = reinterpret_cast<bf16_t*>(p.Y) + ro;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int m0 = mbase + 16 * i;
-                if (rv && m0 < p.Mg) *reinterpret_cast<u32x2*>(yr + m0) = outp[t][i];
-            }
-        }
-        if (p.Y2) {  // SiLU of the STORED value next to it (a and h of a forward step in one pass)
+        // stores: a row tile (16 rows x 96 outputs) goes through the wave's own 3 KB of LDS and leaves as 16-byte pieces, 12 adjacent lanes per
+        // 192-byte row run (from the C layout directly: 8 bytes per lane in 32-byte runs, 24 store instructions per tile instead of 12)
+        bf16_t* stg = reinterpret_cast<bf16_t*>(smem + GL_NST * GL_STAGE + ((p.Mp * 4 + 15) & ~15)) + w * 16 * GL_SLD;
+        const int mw = tl.mc * GL_OUTS + wm * 96;  // first output of the wave's tile
+        for (int pass = 0; pass < (p.Y2 ? 2 : 1); ++pass) {
+            bf16_t* Yb = reinterpret_cast<bf16_t*>(pass ? p.Y2 : p.Y) + p.ycol;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const long row = (long)tl.rt * GL_ROWS + wr * 64 + t * 16 + l15;
-                const bool rv = row < p.rows;
-                bf16_t* y2 = reinterpret_cast<bf16_t*>(p.Y2) + (size_t)row * p.ldy + p.ycol;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    const int m0 = mbase + 16 * i;
-                    const uint32_t v0 = outp[t][i][0], v1 = outp[t][i][1];
-                    if (rv && m0 < p.Mg)
-                        store4(y2 + m0, silu_f(bf2f((bf16_t)(v0 & 0xFFFF))), silu_f(bf2f((bf16_t)(v0 >> 16))), silu_f(bf2f((bf16_t)(v1 & 0xFFFF))), silu_f(bf2f((bf16_t)(v1 >> 16))));
+                    u32x2 v = outp[t][i];
+                    if (pass) {  // SiLU of the STORED value (a and h of a forward step in one pass)
+                        v[0] = pack2bf(silu_f(bf2f((bf16_t)(v[0] & 0xFFFF))), silu_f(bf2f((bf16_t)(v[0] >> 16))));
+                        v[1] = pack2bf(silu_f(bf2f((bf16_t)(v[1] & 0xFFFF))), silu_f(bf2f((bf16_t)(v[1] >> 16))));
+                    }
+                    *reinterpret_cast<u32x2*>(stg + l15 * GL_SLD + 16 * i + 4 * g4) = v;
                 }
+                wave_lds_sync();
+                const long row0 = (long)tl.rt * GL_ROWS + wr * 64 + t * 16;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int pc = lane + 64 * k, r = pc / 12, c8 = (pc % 12) * 8;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * GL_SLD + c8);
+                    if (row0 + r < p.rows && mw + c8 < p.Mg) *reinterpret_cast<u32x4*>(Yb + (size_t)(row0 + r) * p.ldy + mw + c8) = v;
+                }
+                wave_lds_sync();
             }
         }
     }
@@ -191,12 +193,12 @@ static bool gl_disabled() {
     return off;
 }
 bool gl_gemm_takes(const TapGemm& p) {
-    return !gl_disabled() && p.taps == 1 && p.groups == 1 && !p.xact && p.Kg == p.Kp && p.Kg >= 64 && p.Mg >= 64 && p.Mg % 4 == 0 && p.ldx % 8 == 0 && p.xcol % 8 == 0 &&
-           p.ldy % 4 == 0 && p.ycol % 4 == 0 && (!p.R || p.ldr % 4 == 0) && !(p.R && p.Dact) && p.Mp <= 1024;
+    return !gl_disabled() && p.taps == 1 && p.groups == 1 && !p.xact && p.Kg == p.Kp && p.Kg >= 64 && p.Mg >= 64 && p.Mg % 8 == 0 && p.ldx % 8 == 0 && p.xcol % 8 == 0 &&
+           p.ldy % 8 == 0 && p.ycol % 8 == 0 && (!p.R || p.ldr % 4 == 0) && !(p.R && p.Dact) && p.Mp <= 1024;
 }
 int gl_gemm_bf16(const TapGemm& p, hipStream_t st) {
     const int nrt = cdiv(p.rows, GL_ROWS), nmc = cdiv(p.Mg, GL_OUTS);
-    const size_t lds = (size_t)GL_NST * GL_STAGE + (size_t)p.Mp * sizeof(float);
+    const size_t lds = (size_t)GL_NST * GL_STAGE + (((size_t)p.Mp * sizeof(float) + 15) & ~(size_t)15) + (size_t)4 * 16 * GL_SLD * sizeof(bf16_t);
     int e = NBSS_SET_MAX_LDS(gl_gemm_kernel, lds);
     if (e) return e;
     const long ntiles = (long)nrt * nmc;

@@ -136,6 +136,18 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     auto put_glb = [&](void* dst, int j, int i, const float (&v)[4]) {
         if (dst && frame(j) < T) store4(reinterpret_cast<bf16_t*>(dst) + base + goff(j, i), v[0], v[1], v[2], v[3]);
     };
+    // the image -> a [N][FFN] tensor as 16-byte pieces of full 96-byte row slices (between the barrier that completes the image and the one that
+    // ends the conv reading it); from the C layout the same tensor is 12 stores of 8 bytes per lane in 32-byte runs
+    auto img_out = [&](void* dst) {
+        if (!dst) return;
+        bf16_t* d = reinterpret_cast<bf16_t*>(dst) + base;
+#pragma unroll 2
+        for (int q = 0; q < TC_T * PPR / TC_THREADS; ++q) {
+            const int e = tid + q * TC_THREADS, t = e / PPR, pc = e % PPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(img + (size_t)(t + TC_HALO) * RS + pc * 8);
+            if (t < T) *reinterpret_cast<u32x4*>(d + (unsigned)(t * FFN + pc * 8)) = v;
+        }
+    };
     // the lane's 4 OT channels of a per-channel parameter, requested BEFORE the phase's stores (a load between two stores waits for the first)
     auto chan = [&](const float* prm, float (&o)[OT][4]) {
 #pragma unroll
@@ -218,11 +230,11 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
             h[2] = keep_if(ok, silu_fast(bf_lo(A2[j][i][1])));
             h[3] = keep_if(ok, silu_fast(bf_hi(A2[j][i][1])));
             put_img(j, i, h);
-            put_glb(p.h2, j, i, h);
             sched_fence();
         }
     }
     lds_barrier();
+    img_out(p.h2);
     float gmv[OT][4], btv[OT][4];
     w_fetch(p.wf[2]);
     chan(p.cb[1], cbv);
@@ -271,11 +283,11 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[r] = keep_if(ok, silu_fast((a[r] - mean) * rstd * gm[r] + bt[r]));
             put_img(j, i, h);
-            put_glb(p.h4, j, i, h);
             sched_fence();
         }
     }
     lds_barrier();
+    img_out(p.h4);
     u32x2 tin[4][OT];
     if (BWD) w_fetch(p.wd[2]);
     chan(p.cb[2], cbv);
@@ -303,13 +315,13 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, d[r] * dh[r]);
                 put_img(j, i, gq);
-                put_glb(p.g5, j, i, gq);
-            sched_fence();
+                sched_fence();
             }
         }
     }
     if (!BWD) return;
     lds_barrier();
+    img_out(p.g5);
 
     // ---- backward ----
     w_fetch(p.wd[1]);
@@ -356,8 +368,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, rstd * (acc[j][i][r] - m1 - (a[r] - mean) * rstd * m2));
                 put_img(j, i, gq);
-                put_glb(p.g3, j, i, gq);
-            sched_fence();
+                sched_fence();
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // affine gradients: sum over the 16 frames of the lane row, then one LDS atomic per (wave, channel)
@@ -370,6 +381,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
         }
     }
     lds_barrier();
+    img_out(p.g3);
     if (tid < CG) atomicAdd(p.dgn_w + (size_t)g * CG + tid, cgs[tid]);
     else if (tid < 2 * CG) atomicAdd(p.dgn_b + (size_t)g * CG + tid - CG, cgs[tid]);
     w_fetch(p.wd[0]);
@@ -387,10 +399,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, acc[j][i][r] * dsilu_fast(a[r]));
             put_img(j, i, gq);
-            put_glb(p.g2, j, i, gq);
             sched_fence();
         }
     lds_barrier();
+    img_out(p.g2);
     tile_in(p.a1, tin);
     conv();  // dh1
 #pragma unroll

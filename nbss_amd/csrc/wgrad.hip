@@ -286,8 +286,10 @@ NBSS_HD int tr_ld(int cols) {
 // NS = tile slots per wave (compile time, all executed: slots past the last tile contract a dummy tile that is never flushed).
 // The MFMA section has no branches, so the LDS reads of the following tiles are scheduled ahead of each MFMA; with
 // per-slot `if (tile exists)` tests every tile was read -> wait -> MFMA in sequence.
+// NS > 14 (all 8 groups of a large T-conv in one workgroup: 216 tiles = 27 slots per wave, 32-token chunks): one workgroup per CU with up to 256
+// registers, the per-slot read offsets recomputed from the (wave-uniform) tile index instead of kept in 2 NS registers.
 template <int W3_KC, int NS>
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
+__global__ __launch_bounds__(WG_THREADS, NS > 14 ? 1 : 2) void wgrad_tr3_kernel(WgradArgs a) {
     constexpr int NBUF = 2;
     NBSS_LDS(smem);
     typedef bf16_t T;
@@ -325,18 +327,29 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
     const int nfirst = ngrp * mtiles, ntot = nfirst * ntiles;  // tile tl = nt * nfirst + (g * mtiles + mt)
 
     // per-slot offsets (elements, inside a buffer) of this lane's transposing reads
-    int oa[NS], ob[NS];
+    constexpr bool GW = NS > 14;  // wave = group variant: wave w owns the 3 x 9 tiles of group w, tile (mt, nt) in accumulator nt * 3 + mt
+    int oa[GW ? 3 : NS], ob[GW ? 9 : NS];
     const int trow = 4 * g4 + (l15 >> 2), tcol = 4 * (l15 & 3);
+    if constexpr (GW) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int tl = s * WG_WAVES + w;
-        oa[s] = trow * lda + tcol; ob[s] = imgA + trow * ldb + tcol;  // dummy slot: tile 0's operands
-        if (tl < ntot) {
-            const int nt = tl / nfirst, gm = tl % nfirst, g = gm / mtiles, mt = gm % mtiles;
-            oa[s] = trow * lda + g * mg + mt * 16 + tcol;
-            int q0 = nt * 16 + tcol;
-            if (q0 >= nexp) q0 = 0;  // padding columns of the last tile: any valid address, discarded at the flush
-            ob[s] = imgA + ((q0 / ng) * rs + trow) * ldb + g * ng + q0 % ng;  // tap = q0 / ng: image row k + tap rs holds the token tap - h steps away
+        for (int mt = 0; mt < 3; ++mt) oa[mt] = trow * lda + w * mg + mt * 16 + tcol;
+#pragma unroll
+        for (int nt = 0; nt < 9; ++nt) {
+            const int q0 = nt * 16 + tcol;  // (9 x 16 = taps x ng exactly: no padding columns)
+            ob[nt] = imgA + ((q0 / ng) * rs + trow) * ldb + w * ng + q0 % ng;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tl = s * WG_WAVES + w;
+            oa[s] = trow * lda + tcol; ob[s] = imgA + trow * ldb + tcol;  // dummy slot: tile 0's operands
+            if (tl < ntot) {
+                const int nt = tl / nfirst, gm = tl % nfirst, g = gm / mtiles, mt = gm % mtiles;
+                oa[s] = trow * lda + g * mg + mt * 16 + tcol;
+                int q0 = nt * 16 + tcol;
+                if (q0 >= nexp) q0 = 0;  // padding columns of the last tile: any valid address, discarded at the flush
+                ob[s] = imgA + ((q0 / ng) * rs + trow) * ldb + g * ng + q0 % ng;  // tap = q0 / ng: image row k + tap rs holds the token tap - h steps away
+            }
         }
     }
     // Per-vector descriptors (chunk independent).  Slot u is an A slot for EVERY thread when u < UA and a B slot otherwise (a few
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
             if (!vok[u] || (unsigned)(vkk[u] - lo) >= (unsigned)span || (vt1[u] && !t1ok) || WG_PROBE(4)) continue;
             const T* sbase = u < UA ? Ab : Bb;  // wave-uniform
             pre[u] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(sbase) + (size_t)(vgo[u] * 2u));
-            if (u >= UA && sb) { pmu[u] = sb[2 * vtok[u]]; prs[u] = sb[2 * vtok[u] + 1]; }
+            if (!GW && u >= UA && sb) { pmu[u] = sb[2 * vtok[u]]; prs[u] = sb[2 * vtok[u] + 1]; }
         }
     };
     auto stash = [&](T* buf) {
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         for (int u = 0; u < W3_MAXV; ++u) {
             if (!vok[u] || WG_PROBE(8)) continue;
             u32x4 x = pre[u];
-            if (u >= UA && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
+            if (!GW && u >= UA && a.stats) {  // LayerNorm on the fly (rows outside the valid range have rstd = 0 and stay 0)
                 float f[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(x[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(x[i] >> 16)); }
@@ -436,6 +449,21 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         constexpr int KH = W3_KC / 32;
         Frag<T> fa[2], fb[2];
         if (WG_PROBE(2)) { b ^= 1; continue; }  // probe: no MFMA section
+        if constexpr (GW) {  // (one 32-token k-step per chunk) 3 dY fragments x 9 X fragments: 12 transposing fragment reads per 27 MFMAs
+            Frag<T> ga[3];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                frag_load_tr(ga[mt], buf + oa[mt], lda);
+                bacc[mt] = mma(ga[mt], ones, bacc[mt]);
+            }
+            frag_load_tr(fb[0], buf + ob[0], ldb);
+#pragma unroll
+            for (int nt = 0; nt < 9; ++nt) {
+                if (nt + 1 < 9) frag_load_tr(fb[(nt + 1) & 1], buf + ob[nt + 1], ldb);
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) acc[nt * 3 + mt] = mma(ga[mt], fb[nt & 1], acc[nt * 3 + mt]);
+            }
+        } else {
         frag_load_tr(fa[0], buf + oa[0], lda);
         frag_load_tr(fb[0], buf + ob[0], ldb);
 #pragma unroll
@@ -449,6 +477,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
             acc[s] = mma(fa[cur], fb[cur], acc[s]);
             if (s < W3_BS) bacc[s < W3_BS ? s : 0] = mma(fa[cur], ones, bacc[s < W3_BS ? s : 0]);
         }
+        }
         if (NBUF == 1) lds_barrier();
         else b ^= 1;
     }
@@ -458,6 +487,23 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_tr3_kernel(WgradArgs a) {
         const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
         float* pt = a.part + wg * ntot * 256;
         float* pbias = a.part + (size_t)gridDim.y * gridDim.x * ntot * 256 + wg * ntot * 16;
+        if constexpr (GW) {
+#pragma unroll
+            for (int nt = 0; nt < 9; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    const int tl = nt * nfirst + w * 3 + mt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[((size_t)tl * 4 + r) * 64 + lane] = acc[nt * 3 + mt][r];
+                }
+            if (do_bias && l15 == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pbias[(w * 3 + mt) * 16 + 4 * g4 + r] = bacc[mt][r];
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int tl = s * WG_WAVES + w;
@@ -575,6 +621,29 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
     const int ncA = all ? a.MA : mg, ncB = all ? a.NB : ng;
     // transposing-read kernels: whole rows are copied in 16-byte pieces (staged widths % 8) and tiles are addressed in
     // 4-channel pieces (group widths % 4, checked by the caller)
+    // T-convs whose groups do not fit the 112-tile workgroup together (SpatialNet-large: 8 groups x 27 tiles): as one group per blockIdx.y every
+    // workgroup read 96-byte slices of the 768-byte rows and did 7 MFMAs per wave between two barriers (237 us per problem at batch 4, 0.85 TB/s).
+    // All groups in one workgroup on full rows: 32-token chunks, 27 tile slots per wave, one workgroup per CU.
+    if (sizeof(T) == 2 && !all && nz == 1 && a.taps > 1 && a.shift_dim == 0 && a.shift_stride == 1 && a.Ntok % a.T == 0 && a.groups * tpg <= WG_WAVES * 27 &&
+        a.groups == WG_WAVES && mtiles == 3 && ntiles == 9 && a.taps * ng == 144 && a.MA % 8 == 0 && a.NB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && !a.a_gw && !a.b_gw && !a.stats && a.part && !WG_PROBE_HOST(a, 1)) {
+        const int kc = 32, h3 = a.taps / 2, rowsB = kc + 2 * h3;
+        const size_t img = ((size_t)kc * tr_ld(a.MA) + (size_t)rowsB * tr_ld(a.NB)) * 2;
+        const int nvec = (cdiv(kc * (a.MA / 8), WG_THREADS) + cdiv(rowsB * (a.NB / 8), WG_THREADS)) * WG_THREADS;
+        const size_t lds3 = 2 * img + 2 * (size_t)a.NB * sizeof(float);
+        const int ntot3 = a.groups * tpg;
+        int xb = 256;
+        const int nch = (a.Ntok / a.T) * cdiv(a.T, kc);
+        if (xb > nch) xb = nch;
+        if (nvec <= W3_MAXV * WG_THREADS && lds3 <= 158 * 1024 && (size_t)xb * ntot3 * 272 * sizeof(float) <= WGPART_BYTES) {
+            ProfScope ps(PK_WGRAD, st);
+            int e3;
+            if ((e3 = NBSS_SET_MAX_LDS((wgrad_tr3_kernel<32, 27>), lds3))) return e3;
+            NBSS_LAUNCH((wgrad_tr3_kernel<32, 27>), dim3(xb, 1), dim3(WG_THREADS), lds3, st, a);
+            if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
+            NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot3, xb < WG_RSL ? xb : WG_RSL, 1), dim3(256), 0, st, a, xb, 1);
+            return NBSS_CHECK_LAUNCH();
+        }
+    }
     if (nz == 1 && sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
         // 64-token chunks, one X image for all taps: dense problems, T-convs and (96-row chunks of 48 frequencies x 2 frames) F-convs
         const bool fmode3 = a.taps > 1 && a.shift_dim == 1 && a.shift_stride == a.T && a.Ntok % (a.F * a.T) == 0;
