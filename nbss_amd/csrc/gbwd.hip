@@ -295,117 +295,133 @@ __global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd_kernel(const T* __restri
 }
 
 
-// ---- the same three row kernels with 16 lanes per row (4 rows per wave; lane = 4 contiguous channels of every 64: 8-byte pieces, 128 contiguous
-// bytes per row and step) for widths that are multiples of 64: a whole wave per 192-wide row spent its time in six-step wave reductions
-// (LayerNorm backward: 144 us per launch for a 50 MB tensor)
-template <class T, int NQ>
-__global__ __launch_bounds__(GB_THREADS) void gb_ln_fwd4_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+// ---- row kernels for widths that are multiples of 64 with fewer lanes per row: a whole wave per 192-wide row spent its time in six-step wave
+// reductions (LayerNorm backward: 144 us per launch for a 50 MB tensor; with 16 lanes per row 82 us; 8 lanes and one load burst: below)
+// ---- LayerNorm forward / backward with 8 lanes per row (8 rows per wave; lane = 16-byte pieces l7 + 8 k of the row): every load of an iteration is
+// independent of its reductions and issued up front — x, du AND dy: the 16-lane version fetched dy after the row sums, a second memory round trip per
+// 4 rows (82 us per launch for 200 MB of traffic at batch 4) — and the clamped (not branched) addresses keep them in one burst.
+NBSS_DEV float row_sum8(float v) {  // sum over the 8 lanes of a row (lanes sharing l >> 3), result in every lane
+#ifdef NBSS_EMU
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+#else
+#define NBSS_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true))
+    NBSS_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    NBSS_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    NBSS_DPP_ADD(0x141);  // row_half_mirror
+#undef NBSS_DPP_ADD
+    return v;
+#endif
+}
+template <class T, int NP>  // C = 64 NP
+__global__ __launch_bounds__(GB_THREADS) void gb_ln_fwd8_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 T* __restrict__ u, float* __restrict__ stats, long N) {
-    constexpr int C = 64 * NQ;
-    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
-    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 4;
-    for (long n0 = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 4; n0 < N; n0 += nw) {  // (whole-wave loop: row_sum16 is a wave collective)
-        const long n = n0 + g4;
+    constexpr int C = 64 * NP;
+    const int lane = lane_id(), l7 = lane & 7, g8 = lane >> 3;
+    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 8;
+    for (long n0 = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 8; n0 < N; n0 += nw) {  // (whole-wave loop: row_sum8 is a wave collective)
+        const long n = n0 + g8;
         const bool v_ = n < N;
-        float v[NQ][4];
+        const T* xr = x + (v_ ? n : N - 1) * C + 8 * l7;
+        float v[NP][8];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            if (v_) load4(x + n * C + 64 * i + 4 * l15, v[i]);
-            else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-        const float mean = row_sum16(s) * (1.0f / C);
+        for (int k = 0; k < NP; ++k) load8(xr + 64 * k, v[k]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[k][j];
+        const float mean = row_sum8(s) * (1.0f / C);
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i)
+        for (int k = 0; k < NP; ++k)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = v[i][r] - mean;
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[k][j] - mean;
                 q += d * d;
             }
-        const float rstd = rsqrtf(row_sum16(q) * (1.0f / C) + 1e-5f);
-        if (v_ && l15 == 0) {
+        const float rstd = rsqrtf(row_sum8(q) * (1.0f / C) + 1e-5f);
+        if (v_ && l7 == 0) {
             stats[2 * n] = mean;
             stats[2 * n + 1] = rstd;
         }
         if (u && v_) {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int c = 64 * i + 4 * l15;
-                float o[4];
+            for (int k = 0; k < NP; ++k) {
+                float gm[8], bt[8], o[8];
+                load8(gamma + 64 * k + 8 * l7, gm);
+                load8(beta + 64 * k + 8 * l7, bt);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mean) * rstd * gamma[c + r] + beta[c + r];
-                store4(u + n * C + c, o[0], o[1], o[2], o[3]);
+                for (int j = 0; j < 8; ++j) o[j] = (v[k][j] - mean) * rstd * gm[j] + bt[j];
+                store8(u + n * C + 64 * k + 8 * l7, o);
             }
         }
     }
 }
-template <class T, int NQ>
-__global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd4_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ stats,
+template <class T, int NP>
+__global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd8_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ stats,
                                                                 const float* __restrict__ gamma, const T* __restrict__ dy, T* __restrict__ dx,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, long N) {
-    constexpr int C = 64 * NQ;
+    constexpr int C = 64 * NP;
     NBSS_LDS(smem);
     float* red = reinterpret_cast<float*>(smem);  // [2][C]
-    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    const int lane = lane_id(), l7 = lane & 7, g8 = lane >> 3;
     for (int i = threadIdx.x; i < 2 * C; i += GB_THREADS) red[i] = 0.f;
     __syncthreads();
-    float dg[NQ][4], db[NQ][4], gm[NQ][4];
+    float dg[NP][8], db[NP][8];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i)
+    for (int k = 0; k < NP; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dg[i][r] = db[i][r] = 0.f;
-            gm[i][r] = gamma[64 * i + 4 * l15 + r];
-        }
-    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 4;
-    for (long n0 = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 4; n0 < N; n0 += nw) {
-        const long n = n0 + g4;
+        for (int j = 0; j < 8; ++j) dg[k][j] = db[k][j] = 0.f;
+    const long nw = (long)gridDim.x * (GB_THREADS / 64) * 8;
+    for (long n0 = ((long)blockIdx.x * (GB_THREADS / 64) + wave_id()) * 8; n0 < N; n0 += nw) {
+        const long n = n0 + g8;
         const bool v_ = n < N;
-        const float mean = v_ ? stats[2 * n] : 0.f, rstd = v_ ? stats[2 * n + 1] : 0.f;
-        float xh[NQ][4], g[NQ][4];
+        const long nc = v_ ? n : N - 1;
+        const float mean = stats[2 * nc], rstd = v_ ? stats[2 * nc + 1] : 0.f;
+        float xh[NP][8], g[NP][8], yv[NP][8];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            load8(x + nc * C + 64 * k + 8 * l7, xh[k]);
+            load8(du + nc * C + 64 * k + 8 * l7, g[k]);
+            load8(dy + nc * C + 64 * k + 8 * l7, yv[k]);
+        }
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            float xv[4], dv[4];
-            if (v_) {
-                load4(x + n * C + 64 * i + 4 * l15, xv);
-                load4(du + n * C + 64 * i + 4 * l15, dv);
-            } else {
-                xv[0] = xv[1] = xv[2] = xv[3] = mean;
-                dv[0] = dv[1] = dv[2] = dv[3] = 0.f;
-            }
+        for (int k = 0; k < NP; ++k) {
+            float gm[8];
+            load8(gamma + 64 * k + 8 * l7, gm);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xh[i][r] = (xv[r] - mean) * rstd;
-                dg[i][r] += dv[r] * xh[i][r];
-                db[i][r] += dv[r];
-                g[i][r] = dv[r] * gm[i][r];
-                m1 += g[i][r];
-                m2 += g[i][r] * xh[i][r];
+            for (int j = 0; j < 8; ++j) {
+                const float dv = v_ ? g[k][j] : 0.f;
+                xh[k][j] = (xh[k][j] - mean) * rstd;
+                dg[k][j] += dv * xh[k][j];
+                db[k][j] += dv;
+                g[k][j] = dv * gm[j];
+                m1 += g[k][j];
+                m2 += g[k][j] * xh[k][j];
             }
         }
-        m1 = row_sum16(m1) * (1.0f / C);
-        m2 = row_sum16(m2) * (1.0f / C);
+        m1 = row_sum8(m1) * (1.0f / C);
+        m2 = row_sum8(m2) * (1.0f / C);
         if (v_) {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int c = 64 * i + 4 * l15;
-                float yv[4], o[4];
-                load4(dy + n * C + c, yv);
+            for (int k = 0; k < NP; ++k) {
+                float o[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = yv[r] + rstd * (g[i][r] - m1 - xh[i][r] * m2);
-                store4(dx + n * C + c, o[0], o[1], o[2], o[3]);
+                for (int j = 0; j < 8; ++j) o[j] = yv[k][j] + rstd * (g[k][j] - m1 - xh[k][j] * m2);
+                store8(dx + n * C + 64 * k + 8 * l7, o);
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < NQ; ++i)
+    for (int k = 0; k < NP; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            atomicAdd(&red[64 * i + 4 * l15 + r], dg[i][r]);
-            atomicAdd(&red[C + 64 * i + 4 * l15 + r], db[i][r]);
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&red[64 * k + 8 * l7 + j], dg[k][j]);
+            atomicAdd(&red[C + 64 * k + 8 * l7 + j], db[k][j]);
         }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += GB_THREADS) {
@@ -1068,8 +1084,8 @@ static TapGemm gb_conv(const void* X, const void* Wp, const float* bias, void* Y
 template <class T>
 static int gb_ln_fwd(const void* x, const float* gamma, const float* beta, void* u, float* stats, long N, int C, hipStream_t st) {
     if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
-    if (C == 192) NBSS_LAUNCH((gb_ln_fwd4_kernel<T, 3>), dim3(gb_blocks(N, 16)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N);
-    else if (C == 384) NBSS_LAUNCH((gb_ln_fwd4_kernel<T, 6>), dim3(gb_blocks(N, 16)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N);
+    if (C == 192) NBSS_LAUNCH((gb_ln_fwd8_kernel<T, 3>), dim3(gb_blocks(N, 32 * 2)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N);
+    else if (C == 384) NBSS_LAUNCH((gb_ln_fwd8_kernel<T, 6>), dim3(gb_blocks(N, 32 * 2)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N);
     else NBSS_LAUNCH((gb_ln_fwd_kernel<T>), dim3(gb_blocks(N, 4)), dim3(GB_THREADS), 0, st, (const T*)x, gamma, beta, (T*)u, stats, N, C);
     return NBSS_CHECK_LAUNCH();
 }
@@ -1078,11 +1094,11 @@ static int gb_ln_bwd(const void* du, const void* x, const float* stats, const fl
                      int C, hipStream_t st) {
     if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
     const int blocks = gb_blocks(N, 4 * 16) < 1024 ? gb_blocks(N, 4 * 16) : 1024;  // >= 16 rows per wave: the affine sums end in C atomics per workgroup
-    const int blocks4 = gb_blocks(N, 16 * 8) < 1024 ? gb_blocks(N, 16 * 8) : 1024;  // (>= 8 rows per 16-lane group)
+    const int blocks8 = gb_blocks(N, 32 * 4) < 1024 ? gb_blocks(N, 32 * 4) : 1024;  // (>= 4 rows per 8-lane group)
     if (C == 192)
-        NBSS_LAUNCH((gb_ln_bwd4_kernel<T, 3>), dim3(blocks4), dim3(GB_THREADS), 2 * 192 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
+        NBSS_LAUNCH((gb_ln_bwd8_kernel<T, 3>), dim3(blocks8), dim3(GB_THREADS), 2 * 192 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
     else if (C == 384)
-        NBSS_LAUNCH((gb_ln_bwd4_kernel<T, 6>), dim3(blocks4), dim3(GB_THREADS), 2 * 384 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
+        NBSS_LAUNCH((gb_ln_bwd8_kernel<T, 6>), dim3(blocks8), dim3(GB_THREADS), 2 * 384 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
     else
         NBSS_LAUNCH((gb_ln_bwd_kernel<T>), dim3(blocks), dim3(GB_THREADS), 2 * 64 * GB_CPL * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N, C);
     return NBSS_CHECK_LAUNCH();

@@ -51,25 +51,35 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
         GlTile t = {(u / nmc) * 8 + xcd, u % nmc};
         return t;
     };
-    auto issue = [&](int s) {  // stage s = (tile s / nk, K-slab s % nk) into ring slot s % 3
-        const GlTile t = tile_at(s / nk);
-        const int k0 = (s % nk) * 32 + 8 * g4;
-        char* sb = smem + (s % GL_NST) * GL_STAGE;
+    // the copies of the next stage: the lane's five source rows are set up once per tile (the tile index -> rows divisions and the 64-bit row
+    // addresses took ~50 instructions per copy when redone per stage: 250 per k-step against 24 MFMAs), a stage adds the K offset
+    const bf16_t* src[GL_PER_WAVE];
+    int i_tile = 0, i_k = 0, i_slot = 0;  // issue side: tile, K-slab, ring slot
+    auto issue = [&]() {
+        if (i_k == 0) {
+            const GlTile t = tile_at(i_tile);
 #pragma unroll
-        for (int q = 0; q < GL_PER_WAVE; ++q) {
-            const int f = w * GL_PER_WAVE + q;  // wave-uniform
-            const bf16_t* src;
-            if (f < GL_AFB) {
-                int m = t.mc * GL_OUTS + f * 16 + l15;
-                m = m < p.Mp ? m : p.Mp - 1;
-                src = W + (size_t)m * p.Kp + k0;
-            } else {
-                long r = (long)t.rt * GL_ROWS + (f - GL_AFB) * 16 + l15;
-                r = r < p.rows ? r : p.rows - 1;
-                src = X + (size_t)r * p.ldx + k0;
+            for (int q = 0; q < GL_PER_WAVE; ++q) {
+                const int f = w * GL_PER_WAVE + q;  // wave-uniform
+                if (f < GL_AFB) {
+                    int m = t.mc * GL_OUTS + f * 16 + l15;
+                    m = m < p.Mp ? m : p.Mp - 1;
+                    src[q] = W + (size_t)m * p.Kp + 8 * g4;
+                } else {
+                    long r = (long)t.rt * GL_ROWS + (f - GL_AFB) * 16 + l15;
+                    r = r < p.rows ? r : p.rows - 1;
+                    src[q] = X + (size_t)r * p.ldx + 8 * g4;
+                }
             }
-            dma16_to_lds(sb + f * GL_FB, src);
         }
+        char* sb = smem + i_slot * GL_STAGE + w * GL_PER_WAVE * GL_FB;
+#pragma unroll
+        for (int q = 0; q < GL_PER_WAVE; ++q) dma16_to_lds(sb + q * GL_FB, src[q] + i_k * 32);
+        if (++i_k == nk) {
+            i_k = 0;
+            ++i_tile;
+        }
+        i_slot = i_slot == GL_NST - 1 ? 0 : i_slot + 1;
     };
     const int S = mine * nk;
     if (S == 0) return;
@@ -77,8 +87,8 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
     // tile ahead of it — 24 serialised store round trips per tile, 16 us per tile against 1 us of MFMA work in the first version
     float* bl = reinterpret_cast<float*>(smem + GL_NST * GL_STAGE);
     for (int i = threadIdx.x; i < p.Mp; i += 256) bl[i] = p.bias && i < p.Mg ? p.bias[i] : 0.f;
-    issue(0);
-    if (S > 1) issue(1);
+    issue();
+    if (S > 1) issue();
     f32x4 acc[6][4];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -86,12 +96,13 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
         for (int t = 0; t < 4; ++t) acc[i][t] = F32X4_ZERO;
     const bf16_t* ext = reinterpret_cast<const bf16_t*>(p.Dact ? p.Dact : p.R);  // per-element operand of the epilogue (at most one of the two)
     const int lde = p.Dact ? p.ldy : p.ldr;
+    int c_k = 0, c_tile = 0, c_slot = 0;  // consumer side
+    GlTile tl = tile_at(0);
     for (int s = 0; s < S; ++s) {
         if (s + 1 < S) dma_wait_but<GL_PER_WAVE>();
         else dma_wait_all();
         lds_barrier();
-        const bool last = s % nk == nk - 1;
-        const GlTile tl = tile_at(s / nk);
+        const bool last = c_k == nk - 1;
         const int mbase = tl.mc * GL_OUTS + wm * 96 + 4 * g4;
         // the tile's per-element operand is requested BEFORE the next slab's copies (in-order counter: its wait then leaves the copies in flight)
         u32x2 ex[4][6];
@@ -108,8 +119,9 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
                 }
             }
         }
-        if (s + 2 < S) issue(s + 2);
-        const char* sb = smem + (s % GL_NST) * GL_STAGE + lane * 16;
+        if (s + 2 < S) issue();
+        const char* sb = smem + c_slot * GL_STAGE + lane * 16;
+        c_slot = c_slot == GL_NST - 1 ? 0 : c_slot + 1;
         Frag<bf16_t> a[6], b[4];
 #pragma unroll
         for (int i = 0; i < 6; ++i) frag_load(a[i], reinterpret_cast<const bf16_t*>(sb + (wm * 6 + i) * GL_FB));
@@ -119,7 +131,10 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[i][t] = mma(a[i], b[t], acc[i][t]);
-        if (!last) continue;
+        if (!last) {
+            ++c_k;
+            continue;
+        }
         // epilogue of the tile (C layout: lane = outputs 16 i + 4 g4 + r of its row): every value first, then the stores back to back — a load or a
         // conditional block between two stores makes the compiler wait for the earlier store (vmcnt(0) per block)
         u32x2 outp[4][6];
@@ -182,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void gl_gemm_kernel(TapGemm p, int nrt, int
                 wave_lds_sync();
             }
         }
+        c_k = 0;
+        tl = tile_at(++c_tile);
     }
 }
 
