@@ -15,6 +15,7 @@
 #include "layout.h"
 #include "prof.h"
 #include "tchain.h"
+#include "blocks.h"
 #include <cstdlib>
 
 #define FG_WAVES 8
@@ -45,6 +46,7 @@ struct FconvG {
     float* dlnw;  // accumulated (atomics)
     float* dlnb;
     float* dslope;
+    float* part;  // [B T][3 HH] per-workgroup rows of those three (affine_reduce folds them), or null: atomics
     int B, F, T;
 };
 
@@ -270,9 +272,10 @@ __global__ __launch_bounds__(FG_THREADS, 1) void fconv_bwd_g_kernel(FconvG p) {
         }
     }
     lds_barrier();
+    // (1 004 workgroups adding to the same 576 addresses: chains of same-address atomics that outlast the kernel's memory phase — rows + a reduce)
     for (int i = tid; i < 3 * HH; i += FG_THREADS) {
-        float* dst = i < HH ? p.dlnw + i : i < 2 * HH ? p.dlnb + (i - HH) : p.dslope + (i - 2 * HH);
-        atomicAdd(dst, aff[i]);
+        if (p.part) p.part[(size_t)blockIdx.x * 3 * HH + i] = aff[i];
+        else atomicAdd(i < HH ? p.dlnw + i : i < 2 * HH ? p.dlnb + (i - HH) : p.dslope + (i - 2 * HH), aff[i]);
     }
 }
 
@@ -288,7 +291,7 @@ bool fconv_g_takes(const nbss_cfg& c) {
 }
 size_t fconv_g_wfrag_elems() { return tc_wfrag_elems(8, FgGeo<192>::CG, FG_TAPS); }
 int fconv_g_bwd(const nbss_cfg& c, const float* P, float* G, int layer, int which, const void* x, const void* dy, void* dx, void* dv, float* stats, void* wf,
-                void* wd, hipStream_t st) {
+                void* wd, float* part, hipStream_t st) {
     const int pLW = which ? P_FC2_LN_W : P_FC1_LN_W, pLB = which ? P_FC2_LN_B : P_FC1_LN_B, pW = which ? P_FC2_W : P_FC1_W, pB = which ? P_FC2_B : P_FC1_B,
               pA = which ? P_FC2_PRELU : P_FC1_PRELU;
     int e = tc_wprep_one(P + param_off(c, layer, pW), wf, wd, 8, FgGeo<192>::CG, FG_TAPS, st);
@@ -298,9 +301,15 @@ int fconv_g_bwd(const nbss_cfg& c, const float* P, float* G, int layer, int whic
     p.lnw = P + param_off(c, layer, pLW); p.lnb = P + param_off(c, layer, pLB); p.cb = P + param_off(c, layer, pB); p.slope = P + param_off(c, layer, pA);
     p.dlnw = G + param_off(c, layer, pLW); p.dlnb = G + param_off(c, layer, pLB); p.dslope = G + param_off(c, layer, pA);
     p.B = c.B; p.F = c.F; p.T = c.T;
+    p.part = part;
     const int mtf = cdiv(c.F, 16);
     const size_t lds = (size_t)2 * (mtf * 16 + 4) * FgGeo<192>::LD * 2 + (5 * 192 + 2 * 16 * mtf) * sizeof(float);
     if ((e = NBSS_SET_MAX_LDS(fconv_bwd_g_kernel<192>, lds))) return e;
     NBSS_LAUNCH(fconv_bwd_g_kernel<192>, dim3(c.B * c.T), dim3(FG_THREADS), lds, st, p);
-    return NBSS_CHECK_LAUNCH();
+    if ((e = NBSS_CHECK_LAUNCH()) || !part) return e;
+    AffSegs sg;
+    sg.n = 3;
+    sg.off[0] = param_off(c, layer, pLW); sg.off[1] = param_off(c, layer, pLB); sg.off[2] = param_off(c, layer, pA);
+    sg.cnt[0] = sg.cnt[1] = sg.cnt[2] = 192;
+    return affine_reduce_launch(part, c.B * c.T, sg, G, st);
 }

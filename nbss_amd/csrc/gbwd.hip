@@ -20,6 +20,7 @@
 #include "side.h"
 #include "tapgemm.h"
 #include "tchain.h"
+#include "blocks.h"
 
 #define GB_THREADS 256
 
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_ln_fwd8_kernel(const T* __restr
 template <class T, int NP>
 __global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd8_kernel(const T* __restrict__ du, const T* __restrict__ x, const float* __restrict__ stats,
                                                                 const float* __restrict__ gamma, const T* __restrict__ dy, T* __restrict__ dx,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, long N) {
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ part, long N) {
     constexpr int C = 64 * NP;
     NBSS_LDS(smem);
     float* red = reinterpret_cast<float*>(smem);  // [2][C]
@@ -424,9 +425,16 @@ __global__ __launch_bounds__(GB_THREADS) void gb_ln_bwd8_kernel(const T* __restr
             atomicAdd(&red[C + 64 * k + 8 * l7 + j], db[k][j]);
         }
     __syncthreads();
+    // part: one row per workgroup, folded by affine_reduce (1 024 workgroups adding to the same 2 C addresses are 1 024-deep chains of same-address
+    // atomics: ~50 us behind a kernel whose memory phase takes 30)
     for (int c = threadIdx.x; c < C; c += GB_THREADS) {
-        atomicAdd(dgamma + c, red[c]);
-        atomicAdd(dbeta + c, red[C + c]);
+        if (part) {
+            part[(size_t)blockIdx.x * 2 * C + c] = red[c];
+            part[(size_t)blockIdx.x * 2 * C + C + c] = red[C + c];
+        } else {
+            atomicAdd(dgamma + c, red[c]);
+            atomicAdd(dbeta + c, red[C + c]);
+        }
     }
 }
 template <class T, int NQ>
@@ -1091,18 +1099,31 @@ static int gb_ln_fwd(const void* x, const float* gamma, const float* beta, void*
 }
 template <class T>
 static int gb_ln_bwd(const void* du, const void* x, const float* stats, const float* gamma, const void* dy, void* dx, float* dgamma, float* dbeta, long N,
-                     int C, hipStream_t st) {
+                     int C, hipStream_t st, float* part = nullptr, size_t part_floats = 0) {
     if (C > 64 * GB_CPL) return NBSS_EUNSUPPORTED;
     const int blocks = gb_blocks(N, 4 * 16) < 1024 ? gb_blocks(N, 4 * 16) : 1024;  // >= 16 rows per wave: the affine sums end in C atomics per workgroup
-    const int blocks8 = gb_blocks(N, 32 * 4) < 1024 ? gb_blocks(N, 32 * 4) : 1024;  // (>= 4 rows per 8-lane group)
+    int blocks8 = gb_blocks(N, 32 * 4) < 1024 ? gb_blocks(N, 32 * 4) : 1024;  // (>= 4 rows per 8-lane group)
+    if (part && (C == 192 || C == 384)) {
+        if ((size_t)blocks8 * 2 * C > part_floats) blocks8 = (int)(part_floats / (2 * C));
+        if (blocks8 < 64) part = nullptr, blocks8 = gb_blocks(N, 32 * 4) < 1024 ? gb_blocks(N, 32 * 4) : 1024;
+    } else part = nullptr;
     if (C == 192)
-        NBSS_LAUNCH((gb_ln_bwd8_kernel<T, 3>), dim3(blocks8), dim3(GB_THREADS), 2 * 192 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
+        NBSS_LAUNCH((gb_ln_bwd8_kernel<T, 3>), dim3(blocks8), dim3(GB_THREADS), 2 * 192 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, part, N);
     else if (C == 384)
-        NBSS_LAUNCH((gb_ln_bwd8_kernel<T, 6>), dim3(blocks8), dim3(GB_THREADS), 2 * 384 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N);
+        NBSS_LAUNCH((gb_ln_bwd8_kernel<T, 6>), dim3(blocks8), dim3(GB_THREADS), 2 * 384 * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, part, N);
     else
         NBSS_LAUNCH((gb_ln_bwd_kernel<T>), dim3(blocks), dim3(GB_THREADS), 2 * 64 * GB_CPL * sizeof(float), st, (const T*)du, (const T*)x, stats, gamma, (const T*)dy, (T*)dx, dgamma, dbeta, N, C);
-    return NBSS_CHECK_LAUNCH();
+    int e = NBSS_CHECK_LAUNCH();
+    if (e || !part) return e;
+    AffSegs sg;
+    sg.n = 2;
+    sg.off[0] = 0; sg.off[1] = dbeta - dgamma;  // (relative to dgamma)
+    sg.cnt[0] = sg.cnt[1] = C;
+    return affine_reduce_launch(part, blocks8, sg, dgamma, st);
 }
+// the workspace region of the per-workgroup affine rows (layout.h: ws_part_offset; B max(F, T) rows of 576 floats)
+static float* gb_part(const nbss_cfg& c, void* ws) { return (float*)((char*)ws + ws_part_offset(c)); }
+static size_t gb_part_floats(const nbss_cfg& c) { return (size_t)c.B * (c.F > c.T ? c.F : c.T) * 576; }
 template <class T>
 static int gb_silu_bwd(const void* a, const void* gin, void* gout, long n, hipStream_t st) {
     NBSS_LAUNCH((gb_silu_bwd_kernel<T>), dim3(gb_blocks(n, 1024)), dim3(256), 0, st, (const T*)a, (const T*)gin, (T*)gout, n);
@@ -1154,7 +1175,7 @@ static int gb_fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer
         void* wfr = ar.take(fconv_g_wfrag_elems() * sizeof(T));
         void* wdr = ar.take(fconv_g_wfrag_elems() * sizeof(T));
         if (!wdr) return NBSS_EUNSUPPORTED;
-        int e = fconv_g_bwd(c, P, G, layer, which, x, dy, dx, dv, stats, wfr, wdr, st);
+        int e = fconv_g_bwd(c, P, G, layer, which, x, dy, dx, dv, stats, wfr, wdr, gb_part_floats(c) >= (size_t)c.B * c.T * 576 ? gb_part(c, ws) : nullptr, st);
         if (e) return e;
         // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap - 2) T][i] (LayerNorm applied on the fly from the statistics), bias = colsum(dv)
         const hipStream_t gs = side_fork(sd, st);
@@ -1187,7 +1208,7 @@ static int gb_fconv_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer
                     lp.p[pA], (T*)da, G + param_off(c, layer, pA), N, H);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     if ((e = gb_gemm<T>(gb_conv(da, wd, nullptr, du, N, H, c.f_groups, c.f_ks, c.T, c.T, c.F), st))) return e;
-    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[pLW], dy, dx, G + param_off(c, layer, pLW), G + param_off(c, layer, pLB), N, H, st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[pLW], dy, dx, G + param_off(c, layer, pLW), G + param_off(c, layer, pLB), N, H, st, gb_part(c, ws), gb_part_floats(c)))) return e;
     // conv weight: dW[o][i][tap] = sum_n da[n][o] u[n + (tap - 2) T][i], bias = colsum(da)
     const hipStream_t gs = side_fork(sd, st);
     WgradArgs wa;
@@ -1266,7 +1287,7 @@ static int gb_full_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer,
     void* du = ar.take(N * H * sizeof(T));
     if (!du) return NBSS_EUNSUPPORTED;
     if ((e = gb_gemm<T>(gb_lin(ds, SQ, w_sqT, nullptr, du, H, N, H, SQ), st))) return e;
-    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_FULL_LN_W], dy, dx, G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B), N, H, st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_FULL_LN_W], dy, dx, G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B), N, H, st, gb_part(c, ws), gb_part_floats(c)))) return e;
     // weight gradients
     const hipStream_t gs = side_fork(sd, st);
     if ((e = gb_wgrad_dense(c, ws, dyp, H, H, z, SQ, SQ, G + param_off(c, layer, P_USQ_W), G + param_off(c, layer, P_USQ_B), N, gs))) return e;
@@ -1326,7 +1347,7 @@ static int gb_mhsa_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer,
     else e = NBSS_EUNSUPPORTED;
     if (e) return e;
     if ((e = gb_gemm<T>(gb_lin(dqkv, 3 * H, w_inT, nullptr, du, H, N, H, 3 * H), st))) return e;
-    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_MH_LN_W], dy, dx, G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B), N, H, st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_MH_LN_W], dy, dx, G + param_off(c, layer, P_MH_LN_W), G + param_off(c, layer, P_MH_LN_B), N, H, st, gb_part(c, ws), gb_part_floats(c)))) return e;
     const hipStream_t gs = side_fork(sd, st);
     if ((e = gb_wgrad_dense(c, ws, dy, H, H, O, H, H, G + param_off(c, layer, P_OUTP_W), G + param_off(c, layer, P_OUTP_B), N, gs))) return e;
     return gb_wgrad_dense(c, ws, dqkv, 3 * H, 3 * H, u, H, H, G + param_off(c, layer, P_INP_W), G + param_off(c, layer, P_INP_B), N, gs);
@@ -1392,8 +1413,16 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
         tc.gn_w = lp.p[P_TF_GN_W]; tc.gn_b = lp.p[P_TF_GN_B];
         tc.h1 = h1; tc.h2 = h2; tc.h4 = h4; tc.h5 = h5; tc.g5 = g5; tc.g3 = g3; tc.g2 = g2; tc.g1 = g1;
         tc.dgn_w = G + param_off(c, layer, P_TF_GN_W); tc.dgn_b = G + param_off(c, layer, P_TF_GN_B);
+        tc.part = gb_part_floats(c) >= (size_t)nseq * 2 * FFN ? gb_part(c, ws) : nullptr;
         tc.nseq = nseq; tc.T = c.T; tc.FFN = FFN; tc.groups = c.t_groups;
         if ((e = tc_chain_launch(tc, CG, c.t_ks, true, st))) return e;
+        if (tc.part) {
+            AffSegs sg;
+            sg.n = 2;
+            sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.off[1] = param_off(c, layer, P_TF_GN_B);
+            sg.cnt[0] = sg.cnt[1] = FFN;
+            if ((e = affine_reduce_launch(tc.part, nseq, sg, G, st))) return e;
+        }
     } else {
         for (int k = 0; k < 3; ++k) {
             if ((e = gb_wprep<T>(lp.p[convW[k]], cw[k], WP_CONV_FWD, c.t_groups, c.t_ks, CG, CG, Mp, Kp, st))) return e;
@@ -1419,7 +1448,7 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
         if ((e = gb_gemm<T>(with(tconv(g2, cwT[0], nullptr, g1), nullptr, a1), st))) return e;
     }
     if ((e = gb_gemm<T>(gb_lin(g1, FFN, w1T, nullptr, du, H, N, H, FFN), st))) return e;
-    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_TF_LN_W], dy, dx, G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), N, H, st))) return e;
+    if ((e = gb_ln_bwd<T>(du, x, stats, lp.p[P_TF_LN_W], dy, dx, G + param_off(c, layer, P_TF_LN_W), G + param_off(c, layer, P_TF_LN_B), N, H, st, gb_part(c, ws), gb_part_floats(c)))) return e;
     // weight gradients (every operand above is still in place: nothing was overwritten)
     const hipStream_t gs = side_fork(sd, st);
     if ((e = gb_wgrad_dense(c, ws, dy, H, H, h5, FFN, FFN, G + param_off(c, layer, P_TF_W2), G + param_off(c, layer, P_TF_B2), N, gs))) return e;

@@ -20,6 +20,7 @@ struct TChain {
     void* g1;
     float* dgn_w;  // accumulated
     float* dgn_b;
+    float* part;   // [nseq][2 FFN] per-sequence rows of the two (affine_reduce folds them), or null: atomics
     int nseq, T, FFN, groups;
 };
 
@@ -36,4 +37,4 @@ struct nbss_cfg;
 bool fconv_g_takes(const nbss_cfg& c);
 size_t fconv_g_wfrag_elems();
 int fconv_g_bwd(const nbss_cfg& c, const float* P, float* G, int layer, int which, const void* x, const void* dy, void* dx, void* dv, float* stats, void* wf,
-                void* wd, hipStream_t st);
+                void* wd, float* part, hipStream_t st);

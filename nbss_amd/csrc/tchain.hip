@@ -382,7 +382,9 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     }
     lds_barrier();
     img_out(p.g3);
-    if (tid < CG) atomicAdd(p.dgn_w + (size_t)g * CG + tid, cgs[tid]);
+    if (p.part) {  // (4 128 workgroups on 768 addresses: rows + a reduce instead of same-address atomic chains)
+        if (tid < 2 * CG) p.part[(size_t)seq * 2 * FFN + (tid < CG ? 0 : FFN - CG) + (size_t)g * CG + tid] = cgs[tid];
+    } else if (tid < CG) atomicAdd(p.dgn_w + (size_t)g * CG + tid, cgs[tid]);
     else if (tid < 2 * CG) atomicAdd(p.dgn_b + (size_t)g * CG + tid - CG, cgs[tid]);
     w_fetch(p.wd[0]);
     conv();  // dh2
