@@ -258,7 +258,8 @@ def dry_run(args, rank, world):
 
 def large_train_rate(lib, dev, batch=4, steps=2):
     """SpatialNet-large (12 layers, 192 / 384 / squeeze 16: the "for large" comments of configs/SpatialNet.yaml), same 4-s 6-ch input, full bf16
-    train step through the geometry-generic backward (csrc/gbwd.hip: unfused, one tensor pass per operation — a correct path, not a tuned one)"""
+    train step through the geometry-generic path (csrc/gbwd.hip sequencing gemm_g.hip's tile GEMM, tchain.hip's conv chain, fconv_g.hip's F-conv
+    backward, the generic attention and wgrad.hip)"""
     from models.arch.SpatialNet import SpatialNet
     from nbss_amd._lib import NBSS_BF16
     from nbss_amd.engine import SpatialNetEngine, TrainStep
@@ -438,6 +439,9 @@ def main():
                 torch.cuda.synchronize()
                 sweep[str(b2)] = round(b2 * 3 / (time.perf_counter() - t1), 1)
             large = large_train_rate(lib, dev)
+            if large and "value" in large:  # ... and at twice the batch (one more ~0.3 s of steps)
+                l8 = large_train_rate(lib, dev, batch=8, steps=2)
+                large["batch8"] = {k: l8.get(k) for k in ("value", "ms_per_step", "error") if k in l8}
             base = cpu_baseline()
         line = {
             "metric": "utterances/sec (4 s, 6ch, 129 freqs) SpatialNet bf16 train at 1/2/4/8 MI355X",

@@ -1130,6 +1130,7 @@ static int gb_silu_bwd(const void* a, const void* gin, void* gout, long n, hipSt
     return NBSS_CHECK_LAUNCH();
 }
 
+int wgrad_dense_g(const void* A, int lda, int M, const void* B, int ldb, int K, float* dW, float* dbias, long Ntok, float* part, hipStream_t st);
 static void gb_wgrad_base(WgradArgs& a, const nbss_cfg& c, void* ws, long Ntok) {
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
@@ -1142,6 +1143,10 @@ static void gb_wgrad_base(WgradArgs& a, const nbss_cfg& c, void* ws, long Ntok) 
 static int gb_wgrad_dense(const nbss_cfg& c, void* ws, const void* A, int lda, int M, const void* B, int ldb, int K, float* dW, float* dbias, long Ntok,
                           hipStream_t st) {
     const size_t esz = c.dtype == NBSS_BF16 ? 2 : 4;
+    if (c.dtype == NBSS_BF16) {  // 192 x 96 output tiles with fragment reuse (wgrad_g.hip) where the shape allows
+        const int e = wgrad_dense_g(A, lda, M, B, ldb, K, dW, dbias, Ntok, (float*)((char*)ws + ws_wgpart_offset(c)), st);
+        if (e != NBSS_EUNSUPPORTED) return e;
+    }
     int mt = 112 / cdiv(K, 16);
     if (mt > 12) mt = 12;
     while (mt > 1 && cdiv(mt * 16, 64) + cdiv(K, 64) > 7) --mt;
