@@ -1,4 +1,4 @@
-"""The tile weight gradient of the dense maps of the geometry-generic path (nbss_amd/csrc/wgrad_g.hip, opt-in: NBSS_WGRAD_TILE=1, read once per process)
+"""The tile weight gradient of the dense maps of the geometry-generic path (nbss_amd/csrc/wgrad_g.hip; NBSS_WGRAD_TILE=0 selects the other path, read once per process)
 against the column-slice path of wgrad.hip it replaces: the attention block's and the T-ConvFFN block's parameter gradients of SpatialNet-large from two
 child processes, a token count that is not a multiple of the 32-token chunk."""
 import os
