@@ -85,9 +85,9 @@ NBSS_DEV float dsilu_f(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 
-// SiLU and its derivative through ONE v_exp_f32 + ONE v_rcp_f32 (1 ulp) instead of __expf + an IEEE division (~10 more full-rate instructions
-// per element): for kernels whose time is these element passes (tchain.hip: 8 of them per token and channel, VALU-bound on the division)
-// and whose results are rounded to bf16 anyway.  silu_pair() shares the sigmoid between value and derivative.
+// SiLU and its derivative with the sigmoid written as ONE v_exp_f32 + ONE v_rcp_f32, and silu_pair() sharing it between value and derivative.
+// (The library is built with -ffast-math, under which silu_f / dsilu_f above compile to the same v_exp + v_rcp mix — checked on the ISA of
+// tchain.hip: 530 v_rcp, 528 v_exp either way — so these only make the instruction choice independent of the build flags.)
 NBSS_DEV float fast_rcp(float x) {
 #ifdef NBSS_EMU
     return 1.0f / x;
@@ -117,6 +117,15 @@ NBSS_DEV void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt/expcnt untouched
     __builtin_amdgcn_s_barrier();
 #endif
+}
+
+// the same value, but unknown to the optimiser: expressions built from it are not recognised as common with earlier ones (a value recomputed
+// in a late phase from registers that are live anyway, instead of 48 results kept alive — spilled — since an early phase)
+NBSS_DEV float opaque(float x) {
+#ifndef NBSS_EMU
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
 }
 
 // nothing is scheduled across this point (keeps independent register-hungry sections — e.g. the two strips of a LayerNorm — from being

@@ -331,14 +331,14 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
     lds_barrier();
     w_stash();
     {
+        mean = opaque(mean);  // (xhat is recomputed here: the forward's values must not be kept alive across three conv phases)
+        rstd = opaque(rstd);
         float s1 = 0.f, s2 = 0.f;
-        float dwc[OT][4], dbc[OT][4];
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
             const float (&gm)[4] = gmv[i];
             const float (&bt)[4] = btv[i];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dwc[i][r] = dbc[i][r] = 0.f;
+            float dwc[4] = {0.f, 0.f, 0.f, 0.f}, dbc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = frame(j) < T;
@@ -347,16 +347,27 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
                 for (int r = 0; r < 4; ++r) {
                     const float xh = (a[r] - mean) * rstd;
                     const float d4 = keep_if(ok, round_to(acc[j][i][r], img) * dsilu_fast(xh * gm[r] + bt[r]));
-                    dwc[i][r] += d4 * xh;
-                    dbc[i][r] += d4;
+                    dwc[r] += d4 * xh;
+                    dbc[r] += d4;
                     s1 += d4 * gm[r];
                     s2 += d4 * gm[r] * xh;
                     acc[j][i][r] = d4 * gm[r];
                 }
                 sched_fence();
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // affine gradients: sum over the 16 frames of the lane row, then one LDS atomic per (wave, channel)
+                const float sw = row_sum16(dwc[r]), sb = row_sum16(dbc[r]);
+                if (l15 == 0) {
+                    atomicAdd(&cgs[16 * i + 4 * g4 + r], sw);
+                    atomicAdd(&cgs[CG + 16 * i + 4 * g4 + r], sb);
+                }
+            }
+            sched_fence();
         }
         wg_sum2(s1, s2);
+        mean = opaque(mean);
+        rstd = opaque(rstd);
         const float m1 = s1 * invM, m2 = s2 * invM;
 #pragma unroll
         for (int i = 0; i < OT; ++i) {
@@ -369,14 +380,6 @@ __global__ __launch_bounds__(TC_THREADS, 2) void tc_chain_kernel(TChain p) {
                 for (int r = 0; r < 4; ++r) gq[r] = keep_if(ok, rstd * (acc[j][i][r] - m1 - (a[r] - mean) * rstd * m2));
                 put_img(j, i, gq);
                 sched_fence();
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {  // affine gradients: sum over the 16 frames of the lane row, then one LDS atomic per (wave, channel)
-                const float sw = row_sum16(dwc[i][r]), sb = row_sum16(dbc[i][r]);
-                if (l15 == 0) {
-                    atomicAdd(&cgs[16 * i + 4 * g4 + r], sw);
-                    atomicAdd(&cgs[CG + 16 * i + 4 * g4 + r], sb);
-                }
             }
         }
     }
