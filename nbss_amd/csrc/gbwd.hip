@@ -33,7 +33,7 @@ struct WPrep {
     int mode, groups, taps, Mg, Kv, Mp, Kp;  // Mg x Kv valid per (group, tap)
 };
 template <class T>
-__global__ void gb_wprep_kernel(WPrep p) {
+NBSS_DEV void gb_wprep_body(const WPrep& p) {
     const long total = (long)p.groups * p.taps * p.Mp * p.Kp;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int k = (int)(e % p.Kp);
@@ -56,6 +56,16 @@ __global__ void gb_wprep_kernel(WPrep p) {
     }
 }
 
+
+template <class T>
+__global__ void gb_wprep_kernel(WPrep p) { gb_wprep_body<T>(p); }
+// several re-lays in one launch (blockIdx.y = descriptor): a block backward re-laid its 3 - 6 weights with one 5-us launch each, 1 060 per large step
+#define GB_WPREP_MAX 6
+struct WPrepMulti {
+    WPrep d[GB_WPREP_MAX];
+};
+template <class T>
+__global__ void gb_wprep_multi_kernel(WPrepMulti m) { gb_wprep_body<T>(m.d[blockIdx.y]); }
 
 // epilogue of one row: 4 output tiles in C layout (lane: outputs 16 i + 4 g4 + r of its row)
 template <class T>
@@ -1047,6 +1057,21 @@ static int gb_wprep(const float* src, void* dst, int mode, int groups, int taps,
     NBSS_LAUNCH((gb_wprep_kernel<T>), dim3(gb_blocks((long)groups * taps * Mp * Kp, 256)), dim3(256), 0, st, p);
     return NBSS_CHECK_LAUNCH();
 }
+template <class T>
+struct WPrepBatch {
+    WPrepMulti m;
+    int n = 0;
+    long most = 0;
+    void add(const float* src, void* dst, int mode, int groups, int taps, int Mg, int Kv, int Mp, int Kp) {
+        m.d[n++] = {src, dst, mode, groups, taps, Mg, Kv, Mp, Kp};
+        const long el = (long)groups * taps * Mp * Kp;
+        most = el > most ? el : most;
+    }
+    int launch(hipStream_t st) {
+        NBSS_LAUNCH((gb_wprep_multi_kernel<T>), dim3(gb_blocks(most, 256), n), dim3(256), 0, st, m);
+        return NBSS_CHECK_LAUNCH();
+    }
+};
 static int pad16(int v) { return (v + 15) & ~15; }
 static int pad32(int v) { return (v + 31) & ~31; }
 static int pad8(int v) { return (v + 7) & ~7; }
@@ -1250,12 +1275,16 @@ static int gb_full_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer,
     void* w_lgT = ar.take((size_t)SQ * Fp16 * Fp32 * sizeof(T));
     if (!w_lgT) return NBSS_EUNSUPPORTED;
     int e;
-    if ((e = gb_wprep<T>(lp.p[P_SQ_W], w_sq, WP_LIN_FWD, 1, 1, SQ, H, pad16(SQ), pad32(H), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_SQ_W], w_sqT, WP_LIN_DGRAD, 1, 1, H, SQ, pad16(H), pad32(SQ), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_USQ_W], w_us, WP_LIN_FWD, 1, 1, H, SQ, pad16(H), pad32(SQ), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_USQ_W], w_usT, WP_LIN_DGRAD, 1, 1, SQ, H, pad16(SQ), pad32(H), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_FULL_W], w_lg, WP_LG_FWD, SQ, 1, F, F, Fp16, Fp32, st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_FULL_W], w_lgT, WP_LG_DGRAD, SQ, 1, F, F, Fp16, Fp32, st))) return e;
+    {
+        WPrepBatch<T> wb;
+        wb.add(lp.p[P_SQ_W], w_sq, WP_LIN_FWD, 1, 1, SQ, H, pad16(SQ), pad32(H));
+        wb.add(lp.p[P_SQ_W], w_sqT, WP_LIN_DGRAD, 1, 1, H, SQ, pad16(H), pad32(SQ));
+        wb.add(lp.p[P_USQ_W], w_us, WP_LIN_FWD, 1, 1, H, SQ, pad16(H), pad32(SQ));
+        wb.add(lp.p[P_USQ_W], w_usT, WP_LIN_DGRAD, 1, 1, SQ, H, pad16(SQ), pad32(H));
+        wb.add(lp.p[P_FULL_W], w_lg, WP_LG_FWD, SQ, 1, F, F, Fp16, Fp32);
+        wb.add(lp.p[P_FULL_W], w_lgT, WP_LG_DGRAD, SQ, 1, F, F, Fp16, Fp32);
+        if ((e = wb.launch(st))) return e;
+    }
     // forward chain
     if ((e = gb_ln_fwd<T>(x, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B], u, stats, N, H, st))) return e;
     {
@@ -1341,9 +1370,13 @@ static int gb_mhsa_bwd_t(const nbss_cfg& c, const float* P, float* G, int layer,
     void* w_outT = ar.take((size_t)pad16(H) * pad32(H) * sizeof(T));
     if (!w_outT) return NBSS_EUNSUPPORTED;
     int e;
-    if ((e = gb_wprep<T>(lp.p[P_INP_W], w_in, WP_LIN_FWD, 1, 1, 3 * H, H, pad16(3 * H), pad32(H), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_INP_W], w_inT, WP_LIN_DGRAD, 1, 1, H, 3 * H, pad16(H), pad32(3 * H), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_OUTP_W], w_outT, WP_LIN_DGRAD, 1, 1, H, H, pad16(H), pad32(H), st))) return e;
+    {
+        WPrepBatch<T> wb;
+        wb.add(lp.p[P_INP_W], w_in, WP_LIN_FWD, 1, 1, 3 * H, H, pad16(3 * H), pad32(H));
+        wb.add(lp.p[P_INP_W], w_inT, WP_LIN_DGRAD, 1, 1, H, 3 * H, pad16(H), pad32(3 * H));
+        wb.add(lp.p[P_OUTP_W], w_outT, WP_LIN_DGRAD, 1, 1, H, H, pad16(H), pad32(H));
+        if ((e = wb.launch(st))) return e;
+    }
     if ((e = gb_ln_fwd<T>(x, lp.p[P_MH_LN_W], lp.p[P_MH_LN_B], u, stats, N, H, st))) return e;
     if ((e = gb_gemm<T>(gb_lin(u, H, w_in, lp.p[P_INP_B], qkv, 3 * H, N, 3 * H, H), st))) return e;
     if ((e = gb_gemm<T>(gb_lin(dy, H, w_outT, nullptr, dO, H, N, H, H), st))) return e;  // dO = dy Wo
@@ -1386,9 +1419,13 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
     if (!cwT[2]) return NBSS_EUNSUPPORTED;
     const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convB[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
     int e;
-    if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1T, WP_LIN_DGRAD, 1, 1, H, FFN, pad16(H), pad32(FFN), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_TF_W2], w2T, WP_LIN_DGRAD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
+    {
+        WPrepBatch<T> wb;
+        wb.add(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H));
+        wb.add(lp.p[P_TF_W1], w1T, WP_LIN_DGRAD, 1, 1, H, FFN, pad16(H), pad32(FFN));
+        wb.add(lp.p[P_TF_W2], w2T, WP_LIN_DGRAD, 1, 1, FFN, H, pad16(FFN), pad32(H));
+        if ((e = wb.launch(st))) return e;
+    }
     auto with = [](TapGemm p, void* y2, const void* dact) {  // second output SiLU(Y) / result times SiLU'(dact): the activation passes ride along
         p.Y2 = y2;
         p.Dact = dact;
@@ -1490,8 +1527,12 @@ int gb_tconvffn_fwd(const nbss_cfg& c, const float* P, int layer, const void* x,
     for (int k = 0; k < 3; ++k) cw[k] = ar.take(tc_wfrag_elems(c.t_groups, CG, c.t_ks) * sizeof(T));
     if (!cw[2]) return NBSS_EUNSUPPORTED;
     int e;
-    if ((e = gb_wprep<T>(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H), st))) return e;
-    if ((e = gb_wprep<T>(lp.p[P_TF_W2], w2, WP_LIN_FWD, 1, 1, H, FFN, pad16(H), pad32(FFN), st))) return e;
+    {
+        WPrepBatch<T> wb;
+        wb.add(lp.p[P_TF_W1], w1, WP_LIN_FWD, 1, 1, FFN, H, pad16(FFN), pad32(H));
+        wb.add(lp.p[P_TF_W2], w2, WP_LIN_FWD, 1, 1, H, FFN, pad16(H), pad32(FFN));
+        if ((e = wb.launch(st))) return e;
+    }
     const float* wsrc[3] = {lp.p[P_TF_C1W], lp.p[P_TF_C2W], lp.p[P_TF_C3W]};
     void* none[3] = {nullptr, nullptr, nullptr};
     if ((e = tc_wprep(wsrc, cw, none, c.t_groups, CG, c.t_ks, st))) return e;
