@@ -56,3 +56,21 @@ def test_fconv_slab_kernel_vs_unfused_path(tmp_path):
     # the same roundings in the same places: equal up to the order of the fp32 sums
     assert float((dx - dx0).norm() / dx0.norm()) < 1e-4
     assert float((G - G0).norm() / G0.norm()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 2, 3), (1, 1, 17), (1, 2, 256), (2, 1, 255)], ids=lambda v: "x".join(map(str, v)))
+def test_conv_chain_kernel_edge_shapes(tmp_path, shape):
+    """single frames, sequences shorter than a conv's reach, one frame past a 16-row tile, the longest sequence the kernel takes and one less"""
+    (dx, G), (dx0, G0) = _pair(tmp_path, "tconvffn", "NBSS_TCHAIN_OFF", *shape)
+    assert torch.isfinite(dx).all() and torch.isfinite(G).all()
+    assert float((dx - dx0).norm() / dx0.norm()) < 8e-3
+    assert float((G - G0).norm() / G0.norm()) < 1.2e-2
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 2, 2), (2, 5, 1), (1, 17, 3), (1, 144, 2)], ids=lambda v: "x".join(map(str, v)))
+def test_fconv_slab_kernel_edge_shapes(tmp_path, shape):
+    """one frequency (every tap but the centre is padding), fewer frequencies than taps, one past a tile, nine full tiles"""
+    (dx, G), (dx0, G0) = _pair(tmp_path, "fconv", "NBSS_FCONVG_OFF", *shape)
+    assert torch.isfinite(dx).all() and torch.isfinite(G).all()
+    assert float((dx - dx0).norm() / dx0.norm()) < 1e-4
+    assert float((G - G0).norm() / max(float(G0.norm()), 1e-30)) < 1e-5
