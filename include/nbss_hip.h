@@ -237,6 +237,14 @@ int nbss_nb_group_batch_norm(int dtype, int B, int F, int T, int C, const void* 
                              void* stream);
 /* softmax(q k^T / sqrt(dh)) v per (sequence, head): qkv [nseq][T][3H] (q | k | v; head h at columns h dh), o [nseq][T][H]; T <= 256, dh in {24, 48} */
 int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, void* o, void* stream);
+/* the narrow-band conformer NBC (reference models/arch/NBC.py): Transformer-XL relative-position attention (NBC.py:106-143) —
+ *   softmax(((q + u) k^T + (q + v) P[i - j]) * scale) v per (sequence, head); pos [2T - 1][H] = pos_proj of the sinusoid table for the offsets
+ *   -(T - 1) .. T - 1 (stream dtype), u_bias / v_bias [heads][dh] fp32, scale = 1 / sqrt(d_model) in the reference; T <= 256, dh in {24, 48}
+ * — and the GroupNorm(groups, C) + optional SiLU between the convolutions of its feed-forward (NBC.py:195-203; statistics over (C / groups) x T per
+ * sequence, eps 1e-5): x, y [nseq][T][C]. */
+int nbss_nb_attention_relpos_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias,
+                                 float scale, void* o, void* stream);
+int nbss_nb_group_norm(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* gamma, const float* beta, int act_out, void* y, void* stream);
 
 /* ---- the same building blocks for TRAINING (autograd of the reference's torch.nn NBC2: NBC2.py:152-238; sequenced by nbss_amd/nbc2.py) ---------------
  * conv_t_train: conv_t without fused input / output activations, plus an optional second output y_silu = SiLU(y) (pre-activation and activation of a

@@ -2,14 +2,20 @@
 NBC.py:73-293): same constructor, same forward [B,F,T,dim_input] -> [B,F,T,dim_output], same state_dict keys
 (`encoder`, `sa_layers.N.self_attn.{query,key,value,pos,out}_proj / u_bias / v_bias / rel_pos.pe`, `linear1/2`, `norm1/2`,
 `conv.*`, `decoder`).  The position term of the scores is computed as one [T, 2T-1] product per head followed by a gather along
-the relative offset (the reference materialises a [T, T, heads, d] tensor).  Plain PyTorch."""
+the relative offset (the reference materialises a [T, T, heads, d] tensor).  Plain PyTorch; inference on a HIP
+device can take the native path of nbss_amd/nbc.py (see NBC.forward)."""
 import math
+import os
+import weakref
 from typing import Callable, Optional, Tuple
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
+
+
+_NATIVE = weakref.WeakKeyDictionary()  # NBC module -> nbss_amd.nbc.NativeNBC (or None)
 
 
 class _GroupNorm(nn.GroupNorm):
@@ -138,8 +144,27 @@ class NBC(nn.Module):
                      conv_mid_norm=inner_conv_mid_norm) for _ in range(n_layers)])
         self.decoder = nn.ConvTranspose1d(hidden_size, dim_output, kernel_size=encoder_kernel_size, stride=1)
 
+    def _native(self):
+        """nbss_amd.nbc.NativeNBC of this module when the HIP library is there and the configuration is one its kernels take, else None"""
+        if self not in _NATIVE:
+            runner = None
+            try:
+                from nbss_amd._lib import hip
+                from nbss_amd.nbc import NativeNBC, supported
+                if supported(self) is None:
+                    runner = NativeNBC(self, hip())
+            except Exception:  # (no library / no HIP runtime: torch.nn below)
+                runner = None
+            _NATIVE[self] = runner
+        return _NATIVE[self]
+
     def forward(self, x: Tensor) -> Tensor:
         B, Fq, T, _ = x.shape
+        # inference on a HIP device (eval mode: the dropouts of the block are inactive; no autograd): the native forward over the nbss_nb_* building blocks
+        # — opt-in (NBSS_NBC_NATIVE=1) until it has run on the device: it was written after round 4's GPU budget, tests/test_nbc_native.py runs it on the emulator
+        if (x.is_cuda and not self.training and not torch.is_grad_enabled() and 4 <= T <= 256 and x.dtype in (torch.float32, torch.bfloat16)
+                and os.environ.get("NBSS_NBC_NATIVE") == "1" and self._native() is not None):
+            return self._native().forward(x.contiguous())
         h = self.encoder(x.reshape(B * Fq, T, -1).transpose(1, 2)).transpose(1, 2)
         for block in self.sa_layers:
             h, _ = block(h)

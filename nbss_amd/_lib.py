@@ -83,6 +83,8 @@ SIGNATURES = {
     "nbss_nb_layernorm": (_I, [_I, C.c_int64, _I, _P, _P, _P, _P, _P, _P]),
     "nbss_nb_group_batch_norm": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, C.c_float, _I, _P, _P]),
     "nbss_nb_attention_fwd": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P]),
+    "nbss_nb_attention_relpos_fwd": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P, _P, C.c_float, _P, _P]),
+    "nbss_nb_group_norm": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     "nbss_nb_bwd_ws_bytes": (C.c_int64, [_I, _I, _I, _I]),
     "nbss_nb_conv_t_train": (_I, [_I, C.c_int64, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nbss_nb_conv_t_bwd": (_I, [_I, C.c_int64, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

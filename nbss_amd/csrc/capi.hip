@@ -48,6 +48,9 @@ int nb_conv_t_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int
 int nb_layernorm_impl(int dtype, long rows, int C, const void* x, const float* gamma, const float* beta, void* y, float* stats, hipStream_t st);
 int nb_gbn_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, void* y, hipStream_t st);
 int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st);
+int nb_attention_relpos_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o,
+                                 hipStream_t st);
+int nb_group_norm_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, hipStream_t st);
 size_t nb_bwd_ws_bytes_impl(int M, int K, int groups, int taps);
 int nb_conv_t_train_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
                          void* y2, const void* residual, void* ws, hipStream_t st);
@@ -512,6 +515,15 @@ int nbss_nb_group_batch_norm(int dtype, int B, int F, int T, int C, const void* 
 int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, void* o, void* stream) {
     if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !o) return NBSS_EINVAL;
     return nb_attention_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, o, (hipStream_t)stream);
+}
+int nbss_nb_attention_relpos_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias, float scale,
+                                 void* o, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !pos || !u_bias || !v_bias || !o) return NBSS_EINVAL;
+    return nb_attention_relpos_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, pos, u_bias, v_bias, scale, o, (hipStream_t)stream);
+}
+int nbss_nb_group_norm(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* gamma, const float* beta, int act_out, void* y, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq * (int64_t)(groups > 0 ? groups : 1) >= (1LL << 31) || T <= 0 || C <= 0 || !x || !y || !gamma || !beta) return NBSS_EINVAL;
+    return nb_group_norm_impl(dtype, (long)nseq, T, C, groups, x, gamma, beta, act_out, y, (hipStream_t)stream);
 }
 
 int64_t nbss_nb_bwd_ws_bytes(int Cout, int Cin, int groups, int taps) {

@@ -562,7 +562,7 @@ __global__ void gb_pad_cols_kernel(const float* __restrict__ src, T* __restrict_
 // one workgroup per (sequence, group); thread = (frame lane, channel)
 template <class T>
 __global__ __launch_bounds__(GB_THREADS) void gb_gn_fwd_kernel(const T* __restrict__ a, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               T* __restrict__ h, float* __restrict__ stats, int Tn, int C, int CG) {
+                                                               T* __restrict__ h, float* __restrict__ stats, int Tn, int C, int CG, int act = 1) {
     NBSS_LDS(smem);
     float* red = reinterpret_cast<float*>(smem);  // [8]
     const int G = C / CG, seq = blockIdx.x / G, g = blockIdx.x % G;
@@ -587,14 +587,15 @@ __global__ __launch_bounds__(GB_THREADS) void gb_gn_fwd_kernel(const T* __restri
         q += d * d;
     }
     const float rstd = rsqrtf(block_sum(q) / M + 1e-5f);
-    if (threadIdx.x == 0) {
+    if (stats && threadIdx.x == 0) {
         stats[2 * blockIdx.x] = mean;
         stats[2 * blockIdx.x + 1] = rstd;
     }
     for (int e = threadIdx.x; e < M; e += GB_THREADS) {
         const int c = e % CG;
         const size_t o = (size_t)(e / CG) * C + c;
-        store1(hb + o, silu_f((load1(ab + o) - mean) * rstd * gamma[g * CG + c] + beta[g * CG + c]));
+        const float v = (load1(ab + o) - mean) * rstd * gamma[g * CG + c] + beta[g * CG + c];
+        store1(hb + o, act ? silu_f(v) : v);
     }
 }
 // in: dh = gradient w.r.t. h = SiLU(a4), a4 = xhat gamma + beta; out (in place): gradient w.r.t. the GroupNorm input a; dgamma / dbeta accumulate
@@ -1021,6 +1022,135 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_k_kernel(const T* __restri
                     store4(dqkv + nk * ld + H + head * DH + d, kacc[mt][0], kacc[mt][1], kacc[mt][2], kacc[mt][3]);
                     store4(dqkv + nk * ld + 2 * H + head * DH + d, vacc[mt][0], vacc[mt][1], vacc[mt][2], vacc[mt][3]);
                 }
+            }
+        }
+    }
+}
+
+// Attention forward with Transformer-XL relative positions (the narrow-band conformer NBC: models/arch/NBC.py:106-143 in the reference):
+//   score(i, j) = ((q_i + u) . k_j + (q_i + v) . P[i - j + T - 1]) * scale,   P = pos_proj(sinusoid table) [2T - 1][H], u / v per head
+// One workgroup per (sequence, head): K, V and the head's P rows in LDS.  The position term of a (16 queries x 16 keys) tile needs the 31 offsets
+// i - j; they are two MFMA tiles M[r'][i] = P[rb + r'] . (q_i + v) (queries stay the N dimension), written to 2 KB of wave-private LDS and read back
+// along the diagonal r' = i - j + 15 (the reference materialises the whole [T][2T - 1] product and gathers).  T <= 256, DH in {24, 48}.
+template <class T, int DH>
+__global__ __launch_bounds__(GB_THREADS) void gb_attn_relpos_kernel(const T* __restrict__ qkv, const T* __restrict__ pos, const float* __restrict__ ub,
+                                                                    const float* __restrict__ vb, T* __restrict__ O, float scale, int Tn, int H, int heads) {
+    constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NTM = GA_TMAX / 16;
+    NBSS_LDS(smem);
+    const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32), NR = 2 * Tn - 1, RP = 32 * cdiv(NR + 32, 32);
+    T* Ks = reinterpret_cast<T*>(smem);   // [TP][DH]
+    T* Vs = Ks + (size_t)TP * DH;         // [TP][DH]
+    T* Ps = Vs + (size_t)TP * DH;         // [RP][DH] rows 0 .. 2T - 2 = offsets -(T - 1) .. T - 1, zero rows behind
+    float* Mb = reinterpret_cast<float*>(Ps + (size_t)RP * DH) + wave_id() * 32 * 16;  // [32 offsets][16 queries] per wave
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)seq * Tn;
+    const int ld = 3 * H;
+    ga_stage<T, DH>(Ks, qkv + n0 * ld + H + head * DH, ld, Tn, TP);
+    ga_stage<T, DH>(Vs, qkv + n0 * ld + 2 * H + head * DH, ld, Tn, TP);
+    ga_stage<T, DH>(Ps, pos + head * DH, H, NR, RP);
+    __syncthreads();
+    for (int qt = w; qt < NT; qt += GB_THREADS / 64) {
+        const int q = qt * 16 + l15;
+        const bool qv = q < Tn;
+        const size_t nq = n0 + (qv ? q : 0);
+        Frag<T> qc[KS], qp[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = 32 * ks + 8 * g4;
+            frag_zero(qc[ks]);
+            frag_zero(qp[ks]);
+            if (qv && d0 < DH) {
+                float qf[8];
+                load8(qkv + nq * ld + head * DH + d0, qf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    frag_set(qc[ks], j, qf[j] + ub[head * DH + d0 + j]);
+                    frag_set(qp[ks], j, qf[j] + vb[head * DH + d0 + j]);
+                }
+            }
+        }
+        f32x4 st[NTM];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt) {
+            st[jt] = F32X4_ZERO;
+            if (jt < NT) {
+                // offsets of this tile pair: r' = 0 .. 31 <-> P row rb + r', rb = (16 qt - 16 jt - 15) + (T - 1)
+                const int rb = 16 * qt - 16 * jt - 15 + Tn - 1;
+                f32x4 m0 = F32X4_ZERO, m1 = F32X4_ZERO;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d0 = 32 * ks + 8 * g4;
+                    Frag<T> kf, p0, p1;
+                    frag_zero(kf); frag_zero(p0); frag_zero(p1);
+                    if (d0 < DH) {
+                        int r0 = rb + l15, r1 = rb + 16 + l15;  // (rows outside the table belong to masked keys: any valid row)
+                        r0 = r0 < 0 ? 0 : r0 >= RP ? RP - 1 : r0;
+                        r1 = r1 < 0 ? 0 : r1 >= RP ? RP - 1 : r1;
+                        frag_load(kf, Ks + (size_t)(16 * jt + l15) * DH + d0);
+                        frag_load(p0, Ps + (size_t)r0 * DH + d0);
+                        frag_load(p1, Ps + (size_t)r1 * DH + d0);
+                    }
+                    st[jt] = mma(kf, qc[ks], st[jt]);
+                    m0 = mma(p0, qp[ks], m0);
+                    m1 = mma(p1, qp[ks], m1);
+                }
+                wave_lds_sync();  // (the previous tile's reads of Mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Mb[(4 * g4 + r) * 16 + l15] = m0[r];
+                    Mb[(16 + 4 * g4 + r) * 16 + l15] = m1[r];
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kv = 16 * jt + 4 * g4 + r < Tn;
+                    const float pt = Mb[(l15 - (4 * g4 + r) + 15) * 16 + l15];
+                    st[jt][r] = kv ? (st[jt][r] + pt) * scale : -3.0e38f;
+                    mx = fmaxf(mx, st[jt][r]);
+                }
+            }
+        }
+        mx = wave_max16(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kv = jt < NT && 16 * jt + 4 * g4 + r < Tn;
+                st[jt][r] = kv ? __expf(st[jt][r] - mx) : 0.f;
+                sum += st[jt][r];
+            }
+        sum = wave_sum16(sum);
+        const float inv = 1.0f / sum;
+        f32x4 oacc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) oacc[mt] = F32X4_ZERO;
+#pragma unroll
+        for (int kk = 0; kk < NTM / 2; ++kk) {
+            if (2 * kk < NT) {
+                f32x4 a0, a1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a0[r] = st[2 * kk][r] * inv;
+                    a1[r] = st[2 * kk + 1][r] * inv;
+                }
+                Frag<T> pf;
+                frag_from_c2(pf, a0, a1);
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) {
+                    Frag<T> vt;
+                    ga_frag_t<T, DH>(vt, Vs, 32 * kk, mt);
+                    oacc[mt] = mma(vt, pf, oacc[mt]);
+                }
+            }
+        }
+        if (qv) {
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int d = 16 * mt + 4 * g4;
+                if (d < DH) store4(O + nq * H + head * DH + d, oacc[mt][0], oacc[mt][1], oacc[mt][2], oacc[mt][3]);
             }
         }
     }
@@ -1477,7 +1607,7 @@ static int gb_tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* G, int la
         if ((e = gb_gemm<T>(with(gb_lin(u, H, w1, lp.p[P_TF_B1], a1, FFN, N, FFN, H), h1, nullptr), st))) return e;
         if ((e = gb_gemm<T>(with(tconv(h1, cw[0], lp.p[convB[0]], a2), h2, nullptr), st))) return e;
         if ((e = gb_gemm<T>(tconv(h2, cw[1], lp.p[convB[1]], a3), st))) return e;
-        NBSS_LAUNCH((gb_gn_fwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), 8 * sizeof(float), st, (const T*)a3, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)h4, gstats, c.T, FFN, CG);
+        NBSS_LAUNCH((gb_gn_fwd_kernel<T>), dim3(nseq * c.t_groups), dim3(GB_THREADS), 8 * sizeof(float), st, (const T*)a3, lp.p[P_TF_GN_W], lp.p[P_TF_GN_B], (T*)h4, gstats, c.T, FFN, CG, 1);
         if ((e = NBSS_CHECK_LAUNCH())) return e;
         if ((e = gb_gemm<T>(with(tconv(h4, cw[2], lp.p[convB[2]], a5), h5, nullptr), st))) return e;
         // backward chain: g5 = da5, g3 = da3 (through the GroupNorm), g2 = da2, g1 = da1
@@ -1649,6 +1779,37 @@ int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const 
     if (dh == 48) return dtype == NBSS_BF16 ? nb_attn_fwd<bf16_t, 48>(nseq, Tn, H, heads, qkv, o, st) : nb_attn_fwd<float, 48>(nseq, Tn, H, heads, qkv, o, st);
     if (dh == 24) return dtype == NBSS_BF16 ? nb_attn_fwd<bf16_t, 24>(nseq, Tn, H, heads, qkv, o, st) : nb_attn_fwd<float, 24>(nseq, Tn, H, heads, qkv, o, st);
     return NBSS_EUNSUPPORTED;
+}
+
+template <class T, int DH>
+static int nb_attn_relpos(long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o, hipStream_t st) {
+    const int TP = 32 * cdiv(Tn, 32), RP = 32 * cdiv(2 * Tn - 1 + 32, 32);
+    const size_t lds = (size_t)(2 * TP + RP) * DH * sizeof(T) + (size_t)(GB_THREADS / 64) * 32 * 16 * sizeof(float) + 64;
+    if (Tn > GA_TMAX || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e = NBSS_SET_MAX_LDS((gb_attn_relpos_kernel<T, DH>), lds);
+    if (e) return e;
+    NBSS_LAUNCH((gb_attn_relpos_kernel<T, DH>), dim3((unsigned)nseq, heads), dim3(GB_THREADS), lds, st, (const T*)qkv, (const T*)pos, ub, vb, (T*)o, scale, Tn, H, heads);
+    return NBSS_CHECK_LAUNCH();
+}
+int nb_attention_relpos_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o,
+                                 hipStream_t st) {
+    if (heads <= 0 || H % heads) return NBSS_EINVAL;
+    const int dh = H / heads;
+    if (dh == 48)
+        return dtype == NBSS_BF16 ? nb_attn_relpos<bf16_t, 48>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st) : nb_attn_relpos<float, 48>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st);
+    if (dh == 24)
+        return dtype == NBSS_BF16 ? nb_attn_relpos<bf16_t, 24>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st) : nb_attn_relpos<float, 24>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st);
+    return NBSS_EUNSUPPORTED;
+}
+// GroupNorm(groups, C) over (C / groups x T) per sequence (eps 1e-5), optional SiLU: x, y [nseq][T][C]
+int nb_group_norm_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, hipStream_t st) {
+    if (groups <= 0 || C % groups) return NBSS_EINVAL;
+    const int CG = C / groups;
+    if (dtype == NBSS_BF16)
+        NBSS_LAUNCH((gb_gn_fwd_kernel<bf16_t>), dim3((unsigned)(nseq * groups)), dim3(GB_THREADS), 8 * sizeof(float), st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, (float*)nullptr, Tn, C, CG, act);
+    else
+        NBSS_LAUNCH((gb_gn_fwd_kernel<float>), dim3((unsigned)(nseq * groups)), dim3(GB_THREADS), 8 * sizeof(float), st, (const float*)x, gamma, beta, (float*)y, (float*)nullptr, Tn, C, CG, act);
+    return NBSS_CHECK_LAUNCH();
 }
 
 // ---- training-mode building blocks (nbss_nb_*_train / _bwd: include/nbss_hip.h) ------------------------------------------------------------
