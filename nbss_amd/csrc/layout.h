@@ -216,10 +216,11 @@ NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 #define NBSS_FC_PROW(c) (3 * (c).H + (c).H * ((c).H / (c).f_groups) * (c).f_ks + (c).H)
 NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * ((c.T + 1) / 2) * NBSS_FC_PROW(c) * sizeof(float); }
 // T-ConvFFN backward from saved pre-activations (tconvffn_s.hip: tconvffn_bwd_v_kernel; bf16 stream, small geometry): per sequence one fp32
-// partial row (GroupNorm affine sums 2 FFN + the three conv bias sums 3 FFN) and one bf16 row (the three conv weight gradients)
+// partial row (GroupNorm affine sums 2 FFN + the three conv bias sums 3 FFN + W2's bias sums H) and one bf16 row (the three conv weight
+// gradients + the W2 weight gradient)
 NBSS_HD size_t tc_part_bytes(const nbss_cfg& c) {
     return c.dtype == NBSS_BF16 && c.H == 96 && c.T <= 256
-               ? (size_t)c.B * c.F * (5 * c.FFN * sizeof(float) + (size_t)3 * c.FFN * (c.FFN / c.t_groups) * c.t_ks * 2)
+               ? (size_t)c.B * c.F * ((5 * c.FFN + c.H) * sizeof(float) + ((size_t)3 * c.FFN * (c.FFN / c.t_groups) * c.t_ks + (size_t)c.FFN * c.H) * 2)
                : 0;
 }
 // operand regions ([N][FFN] tensors of the stream dtype) behind the statistics: 8 for the fused backward kernels of the small geometry; the generic

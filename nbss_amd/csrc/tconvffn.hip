@@ -1112,19 +1112,18 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
     return NBSS_CHECK_LAUNCH();
 }
 
-int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5,
-                          void* op_da1, hipStream_t st);
+int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_da1,
+                          hipStream_t st);
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave);
 int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, hipStream_t st);
 
-// bf16 stream, from the pre-activations a training-mode forward saved (tconvffn_s.hip): data gradient + the three T-conv weight gradients in
-// one kernel, the tail + W1 weight gradient in tailw.hip, one fold of the per-sequence partial rows, the W2 weight gradient through wgrad.hip
+// bf16 stream, from the pre-activations a training-mode forward saved (tconvffn_s.hip): data gradient + the three T-conv weight gradients + the
+// W2 weight gradient in one kernel, the tail + W1 weight gradient in tailw.hip, one fold of the per-sequence partial rows
 static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, void* tsave,
                               void* dx, void* ws, hipStream_t st, const Side* sd) {
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const size_t N = (size_t)c.B * c.F * c.T;
     char* base = (char*)ws + ws_align(N * 2 * sizeof(float));
-    void* op_h5 = base + (size_t)3 * ws_align(N * TF_FFN * 2);
     void* op_da1 = base + (size_t)4 * ws_align(N * TF_FFN * 2);
     float* part = (float*)((char*)ws + ws_tcpart_offset(c));
     float* wgpart = (float*)((char*)ws + ws_wgpart_offset(c));
@@ -1132,29 +1131,20 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     hipStream_t gs = st;  // parameter-gradient launches (side.h): everything behind the tail kernel
     {
         ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
-        if ((e = tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_h5, op_da1, st))) return e;
+        if ((e = tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_da1, st))) return e;
         if ((e = tailw_tconvffn(c, lp, packed, layer, x, dy, dx, tconvffn_save_ln_stats(c, tsave), op_da1, wgpart, G, P, st, sd, &gs))) return e;
     }
     const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convBias[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
-    AffSegs sg;  // fp32 rows: GroupNorm affine sums + the three conv bias sums
-    sg.n = 5;
+    AffSegs sg;  // fp32 rows: GroupNorm affine sums + the three conv bias sums + W2's bias sums
+    sg.n = 6;
     sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
     sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
     for (int k = 0; k < 3; ++k) { sg.off[2 + k] = param_off(c, layer, convBias[k]); sg.cnt[2 + k] = TF_FFN; }
+    sg.off[5] = param_off(c, layer, P_TF_B2); sg.cnt[5] = TF_H;
     if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, gs))) return e;
-    const long long woffs[3] = {param_off(c, layer, convW[0]), param_off(c, layer, convW[1]), param_off(c, layer, convW[2])};
-    // (the slice sums of the fold live in the wgrad partial-tile region, idle between this sub-block's wgrad launches: 64 x 41 472 floats = 10.6 MB)
-    if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN), wgpart, G, woffs, gs))) return e;
-    // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
-    WgradArgs a;
-    a.part = wgpart;
-    a.mvalid = 0; a.nvalid = 0;
-    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
-    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
-    a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = op_h5; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
-    a.b_gw = TF_CG; a.b_gs = (int)(N * TF_CG);
-    a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
-    return wgrad_launch(a, c.dtype, gs);
+    const long long woffs[4] = {param_off(c, layer, convW[0]), param_off(c, layer, convW[1]), param_off(c, layer, convW[2]), param_off(c, layer, P_TF_W2)};
+    // (the slice sums of the fold live in the wgrad partial-tile region, idle between this sub-block's wgrad launches: 64 x 59 904 floats = 15.3 MB)
+    return tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN + TF_H), wgpart, G, woffs, gs);
 }
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,

@@ -1148,8 +1148,13 @@ int tconvffn_bwd_s_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
 //     constant-one operand, and the workgroup's partial leaves in dW's own memory order inside the sequence's `part` row, which
 //     affine_reduce folds (the fconv_bwd pattern, profiles/README.md row 45).
 // Gone per layer: 12 S.B of operand stores, 12 S.B of operand reads, three wgrad_tr3 launches; new: 8 S.B of saved pre-activations written
-// by the forward and read here, 170 KB of partial row per sequence.  Still emitted: h5 (W2 weight gradient) and da1 (tail + W1 weight
-// gradient, tailw.hip).
+// by the forward and read here, 170 KB of partial row per sequence.  Still emitted: da1 (tail + W1 weight gradient, tailw.hip).
+//   * (round 5) the W2 weight gradient dW2[o][c] = sum_t dy[t][o] h5[t][c] is contracted here as well: the strip phase leaves its dy strip
+//     in a third LDS image D ([frame][96], 200-byte rows: the three images fill 158 of the 160 KB), h5 — rebuilt from a5 in stage 1b — is
+//     parked in registers until the conv3 contraction has released H, written there, and after the next barrier waves 0-5 contract one
+//     16-channel tile column of the workgroup's 96 x 96 block each (wave 6: db2 = colsum(dy)); the partial leaves inside the sequence's
+//     bf16 row as [channel][output] and is folded with the conv weight gradients.  Gone per layer: the h5 operand (2 S.B of lane-wise
+//     stores, 2 S.B of reads), the dy re-read and the wgrad_tr3<64,10> launch with its fold.
 struct TvIn {
     const bf16_t *a1, *a2, *a3;
     const float* gn;
@@ -1158,8 +1163,9 @@ struct TvW {
     const bf16_t *W2T, *C1T, *C2T, *C3T, *C3;
 };
 #define TV_CONVW (TS_FFN * TS_CG * 3)                 // one conv weight [192][24][3]
-#define TV_PSTRIDE (2 * TS_FFN + 3 * TS_FFN)           // floats per fp32 `part` row: GN w | GN b | conv1 b | conv2 b | conv3 b
-#define TV_P16 (3 * TV_CONVW)                          // bf16 per `part16` row: the three conv weight gradients, each as [tap][in][out]
+#define TV_PSTRIDE (2 * TS_FFN + 3 * TS_FFN + TS_H)    // floats per fp32 `part` row: GN w | GN b | conv1 b | conv2 b | conv3 b | W2 b
+#define TV_P16 (3 * TV_CONVW + TS_FFN * TS_H)          // bf16 per `part16` row: the three conv weight gradients, each as [tap][in][out], then dW2 as [FFN channel][H output]
+#define TV_DRS 100                                     // dy image row stride in elements (200 B; with 208 B the three images miss the 160 KB by 176 bytes)
 
 // dW tile accumulation of one conv group over the whole sequence.  Sg = &S[0][24 gl], Hg = &H[0][24 gl]; bases (bl, bu) as in the stage that
 // wrote S; H holds token t at row t + 1 (rows 0 and NT + 1 are zero).
@@ -1247,23 +1253,32 @@ __global__ __launch_bounds__(256) void tconv_part_reduce1_kernel(const bf16_t* _
     store4(out, acc[0], acc[1], acc[2], acc[3]);
     store4(out + 4, acc[4], acc[5], acc[6], acc[7]);
 }
-__global__ __launch_bounds__(256) void tconv_part_reduce2_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ G, long long off0, long long off1, long long off2) {
+__global__ __launch_bounds__(256) void tconv_part_reduce2_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ G, long long off0, long long off1, long long off2,
+                                                                 long long off3) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= TV_P16) return;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, c2 = 0.f, d = 0.f;
     int y = 0;
-    for (; y + 2 <= nsl; y += 2) {
+    for (; y + 4 <= nsl; y += 4) {
         a += slices[(size_t)y * TV_P16 + e];
         b += slices[(size_t)(y + 1) * TV_P16 + e];
+        c2 += slices[(size_t)(y + 2) * TV_P16 + e];
+        d += slices[(size_t)(y + 3) * TV_P16 + e];
     }
-    if (y < nsl) a += slices[(size_t)y * TV_P16 + e];
+    for (; y < nsl; ++y) a += slices[(size_t)y * TV_P16 + e];
+    const float sum = (a + b) + (c2 + d);
+    if (e >= 3 * TV_CONVW) {  // dW2 partial: [FFN channel][H output] -> the parameter's [H][FFN]
+        const int q = e - 3 * TV_CONVW, ch = q / TS_H, o = q - ch * TS_H;
+        G[off3 + (size_t)o * TS_FFN + ch] += sum;
+        return;
+    }
     const int k = e / TV_CONVW, q = e - k * TV_CONVW, tap = q / (TS_CG * TS_FFN), i = (q / TS_FFN) % TS_CG, o = q % TS_FFN;
     float* g = G + (k == 0 ? off0 : k == 1 ? off1 : off2);
-    g[((size_t)o * TS_CG + i) * 3 + tap] += a + b;  // (stream order: nothing else writes these gradients between the two launches)
+    g[((size_t)o * TS_CG + i) * 3 + tap] += sum;  // (stream order: nothing else writes these gradients between the two launches)
 }
 
 __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPtrs lp, TvW W, TvIn sv, const bf16_t* __restrict__ dy, float* __restrict__ part,
-                                                             bf16_t* __restrict__ part16, bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1) {
+                                                             bf16_t* __restrict__ part16, bf16_t* __restrict__ op_da1) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);         // [NT + TB_PAD][TB_RS]  the gradient chain, in place
@@ -1272,8 +1287,9 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     float* red = reinterpret_cast<float*>(H + h_el);     // [4 groups][2 halves][2]
     float* gnp = red + 16;                               // [2 halves][2 kinds][96] GroupNorm affine partial sums
     bf16_t* mbox = reinterpret_cast<bf16_t*>(gnp + 4 * 96);  // [8 waves][24]
+    bf16_t* D = mbox + 8 * TS_CG;                            // [NT][TV_DRS]          dy of the sequence (the W2 weight gradient's other operand)
     bf16_t* wl = H;
-    PHASE_BEGIN(mbox + 8 * TS_CG);
+    PHASE_BEGIN(D + (size_t)NT * TV_DRS);
     const TsLane L;
     const int w = wave_id_u(), tid = threadIdx.x;
     const int row = blockIdx.x >> 1, gh = blockIdx.x & 1;
@@ -1316,6 +1332,14 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
             FragH dq[6];
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) dq[ks].v = __builtin_bit_cast(s16x8, rawd[ks]);
+            {  // the strip's dy rows -> D (frames past T: zero rows)
+                bf16_t* drow = D + (size_t)t * TV_DRS + 8 * L.h;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    *reinterpret_cast<u32x2*>(drow + 16 * ks) = (u32x2){rawd[ks][0] & vm, rawd[ks][1] & vm};
+                    *reinterpret_cast<u32x2*>(drow + 16 * ks + 4) = (u32x2){rawd[ks][2] & vm, rawd[ks][3] & vm};
+                }
+            }
             bf16_t* srow = S + (size_t)((w < NSL ? 1 : 7) + t) * TB_RS + 4 * L.h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1398,17 +1422,17 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     TV_STAGE1(2, ra2, pn2, pd2)
     TV_STAGE1(3, ra3, pn3, pd3)
 #undef TV_STAGE1
-    TV_LOADA4(sv.a2)  // needed in B3b: requested now, AHEAD of the contraction's partial-row stores (loads and stores share vmcnt)
     PHASE(4);
     lds_barrier();
-    // stage 1b: a5 = conv3(h4) rebuilt from H (own strips; neighbours' rows are complete), (h5, SiLU'(a5)) from one sigmoid: h5 -> operand,
-    // da5 = dh5 * SiLU'(a5) in place in S (this lane's own piece)
+    // stage 1b: a5 = conv3(h4) rebuilt from H (own strips; neighbours' rows are complete), (h5, SiLU'(a5)) from one sigmoid: h5 -> parked in ra*
+    // (H still holds h4 for the conv3 contraction), da5 = dh5 * SiLU'(a5) in place in S (this lane's own piece)
     {
         FragH wf[5];
         load_wfrags<5>(wf, W.C3, g, L.lane);
 #pragma unroll 1
         for (int s0 = s_beg; s0 < s_end; s0 += TB_SB) {
             FragH b[TB_SB][5];
+            const bool hib = s0 - s_beg >= 2;
 #pragma unroll
             for (int k = 0; k < TB_SB; ++k)
                 if (s0 + k < s_end) {
@@ -1435,7 +1459,16 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
                     p6_pack(hv, vm, ph);
                     p6_pack(dv, vm, pd);
                     p6_store(r, pd);
-                    p6_gstore(op_h5 + gsv + (size_t)t * TS_CG, ph, tv, true);
+#pragma unroll
+                    for (int i_ = 0; i_ < 6; ++i_) {  // park h5 of strip 2 hib + k (named registers + selects, as TV_PICK)
+                        if (k == 0) {
+                            ra0.d[i_] = hib ? ra0.d[i_] : ph.d[i_];
+                            ra2.d[i_] = hib ? ph.d[i_] : ra2.d[i_];
+                        } else {
+                            ra1.d[i_] = hib ? ra1.d[i_] : ph.d[i_];
+                            ra3.d[i_] = hib ? ph.d[i_] : ra3.d[i_];
+                        }
+                    }
                 }
         }
     }
@@ -1450,6 +1483,12 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     PHASE(6);
     // B3: conv3^T: da5 (1,7) -> dh4; dn3 = dh4 * SiLU'(n3) -> S (2,6); GroupNorm backward sums and affine gradients
     fetch_cross(1, 7);
+    // (every wave is past its conv3 contraction: H is free) h5 -> H for the W2 contraction behind B3's barrier; then the a2 request (needed in B3b)
+#define TV_H5STORE(k, RA)                                                                                                      \
+    if (s_beg + (k) < s_end) p6_store(Hc + (size_t)(1 + 32 * (s_beg + (k)) + L.n) * TB_RS + 4 * L.h, RA);
+    TV_H5STORE(0, ra0) TV_H5STORE(1, ra1) TV_H5STORE(2, ra2) TV_H5STORE(3, ra3)
+#undef TV_H5STORE
+    TV_LOADA4(sv.a2)
     PHASE(7);
     {
         float sa = 0.f, sb = 0.f, dgw[12], dgb[12];
@@ -1511,6 +1550,54 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     load_wfrags<5>(wt, W.C2T, g, L.lane);
     PHASE(8);
     lds_barrier();
+    // W2 weight gradient of the workgroup's 96 channels: dW2[o][c] = sum_t dy[t][o] h5[t][c]  (D x H, K = the frames).  Wave w < 6: channel tile w, all six
+    // output tiles (one h5 + six dy transposing fragment reads per six MFMAs and 32 frames); wave 6 of the sequence's first workgroup: db2 = colsum(dy)
+    {
+        const int l15 = L.lane & 15, g4 = L.lane >> 4;
+        const int rowoff = 4 * g4 + (l15 >> 2), c4 = 4 * (l15 & 3);
+        if (w < 6) {
+            f32x4 acc[6];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) acc[mt] = F32X4_ZERO;
+#pragma unroll 2
+            for (int ks = 0; ks < NS; ++ks) {
+                Frag<bf16_t> fb, fa[6];
+                frag_load_tr(fb, H + (size_t)(1 + 32 * ks + rowoff) * TB_RS + 16 * w + c4, TB_RS);
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) frag_load_tr(fa[mt], D + (size_t)(32 * ks + rowoff) * TV_DRS + 16 * mt + c4, TV_DRS);
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) acc[mt] = mma(fa[mt], fb, acc[mt]);
+            }
+            // lane: outputs 16 mt + 4 g4 + r of channel 96 gh + 16 w + l15 -> the sequence's bf16 row, [channel][output]: one 8-byte store per tile
+            bf16_t* dst = prow16 + 3 * TV_CONVW + (size_t)(96 * gh + 16 * w + l15) * TS_H + 4 * g4;
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) *reinterpret_cast<u32x2*>(dst + 16 * mt) = (u32x2){pack2bf(acc[mt][0], acc[mt][1]), pack2bf(acc[mt][2], acc[mt][3])};
+        } else if (w == 6 && gh == 0) {
+            Frag<bf16_t> ones;
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) frag_set(ones, jq, 1.0f);
+            f32x4 bs[6];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) bs[mt] = F32X4_ZERO;
+            for (int ks = 0; ks < NS; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) {
+                    Frag<bf16_t> fa;
+                    frag_load_tr(fa, D + (size_t)(32 * ks + rowoff) * TV_DRS + 16 * mt + c4, TV_DRS);
+                    bs[mt] = mma(fa, ones, bs[mt]);
+                }
+            }
+            if (l15 == 0) {  // every column holds the sums: rows 4 g4 + r
+                float* brow2 = part + (size_t)row * TV_PSTRIDE + 5 * TS_FFN + 4 * g4;
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) brow2[16 * mt + r] = bs[mt][r];
+            }
+        }
+    }
+    PHASE(19);
+    lds_barrier();  // H is rewritten (h2) by the next stage
     PHASE(9);
     // B3b (in place, own values): da3 = rstd (gw dn3 - mean(gw dn3) - a3hat mean(gw dn3 a3hat)) -> S (2,6);
     // and the next activation: (h2, SiLU'(a2)) from the saved a2: h2 -> H (every wave is past its conv3 contraction), SiLU' parked
@@ -1657,24 +1744,25 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
 PHASE_READER(nbss_phase_read_tconvffn_bwd_v)
 
 size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV_PSTRIDE * sizeof(float) + TV_P16 * sizeof(bf16_t)); }
-// fold of the bf16 conv-weight partial rows into G (fp32); offs = flat-gradient offsets of the three conv weights; `slices`: TV_RSL x TV_P16 floats of scratch
+// fold of the bf16 weight-gradient partial rows into G (fp32); offs = flat-gradient offsets of the three conv weights and of W2; `slices`: TV_RSL x TV_P16 floats of scratch
 int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, hipStream_t st) {
     const int nrows = c.B * c.F, nsl = nrows < TV_RSL ? nrows : TV_RSL;
     NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((TV_P16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;
-    NBSS_LAUNCH(tconv_part_reduce2_kernel, dim3((TV_P16 + 255) / 256), dim3(256), 0, st, (const float*)slices, nsl, G, offs[0], offs[1], offs[2]);
+    NBSS_LAUNCH(tconv_part_reduce2_kernel, dim3((TV_P16 + 255) / 256), dim3(256), 0, st, (const float*)slices, nsl, G, offs[0], offs[1], offs[2], offs[3]);
     return NBSS_CHECK_LAUNCH();
 }
 size_t tconvffn_v_slices_bytes() { return (size_t)TV_RSL * TV_P16 * sizeof(float); }
 // data-gradient + T-conv weight-gradient kernel from saved pre-activations; `part`: [B*F][TV_PSTRIDE] floats, then [B*F][TV_P16] bf16
-int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5,
-                          void* op_da1, hipStream_t st) {
+int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_da1,
+                          hipStream_t st) {
     bf16_t* part16 = reinterpret_cast<bf16_t*>(part + (size_t)c.B * c.F * TV_PSTRIDE);
     if (c.dtype != NBSS_BF16 || c.T > 256 || !tsave) return NBSS_EUNSUPPORTED;
     const size_t NT = (size_t)((c.T + 31) / 32) * 32;
     const size_t h_el = (NT + 2) * TB_RS > (size_t)24 * 512 ? (NT + 2) * TB_RS : (size_t)24 * 512;
-    const size_t lds = ((NT + TB_PAD) * TB_RS + h_el) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + 8 * TS_CG * sizeof(bf16_t) + PHASE_LDS_BYTES;
+    const size_t lds = ((NT + TB_PAD) * TB_RS + h_el + NT * TV_DRS) * sizeof(bf16_t) + (16 + 4 * 96) * sizeof(float) + 8 * TS_CG * sizeof(bf16_t) + PHASE_LDS_BYTES;
+    if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;  // (T = 256: 161 968 of 163 840 bytes; the diagnostic build's timer slots fit up to T = 224)
     const bf16_t* pk = (const bf16_t*)packed;
     TvW W = {pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1_T), pk + pack_off(c, layer, K_TS_C2_T), pk + pack_off(c, layer, K_TS_C3_T),
              pk + pack_off(c, layer, K_TS_C3)};
@@ -1682,7 +1770,7 @@ int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     TvIn in = {s.a1, s.a2, s.a3, s.gn};
     int e = NBSS_SET_MAX_LDS(tconvffn_bwd_v_kernel, lds);
     if (e) return e;
-    NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_h5, (bf16_t*)op_da1);
+    NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_da1);
     return NBSS_CHECK_LAUNCH();
 }
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave) { return ts_save_ptrs(c, tsave).ln; }
