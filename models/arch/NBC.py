@@ -3,9 +3,10 @@ NBC.py:73-293): same constructor, same forward [B,F,T,dim_input] -> [B,F,T,dim_o
 (`encoder`, `sa_layers.N.self_attn.{query,key,value,pos,out}_proj / u_bias / v_bias / rel_pos.pe`, `linear1/2`, `norm1/2`,
 `conv.*`, `decoder`).  The position term of the scores is computed as one [T, 2T-1] product per head followed by a gather along
 the relative offset (the reference materialises a [T, T, heads, d] tensor).  Plain PyTorch; inference on a HIP
-device can take the native path of nbss_amd/nbc.py (see NBC.forward)."""
+device takes the native path of nbss_amd/nbc.py (see NBC.forward)."""
 import math
 import os
+import warnings
 import weakref
 from typing import Callable, Optional, Tuple
 
@@ -15,7 +16,8 @@ import torch.nn.functional as F
 from torch import Tensor
 
 
-_NATIVE = weakref.WeakKeyDictionary()  # NBC module -> nbss_amd.nbc.NativeNBC (or None)
+_NATIVE = weakref.WeakKeyDictionary()  # NBC module -> (nbss_amd.nbc.NativeNBC or None, reason it is None)
+_NOTED = weakref.WeakKeyDictionary()   # NBC module -> reasons already reported
 
 
 class _GroupNorm(nn.GroupNorm):
@@ -145,26 +147,51 @@ class NBC(nn.Module):
         self.decoder = nn.ConvTranspose1d(hidden_size, dim_output, kernel_size=encoder_kernel_size, stride=1)
 
     def _native(self):
-        """nbss_amd.nbc.NativeNBC of this module when the HIP library is there and the configuration is one its kernels take, else None"""
+        """nbss_amd.nbc.NativeNBC of this module when the HIP library is there and the configuration is one its kernels take, else None (the reason is kept)"""
         if self not in _NATIVE:
-            runner = None
+            runner, why = None, None
             try:
                 from nbss_amd._lib import hip
                 from nbss_amd.nbc import NativeNBC, supported
-                if supported(self) is None:
+                why = supported(self)
+                if why is None:
                     runner = NativeNBC(self, hip())
-            except Exception:  # (no library / no HIP runtime: torch.nn below)
-                runner = None
-            _NATIVE[self] = runner
-        return _NATIVE[self]
+            except Exception as e:  # (no library / no HIP runtime: torch.nn below)
+                runner, why = None, f"{type(e).__name__}: {e}"
+            _NATIVE[self] = (runner, why)
+        return _NATIVE[self][0]
+
+    def _torch_path_note(self, why: str) -> None:
+        """one warning per module and reason: a user on a HIP device can tell which path ran"""
+        seen = _NOTED.setdefault(self, set())
+        if why not in seen:
+            seen.add(why)
+            warnings.warn(f"NBC: torch.nn path instead of the native HIP kernels ({why})", RuntimeWarning, stacklevel=3)
 
     def forward(self, x: Tensor) -> Tensor:
         B, Fq, T, _ = x.shape
         # inference on a HIP device (eval mode: the dropouts of the block are inactive; no autograd): the native forward over the nbss_nb_* building blocks
-        # — opt-in (NBSS_NBC_NATIVE=1) until it has run on the device: it was written after round 4's GPU budget, tests/test_nbc_native.py runs it on the emulator
-        if (x.is_cuda and not self.training and not torch.is_grad_enabled() and 4 <= T <= 256 and x.dtype in (torch.float32, torch.bfloat16)
-                and os.environ.get("NBSS_NBC_NATIVE") == "1" and self._native() is not None):
-            return self._native().forward(x.contiguous())
+        # (verified on the device in round 5, tests/test_nbc_native.py; NBSS_NBC_NATIVE=0 switches it off).  Training, the CPU and shapes the kernels
+        # refuse run the torch.nn modules below — on a device with one warning naming the reason.
+        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+            why = None
+            if os.environ.get("NBSS_NBC_NATIVE", "1") == "0":
+                why = "NBSS_NBC_NATIVE=0"
+            elif x.dtype not in (torch.float32, torch.bfloat16):
+                why = f"input dtype {x.dtype}"
+            elif not 4 <= T <= 256:
+                why = f"{T} frames: the attention kernel keeps a sequence and its offsets table in LDS (4 .. 256)"
+            elif any(p.dtype != torch.float32 for p in self.parameters()):
+                why = "parameters are not fp32"
+            elif self._native() is None:
+                why = _NATIVE[self][1] or "native path unavailable"
+            if why is None:
+                from nbss_amd._lib import NbssError
+                try:
+                    return self._native().forward(x.contiguous())
+                except NbssError as e:  # (a shape the kernels refuse, e.g. fp32 with head width 48 beyond ~200 frames: LDS)
+                    why = str(e)
+            self._torch_path_note(why)
         h = self.encoder(x.reshape(B * Fq, T, -1).transpose(1, 2)).transpose(1, 2)
         for block in self.sa_layers:
             h, _ = block(h)

@@ -13,9 +13,11 @@ from torch import Tensor
 from torch.nn import MultiheadAttention
 
 
+import warnings
 import weakref
 
-_NATIVE = weakref.WeakKeyDictionary()  # NBC2 module -> nbss_amd.nbc2.NativeNBC2 (or None)
+_NATIVE = weakref.WeakKeyDictionary()  # NBC2 module -> (nbss_amd.nbc2.NativeNBC2 or None, reason it is None)
+_NOTED = weakref.WeakKeyDictionary()   # NBC2 module -> reasons already reported
 
 
 class LayerNorm(nn.LayerNorm):
@@ -144,29 +146,61 @@ class NBC2(nn.Module):
     def _native(self):
         """the HIP path (nbss_amd/nbc2.py) when this configuration is one its kernels are built for, else None.  The handle lives in a module-level
         WeakKeyDictionary (a ctypes library handle as a module attribute would break deepcopy / pickle of the module); a library that cannot be
-        loaded means the torch.nn path, not an exception."""
+        loaded means the torch.nn path, not an exception — the reason is kept and reported once by forward()."""
         if self not in _NATIVE:
-            runner = None
+            runner, why = None, None
             try:
                 from nbss_amd._lib import hip
                 from nbss_amd.nbc2 import NativeNBC2, supported
-                if supported(self) is None:
+                why = supported(self)
+                if why is None:
                     runner = NativeNBC2(self, hip())
-            except Exception:  # (no library / no HIP runtime: torch.nn below)
-                runner = None
-            _NATIVE[self] = runner
-        return _NATIVE[self]
+            except Exception as e:  # (no library / no HIP runtime: torch.nn below)
+                runner, why = None, f"{type(e).__name__}: {e}"
+            _NATIVE[self] = (runner, why)
+        return _NATIVE[self][0]
+
+    def _torch_path_note(self, why: str) -> None:
+        """one warning per module and reason: a user on a HIP device can tell which path ran"""
+        seen = _NOTED.setdefault(self, set())
+        if why not in seen:
+            seen.add(why)
+            warnings.warn(f"NBC2: torch.nn path instead of the native HIP kernels ({why})", RuntimeWarning, stacklevel=3)
+
+    def _native_or_reason(self, x: Tensor):
+        """(runner, None) when the native path takes this call, else (None, reason); reason None on the CPU (nothing to report)"""
+        if not x.is_cuda:
+            return None, None
+        B, F, T, _ = x.shape
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            return None, f"input dtype {x.dtype}"
+        nat = self._native()  # first: supported() also guards the attribute reads below (other norm types have no group_size)
+        if nat is None:
+            return None, _NATIVE[self][1] or "native path unavailable"
+        if T > 256:
+            return None, f"{T} frames: the attention kernels keep a sequence in LDS (<= 256)"
+        gs = getattr(self.sa_layers[0].norm2, "group_size", None)
+        if F != gs:
+            return None, f"{F} frequencies per utterance, GroupBatchNorm group_size {gs}"
+        return nat, None
 
     def forward(self, x: Tensor) -> Tensor:
         B, F, T, _ = x.shape
         # on a HIP device: the native forward (torch.no_grad(): validate / test / predict) or the native training path (autograd.Function whose backward
-        # runs the nbss_nb_*_bwd building blocks); CPU and configurations the kernels are not built for: the torch.nn modules below
-        if (x.is_cuda and T <= 256 and x.dtype in (torch.float32, torch.bfloat16) and F == self.sa_layers[0].norm2.group_size and self._native() is not None):
+        # runs the nbss_nb_*_bwd building blocks); CPU and configurations the kernels are not built for: the torch.nn modules below (with one warning
+        # naming the reason when the input is on a device)
+        nat, why = self._native_or_reason(x)
+        if nat is not None:
             if not torch.is_grad_enabled():
-                return self._native().forward(x.contiguous())
+                return nat.forward(x.contiguous())
             from nbss_amd.nbc2 import _train_supported
-            if _train_supported(self) is None and not x.requires_grad:
-                return self._native().forward_train(x.contiguous())
+            why = _train_supported(self)
+            if why is None and x.requires_grad:
+                why = "the input requires a gradient (the native backward produces parameter gradients only)"
+            if why is None:
+                return nat.forward_train(x.contiguous())
+        if why is not None:
+            self._torch_path_note(why)
         h = self.encoder(x.reshape(B * F, T, -1).transpose(1, 2)).transpose(1, 2)
         for block in self.sa_layers:
             h, _ = block(h)

@@ -2,7 +2,8 @@
 `NBSS(n_channel, n_speaker, n_fft, n_overlap, ref_channel, arch, arch_kwargs).forward(x [B,C,T]) -> [B,Spk,T]` around a
 narrow-band network ("NB_BLSTM", "NBC" or "NBC2").  STFT (hann, hop = n_overlap) -> per-frequency normalisation by the mean
 magnitude of the reference channel -> network on [B,F,T,2C] -> de-normalisation -> iSTFT.  `neg_si_sdr` is the full-band PIT
-criterion's metric (the reference takes SI-SDR from torchmetrics; its closed form is restated here).  Plain PyTorch."""
+criterion's metric (the reference takes SI-SDR from torchmetrics; its closed form is restated here).  On a HIP device the STFT / iSTFT are the
+kernels of nbss_amd/csrc/signal.hip (through models.io.stft.STFT) and NBC / NBC2 take their native paths; the CPU runs plain PyTorch."""
 from typing import Any, Dict
 
 import torch
@@ -40,9 +41,22 @@ class NBSS(nn.Module):
         self.register_buffer("window", torch.hann_window(n_fft), False)
         self.n_fft, self.n_overlap, self.ref_channel, self.n_channel, self.n_speaker = n_fft, n_overlap, ref_channel, n_channel, n_speaker
 
+    def _io(self):
+        """models.io.stft.STFT of this geometry — NOT a registered sub-module: the reference's NBSS has no `stft.*` state_dict key (its window is a
+        non-persistent buffer), and checkpoints interchange both ways"""
+        if "_stft" not in self.__dict__:
+            from models.io.stft import STFT
+            object.__setattr__(self, "_stft", STFT(self.n_fft, self.n_overlap))
+        return self.__dict__["_stft"]
+
     def forward(self, x: Tensor) -> Tensor:
         B, C, N = x.shape
-        X = torch.stft(x.reshape(B * C, N), n_fft=self.n_fft, hop_length=self.n_overlap, win_length=self.n_fft, window=self.window, return_complex=True)
+        io = self._io()
+        native_io = x.is_cuda and io.hip_ok  # HIP device: the DFT-as-GEMM kernels of nbss_amd/csrc/signal.hip (models/io/stft.py); else torch.stft / istft
+        if native_io:
+            X = io.stft(x.reshape(B * C, N))[0]
+        else:
+            X = torch.stft(x.reshape(B * C, N), n_fft=self.n_fft, hop_length=self.n_overlap, win_length=self.n_fft, window=self.window, return_complex=True)
         Fq, TF = X.shape[-2:]
         X = X.reshape(B, C, Fq, TF).permute(0, 2, 3, 1)  # [B,F,T,C]
         scale = X[..., self.ref_channel].abs().mean(dim=2)  # [B,F]: mean magnitude of the reference channel per frequency
@@ -50,5 +64,8 @@ class NBSS(nn.Module):
         out = self.arch(feats).reshape(B, Fq, TF, self.n_speaker, 2)
         Y = torch.view_as_complex(out.float().contiguous()) * scale[:, :, None, None]  # [B,F,T,S]
         Y = Y.permute(0, 3, 1, 2).reshape(B * self.n_speaker, Fq, TF)
-        y = torch.istft(Y, n_fft=self.n_fft, hop_length=self.n_overlap, win_length=self.n_fft, window=self.window, length=N)
+        if native_io:
+            y = io.istft(Y, N)  # (autograd.Function: its backward is the iSTFT adjoint kernel)
+        else:
+            y = torch.istft(Y, n_fft=self.n_fft, hop_length=self.n_overlap, win_length=self.n_fft, window=self.window, length=N)
         return y.reshape(B, self.n_speaker, N)

@@ -22,6 +22,13 @@ HIP_LIB = LIBDIR / "libnbss_hip.so"
 EMU_LIB = EMUDIR / "libnbss_emu.so"
 
 
+# The SLP vectoriser turns adjacent f32 adds / multiplies into v_pk_*_f32.  On gfx950 a packed f32 instruction issues no faster than its two
+# scalar halves (SIMD-32: 157 TFLOP/s IS the unpacked rate) and constrains register pairing; measured per kernel in one call (profiles/README.md,
+# round 5): full_bwd 766 -> 716 us, mhsa_bwd 1417 -> 1406 without it, fconv_bwd within noise, the T-ConvFFN kernels 4 % SLOWER (fewer issue slots
+# matter there) — so it is switched off per file.
+PER_FILE_FLAGS = {k: ["-fno-slp-vectorize"] for k in ("full", "mhsa", "mhsa_bwd")}
+
+
 def _sources():
     return sorted(CSRC.glob("*.hip"))
 
@@ -73,8 +80,8 @@ def build_hip(force: bool = False, verbose: bool = False, phase_prof: bool = Fal
     for s in _sources():
         o = objdir / (s.stem + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+        if force or _newer(o, [s] + hdrs + [Path(__file__)]):
+            jobs.append([hipcc, *flags, *PER_FILE_FLAGS.get(s.stem, []), "-c", str(s), "-o", str(o)])
     if jobs:
         if verbose:
             print(f"[nbss_amd.build] hipcc: compiling {len(jobs)} file(s) for gfx950", flush=True)

@@ -292,8 +292,14 @@ class TrainStep:
         if self.collectives:
             torch.distributed.all_reduce(e.grads, group=self.pg)
         self.step_count += 1
-        self.lib.call("nbss_adam_hyper", int(self.step_count), float(self.lr), float(self.betas[0]), float(self.betas[1]), g["hyper_host"].data_ptr())
-        g["hyper"].copy_(g["hyper_host"], non_blocking=True)
+        # per-step scalars: a small ring of pinned host buffers, each guarded by an event recorded behind its copy — the host may run several steps
+        # ahead of the device (no per-step sync), and a single buffer would be rewritten under a pending DMA
+        i = self.step_count % len(g["hyper_host"])
+        hh, ev = g["hyper_host"][i], g["hyper_ev"][i]
+        ev.synchronize()  # (no-op for an event that was never recorded)
+        self.lib.call("nbss_adam_hyper", int(self.step_count), float(self.lr), float(self.betas[0]), float(self.betas[1]), hh.data_ptr())
+        g["hyper"].copy_(hh, non_blocking=True)
+        ev.record()
         g["b"].replay()
         e.version += 1
         e._packed_version = e.version  # the replayed re-pack refreshed the fragments in place
@@ -302,10 +308,17 @@ class TrainStep:
     def _capture(self, key, x: Tensor, yr: Tensor) -> dict:
         e = self.e
         g = {"state": 1, "x": torch.empty_like(x), "yr": torch.empty_like(yr), "hyper": torch.zeros(4, dtype=torch.float32, device=x.device),
-             "hyper_host": torch.zeros(4, dtype=torch.float32).pin_memory()}
+             "hyper_host": [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(4)], "hyper_ev": [torch.cuda.Event() for _ in range(4)]}
         g["x"].copy_(x)
         g["yr"].copy_(yr)
         g["packed"] = e.packed_for(e.dtype)
+        # the training workspace / saved activations of THIS shape, allocated eagerly (another shape may have taken the engine's slot since the
+        # eager first step) and held by the graph: its kernels have these addresses baked in, and a later change of shape drops the engine's
+        # reference (ensure_geometry) — without the graph's own the replay would write into memory returned to the allocator
+        xin0, _ = ops.stft_norm_fwd(self.lib, self.n_fft, e.dtype, self.tables, g["x"], self.ref)
+        e.ensure_geometry(xin0.shape[0], xin0.shape[2], True, e.dtype)
+        g["ws"], g["acts"] = e.ws, e.acts
+        del xin0
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
@@ -317,6 +330,7 @@ class TrainStep:
             # re-pack IN PLACE: graph A reads this very buffer (a fresh one per step, as the eager path allocates, would leave the replayed
             # forward on the fragments of the capture step)
             ops.pack_params(self.lib, e.cfg_for(1, 16, e.dtype), e.params, out=g["packed"])
+        assert e.ws is g["ws"] and e.acts is g["acts"]  # (nothing re-allocated under capture)
         e.version += 1
         e._packed_version = e.version
         g.update(a=ga, b=gb, loss=loss)

@@ -44,6 +44,8 @@ def supported(net) -> Optional[str]:
         for cv in convs:
             if cv.kernel_size[0] % 2 == 0 or (cv.in_channels // cv.groups) % 8 or cv.bias is None:
                 return "grouped convs need an odd kernel, a bias and groups that are multiples of 8 channels wide"
+            if cv.in_channels != b.linear1.out_features or cv.out_channels != b.linear1.out_features:
+                return "the feed-forward convs must be ffn_size wide"
         for gn in gns:
             if abs(gn.eps - 1e-5) > 1e-12 or not gn.affine:
                 return "GroupNorm must be affine with eps 1e-5"
@@ -89,8 +91,12 @@ class NativeNBC:
                                                          (H, FFN, 1, 1), (Co8, H, 1, K1))]
         ws = torch.empty(max(need), dtype=torch.uint8, device=dev)
 
-        def f32(t):
-            return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep = []  # converted copies stay alive until this call returns: a temporary freed before its kernel is enqueued could be re-used by the next one
+
+        def f32(t):  # parameters as fp32 contiguous device tensors (no copy for the fp32 parameters of an nn.Module)
+            v = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(v)
+            return v
 
         def conv(xin, rows_t, cin, ldx, cout, groups, taps, w, b, res=None, act_in=0, act_out=0, n=nseq):
             y = torch.empty(n, rows_t, cout, dtype=td, device=dev)

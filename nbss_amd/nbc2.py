@@ -86,8 +86,12 @@ class NativeNBC2:
         ws = torch.empty(max(need), dtype=torch.uint8, device=dev)
         stats = torch.empty(N, 2, dtype=torch.float32, device=dev)
 
-        def f32(t):  # parameters as fp32 contiguous device tensors (they are: nn.Module parameters of an fp32 module)
-            return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep = []  # converted copies stay alive until this call returns: a temporary freed before its kernel is enqueued could be re-used by the next one
+
+        def f32(t):  # parameters as fp32 contiguous device tensors (no copy for the fp32 parameters of an nn.Module)
+            v = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(v)
+            return v
 
         def conv(xin, cin, ldx, cout, groups, taps, w, b, res=None, act_in=0, act_out=0):
             y = torch.empty(nseq, T, cout, dtype=td, device=dev)
@@ -196,8 +200,12 @@ def _forward_train(self, x: Tensor):
     ws = torch.empty(max(lib._dll.nbss_nb_bwd_ws_bytes(*a) for a in shapes), dtype=torch.uint8, device=dev)
     p = self._p
 
-    def f32(t):
-        return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    keep = []  # converted copies stay alive until this call returns: a temporary freed before its kernel is enqueued could be re-used by the next one
+
+    def f32(t):  # parameters as fp32 contiguous device tensors (no copy for the fp32 parameters of an nn.Module)
+        v = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(v)
+        return v
 
     def conv(xin, cin, ldx, cout, groups, taps, w, b, res=None, y2=False):
         y = torch.empty(nseq, T, cout, dtype=td, device=dev)
@@ -248,8 +256,12 @@ def _backward_train(self, sv, dout: Tensor):
     aws = torch.empty(lib._dll.nbss_nb_attention_bwd_ws_bytes(dt, nseq, T, H, heads), dtype=torch.uint8, device=dev)
     blocks = list(net.sa_layers)
 
-    def f32(t):
-        return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    keep = []  # converted copies stay alive until this call returns: a temporary freed before its kernel is enqueued could be re-used by the next one
+
+    def f32(t):  # parameters as fp32 contiguous device tensors (no copy for the fp32 parameters of an nn.Module)
+        v = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(v)
+        return v
 
     def zeros_like_param(t):
         return torch.zeros(t.numel(), dtype=torch.float32, device=dev)

@@ -50,3 +50,33 @@ def test_graph_mode_is_opt_in(hip_lib):
     eng = SpatialNetEngine(hip_lib, dev, dim_input=12, dim_output=4, num_freqs=129, num_layers=1, dtype=NBSS_BF16)
     assert not TrainStep(eng)._use_graph(torch.empty(2, 6, 8, device=dev))
     assert TrainStep(eng, graph=True)._use_graph(torch.empty(2, 6, 8, device=dev))
+
+
+@pytest.mark.gpu
+def test_two_alternating_shapes_replay_into_their_own_workspaces(hip_lib):
+    """a smaller last batch / another segment length alternating with the usual one: each shape's graph holds the workspace and saved-activation
+    buffers its kernels were captured with (the engine's slot is re-allocated at every change of shape), so the alternating graph run trains like the
+    alternating eager run"""
+    dev = torch.device("cuda:0")
+
+    def run(graph):
+        eng = SpatialNetEngine(hip_lib, dev, dim_input=12, dim_output=4, num_freqs=129, num_layers=2, dtype=NBSS_BF16)
+        eng.load_params(ref.init_params(num_layers=2, num_freqs=129, dim_input=12, dim_output=4, seed=0))
+        ts = TrainStep(eng, lr=3e-2, clip=5.0, graph=graph, eps=1.0)
+        g = torch.Generator().manual_seed(7)
+        losses = []
+        for i in range(8):
+            B, N = ((2, 16000), (1, 12000))[i % 2]
+            x = torch.randn(B, 6, N, generator=g).to(dev)
+            yr = torch.randn(B, 2, N, generator=g).to(dev)
+            losses.append(float(ts.step(x, yr)))
+        torch.cuda.synchronize()
+        return np.array(losses), eng.params.double().cpu().numpy(), ts
+
+    le, pe, _ = run(False)
+    lg, pg, ts = run(True)
+    assert len(ts._graphs) == 2 and all(g["state"] == 1 for g in ts._graphs.values())
+    ptrs = {(g["ws"].data_ptr(), g["acts"].data_ptr()) for g in ts._graphs.values()}
+    assert len(ptrs) == 2  # two live buffer sets
+    assert np.isfinite(lg).all() and np.allclose(lg, le, rtol=1.5e-2, atol=1e-5), (lg, le)
+    assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 5e-3

@@ -150,3 +150,30 @@ def test_group_norm_gradients_beyond_128_samples_on_the_device():
             grads.append([gn.weight.grad.cpu(), gn.bias.grad.cpu(), x.grad.cpu()])
         for a, b in zip(*grads):
             assert float((a - b).norm() / b.norm()) < 1e-5, N
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch", ["NB_BLSTM", "NBC2"])
+def test_nbss_on_the_device_uses_the_hip_stft_and_equals_the_host_path(hip_lib, arch):
+    """NBSS.forward on a HIP tensor (n_fft 256 / hop 128: BASELINE config 1's geometry) runs the STFT / iSTFT kernels of signal.hip — and NBC2 its native
+    path — and returns what the host path (torch.stft / torch.istft / torch.nn, pinned to the reference fixture above) returns; gradients too; the
+    state_dict carries no key the reference's NBSS lacks"""
+    from models.arch.NBSS import NBSS
+    torch.manual_seed(4)
+    kw = {"hidden_size": (16, 8)} if arch == "NB_BLSTM" else {"n_layers": 1, "dim_hidden": 96, "dim_ffn": 192, "num_freqs": 129}
+    net = NBSS(n_channel=2, n_speaker=2, n_fft=256, n_overlap=128, ref_channel=0, arch=arch, arch_kwargs=kw)
+    assert not any(k.startswith("_stft") or k.startswith("stft") for k in net.state_dict())
+    x = torch.randn(2, 2, 8000)
+    r = torch.randn(2, 2, 8000)
+    y = net(x)
+    (y * r).sum().backward()
+    want = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.zero_grad()
+    dev = net.cuda()
+    yd = dev(x.cuda())
+    assert dev._io().hip_ok and yd.is_cuda
+    assert rel_l2(yd, y) < 2e-4
+    (yd * r.cuda()).sum().backward()
+    top = max(float(g.norm()) for g in want.values())
+    for k, p in dev.named_parameters():
+        assert float((p.grad.cpu() - want[k]).norm()) <= 2e-3 * float(want[k].norm()) + 1e-5 * top, k

@@ -299,3 +299,32 @@ def test_training_blocks_random_shapes(emu_lib):
     conv()
     gbn()
     attn()
+
+
+@pytest.mark.gpu
+def test_module_dispatch_on_the_device(hip_lib):
+    """models.arch.NBC2.NBC2.forward on a HIP tensor: the default norms take the native path silently; other norm types (no GroupBatchNorm, hence no
+    `group_size`), a frequency count other than the group size and sequences beyond 256 frames run the torch.nn modules with ONE warning naming the reason
+    (round 4 raised AttributeError for the first of these)"""
+    import warnings
+
+    from models.arch.NBC2 import NBC2
+    torch.manual_seed(11)
+    x = torch.randn(1, 9, 40, 12).cuda()
+    net = NBC2(dim_input=12, dim_output=4, n_layers=1, dim_hidden=96, dim_ffn=192, num_freqs=9).cuda().eval()
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y = net(x)
+    assert y.shape == (1, 9, 40, 4)
+    bk = {"n_heads": 2, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 8, "norms": ("LN", "LN", "GN")}
+    other = NBC2(dim_input=12, dim_output=4, n_layers=1, dim_hidden=96, dim_ffn=192, num_freqs=9, block_kwargs=bk).cuda()
+    for train in (False, True):
+        other.train(train)
+        with pytest.warns(RuntimeWarning, match="norms must be") if not train else warnings.catch_warnings():  # (one warning per module and reason)
+            y = other(x)
+        assert y.shape == (1, 9, 40, 4)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="group_size"):  # (18 sequences = two groups of 9 for the module; the kernels take whole utterances)
+            assert net(torch.randn(1, 18, 40, 12).cuda()).shape == (1, 18, 40, 4)
+        with pytest.warns(RuntimeWarning, match="300 frames"):
+            assert net(torch.randn(1, 9, 300, 12).cuda()).shape == (1, 9, 300, 4)
