@@ -206,6 +206,34 @@ NBSS_DEV float row_sum16(float v) {
     return v;
 #endif
 }
+// One lane pairing inside a row of 16 lanes as a VALU move (DPP): STEP 0 = row_mirror (l <-> 15 - l), 1 = row_half_mirror (l <-> 7 - l inside each 8),
+// 2 = quad_perm [2,3,0,1] (l ^ 2), 3 = quad_perm [1,0,3,2] (l ^ 1)
+template <int STEP>
+NBSS_DEV float row_pair(float v) {
+#ifdef NBSS_EMU
+    const int l = (int)(threadIdx.x & 63);
+    const int p = STEP == 0 ? (l & ~15) | (15 - (l & 15)) : STEP == 1 ? (l & ~7) | (7 - (l & 7)) : STEP == 2 ? l ^ 2 : l ^ 1;
+    return __shfl(v, p);
+#else
+    constexpr int ctrl = STEP == 0 ? 0x140 : STEP == 1 ? 0x141 : STEP == 2 ? 0x4E : 0xB1;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true));
+#endif
+}
+// Transpose-reduce: SIXTEEN per-lane values summed over the 16 lanes of a row at once — each step pairs the lanes, one of a pair keeps the first half of
+// the values and sends the second, its partner the other way round, so the value count halves per step: 8 + 4 + 2 + 1 adds (and two selects each)
+// instead of 16 x 4 DPP adds; lane l15 returns the row total of v[l15] (a fixed summation order).
+NBSS_DEV float row_reduce16x16(const float (&v)[16]) {
+    const int l = (int)(threadIdx.x & 63);
+    const bool c0 = l & 8, c1 = l & 4, c2 = l & 2, c3 = l & 1;
+    float a[8], b[4], c[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (c0 ? v[8 + i] : v[i]) + row_pair<0>(c0 ? v[i] : v[8 + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (c1 ? a[4 + i] : a[i]) + row_pair<1>(c1 ? a[i] : a[4 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) c[i] = (c2 ? b[2 + i] : b[i]) + row_pair<2>(c2 ? b[i] : b[2 + i]);
+    return (c3 ? c[1] : c[0]) + row_pair<3>(c3 ? c[0] : c[1]);
+}
 NBSS_DEV float wave_sum64(float v) {
     v = row_sum16(v);
     v += __shfl_xor(v, 16);

@@ -327,7 +327,9 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     T* dvb = u + (size_t)FP * ROW;               // [FP][TT][LD]  dy (phase 0), then dv in place
     float* aff = reinterpret_cast<float*>(dvb + (size_t)FP * ROW);  // [3H] LN weight | LN bias | PReLU slope gradient sums
     float* lnp = aff + 3 * FC_H;                 // [2H] gamma | beta
-    PHASE_BEGIN(lnp + 2 * FC_H);
+    float* affw = lnp + 2 * FC_H;                // [NW][2H] per-wave LayerNorm affine sums: each wave adds its units in its own order, the waves are
+                                                 // added in wave order at the end (LDS float atomics made the partial row depend on the wave timing)
+    PHASE_BEGIN(affw + NW * 2 * FC_H);
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
 #ifdef NBSS_FCONV_NO_DMA  // (A/B flavour)
     constexpr bool DMA = false;
@@ -343,6 +345,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     }
     const bool gwave = NW == FC_G || w < FC_G;  // this wave owns a conv group in the group phases
     for (int i = tid; i < 3 * FC_H; i += blockDim.x) aff[i] = 0.f;
+    for (int i = tid; i < NW * 2 * FC_H; i += blockDim.x) affw[i] = 0.f;
     for (int i = tid; i < 2 * FC_H; i += blockDim.x) lnp[i] = i < FC_H ? lnw[i] : lnb[i - FC_H];
     constexpr int VZ = VecOf<T>::N;  // elements per 16-byte store (ROW is a multiple of 8)
     for (int i = tid; i < 4 * ROW / VZ; i += blockDim.x) {  // halo rows (f = -2, -1, 16 mtf, 16 mtf + 1) of both images
@@ -605,24 +608,53 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
         const T* ur = u + (size_t)(f + 2) * ROW + tt * FC_LD;
         const float rstd = valid ? rstd0 : 0.f;
         float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < BK_KS; ++ks) {
+        // LayerNorm affine sums of the unit: per channel the sum over the tile's 16 rows of du xhat (gamma) and du (beta) — 48 row sums.  They are taken
+        // SIXTEEN at a time (row_reduce16x16: the lanes of a row end up with one total each and add it to the wave's own slot row, all lanes busy) in
+        // three groups: xhat-products of k-steps 0-1 | xhat-products and plain sums of k-step 2 | plain sums of k-steps 0-1.  (Round 4: one 4-step DPP
+        // reduction per value and 48 single-lane LDS atomics per unit.)
+        static_assert(BK_KS == 3, "three k-steps of 32 channels");
+        float* aw = affw + w * 2 * FC_H;
+        float va[16];
+        auto ks_vals = [&](int ks, float (&dvv)[8], float (&xhv)[8], bool stats) {
             const int c0 = ks * 32 + 8 * g4;
             float duv[8], gm[8];
             load8(ur + c0, duv);
-            load8(lnp + c0, gm);
+            if (stats) load8(lnp + c0, gm);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float dv = valid ? duv[j] : 0.f;
-                const float xh = (frag_get(xq[ks], j) - mean) * rstd;
-                const float a = row_sum16(dv * xh), bb = row_sum16(dv);
-                if (l15 == 0) {
-                    atomicAdd(aff + c0 + j, a);
-                    atomicAdd(aff + FC_H + c0 + j, bb);
+                dvv[j] = valid ? duv[j] : 0.f;
+                xhv[j] = (frag_get(xq[ks], j) - mean) * rstd;
+                if (stats) {
+                    m1 += dvv[j] * gm[j];
+                    m2 += dvv[j] * gm[j] * xhv[j];
                 }
-                m1 += dv * gm[j];
-                m2 += dv * gm[j] * xh;
             }
+        };
+        {
+            float dvv[8], xhv[8];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ks_vals(ks, dvv, xhv, true);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) va[8 * ks + j] = dvv[j] * xhv[j];
+            }
+            const float r0 = row_reduce16x16(va);  // lane l15: k-step l15 >> 3, channel l15 & 7 of the lane group
+            aw[(l15 >> 3) * 32 + 8 * g4 + (l15 & 7)] += r0;
+            ks_vals(2, dvv, xhv, true);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] = dvv[j] * xhv[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[8 + j] = dvv[j];
+            const float r1 = row_reduce16x16(va);
+            aw[(l15 >> 3) * FC_H + 64 + 8 * g4 + (l15 & 7)] += r1;  // lanes 0-7: gamma sums of k-step 2, lanes 8-15: its beta sums
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ks_vals(ks, dvv, xhv, false);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) va[8 * ks + j] = dvv[j];
+            }
+            const float r2 = row_reduce16x16(va);
+            aw[FC_H + (l15 >> 3) * 32 + 8 * g4 + (l15 & 7)] += r2;
         }
         m1 = wave_sum16(m1) * (1.0f / FC_H);
         m2 = wave_sum16(m2) * (1.0f / FC_H);
@@ -658,7 +690,12 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     }
     PHASE(6);
     lds_barrier();
-    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) part[(size_t)blockIdx.x * (WGF ? PROW : 3 * FC_H) + i] = aff[i];
+    for (int i = threadIdx.x; i < 3 * FC_H; i += blockDim.x) {
+        float v = aff[i];  // (PReLU slope sums: one contributor per channel)
+        if (i < 2 * FC_H)
+            for (int k = 0; k < NW; ++k) v += affw[k * 2 * FC_H + i];
+        part[(size_t)blockIdx.x * (WGF ? PROW : 3 * FC_H) + i] = v;
+    }
     PHASE(7);
     PHASE_END();
 }
@@ -669,7 +706,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
                        float* stats, void* dv, hipStream_t st) {
     const int mtf = cdiv(c.F, 16);
     if (mtf > FC_MTF_BIG) return NBSS_EUNSUPPORTED;
-    const size_t lds = (size_t)2 * (mtf * 16 + 4) * TT * FC_LD * sizeof(T) + 5 * FC_H * sizeof(float) + PHASE_LDS_BYTES;
+    const size_t lds = (size_t)2 * (mtf * 16 + 4) * TT * FC_LD * sizeof(T) + (5 + 2 * NW) * FC_H * sizeof(float) + PHASE_LDS_BYTES;
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     const int lw = which ? P_FC2_LN_W : P_FC1_LN_W, lb = which ? P_FC2_LN_B : P_FC1_LN_B, sl = which ? P_FC2_PRELU : P_FC1_PRELU;
     const T* pk = (const T*)packed;

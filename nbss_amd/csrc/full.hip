@@ -254,10 +254,11 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]   s, later dz
     T* sp = s + FL_SQ * TT * FK;                // [FM][TT][SQ]   s_pre
     T* z = sp + FM * TT * FL_SQ;                // [FM][TT][SQ]   z, later ds_pre
-    float* aff = reinterpret_cast<float*>(z + FM * TT * FL_SQ);  // [SQ] squeeze bias gradient sums (fp32)
+    float* aff = reinterpret_cast<float*>(z + FM * TT * FL_SQ);  // [SQ][17] squeeze bias gradient sums (fp32), one slot per (channel, frequency tile) task —
+                                                                 // added in tile order at the end (waves adding to one slot with LDS atomics: order-dependent bits)
     // the unsqueeze / squeeze weight fragments of the two row loops live in LDS, not in 60 registers per lane: with the LayerNorm affine
     // sums gone as well (below) the kernel fits 128 VGPRs and TWO workgroups share a CU — its row loops are bound by exposed latency
-    T* wl = reinterpret_cast<T*>(aff + FL_SQ);                         // [FL_WFR][512]
+    T* wl = reinterpret_cast<T*>(aff + FL_SQ * 17);                    // [FL_WFR][512]
     const int ntt = cdiv(T_, TT);
     const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
     const float* bu = lp.p[P_USQ_B];
 
     for (int i = tid; i < FL_SQ * TT * FK + 2 * FM * TT * FL_SQ; i += nthr) store1(s + i, 0.f);
-    for (int i = tid; i < FL_SQ; i += nthr) aff[i] = 0.f;
+    for (int i = tid; i < FL_SQ * 17; i += nthr) aff[i] = 0.f;
     {
         constexpr int VPF = 512 * (int)sizeof(T) / 16;  // 16-byte pieces per fragment (64 bf16, 128 fp32)
         for (int v = tid; v < FL_WFR * VPF; v += nthr) {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
             }
         }
         dbs = wave_sum64(dbs);
-        if (lane == 0) atomicAdd(aff + ch, dbs);
+        if (lane == 0) aff[ch * 17 + mt] = dbs;
         FL_TASK_LOOP_END
     }
     PHASE(7);
@@ -498,7 +499,11 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
     PHASE(9);
     lds_barrier();
     PHASE(10);
-    for (int i = tid; i < FL_SQ; i += nthr) part[(size_t)blockIdx.x * FL_SQ + i] = aff[i];
+    for (int i = tid; i < FL_SQ; i += nthr) {
+        float v = 0.f;
+        for (int mt = 0; mt < mtf; ++mt) v += aff[i * 17 + mt];
+        part[(size_t)blockIdx.x * FL_SQ + i] = v;
+    }
     PHASE_END();
 }
 PHASE_READER(nbss_phase_read_full_bwd)
@@ -541,7 +546,7 @@ static int full_tt(const nbss_cfg& c) {
 static size_t full_bwd_lds(const nbss_cfg& c, int tt) {
     const size_t esz = c.dtype == NBSS_BF16 ? 2 : 4;
     const int mtf = cdiv(c.F, 16), ksf = cdiv(c.F, 32);
-    return ((size_t)FL_SQ * tt * ksf * 32 + (size_t)2 * mtf * 16 * tt * FL_SQ + (size_t)FL_WFR * 512) * esz + FL_SQ * sizeof(float) + PHASE_LDS_BYTES;
+    return ((size_t)FL_SQ * tt * ksf * 32 + (size_t)2 * mtf * 16 * tt * FL_SQ + (size_t)FL_WFR * 512) * esz + FL_SQ * 17 * sizeof(float) + PHASE_LDS_BYTES;
 }
 // ... and the width the backward pass runs at: full_tt(), narrowed until the squeezed images fit (fp32 stream at F = 257: 213 KB at 8 frames, 136 KB at 4)
 static int full_bwd_width(const nbss_cfg& c) {

@@ -210,47 +210,70 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     }
 }
 
-// Second pass: block (tile, slice) sums its slice of the workgroups' partial D tiles (and the bias sums of the tile's rows) and adds
-//   dW[o][i] += D gamma[i] + db[o] beta[i],   db[o] (nt == 0 tiles),   dgamma[i] += sum_o W[o][i] D[o][i],   dbeta[i] += sum_o W[o][i] db[o]
-// W = the fp32 master weight [MA][96].  Tile tl = nt * MTA + mt; thread (r = tid >> 6, lane): row 16 mt + 4 (lane >> 4) + r, column 16 nt + (lane & 15).
-#define TW_RSL 8
-__global__ __launch_bounds__(256) void tailw_finalize_kernel(const float* __restrict__ part, int xb, int MTA, const float* __restrict__ W,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
-                                                             float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// Second pass: ONE block per (tile, accumulator register r) folds the workgroups' partial D values of its 64 elements (and the bias sums of their rows)
+// in a fixed order — thread (slice, lane) sums its slice of the workgroups, the four slices meet in LDS, slice 0 adds them in slice order — and adds
+//   dW[o][i] += D gamma[i] + db[o] beta[i],   db[o] (nt == 0 tiles)
+// with plain read-modify-writes (one owner per element).  The LayerNorm affine gradients  dgamma[i] = sum_o W[o][i] D[o][i],  dbeta[i] = sum_o W[o][i] db[o]
+// cross the blocks of a column: every block leaves its 16 + 16 column sums (over its four rows) in its own, now consumed, part of workgroup 0's partial
+// tile, and tailw_affine_kernel adds the 4 MTA blocks of each column in (tile, r) order.  No float atomics anywhere: bitwise repeatable parameter
+// gradients.  (256-thread blocks: see wgrad_reduce_kernel.)
+// W = the fp32 master weight [MA][96].  Tile tl = nt * MTA + mt; block (tl, r), lane: row 16 mt + 4 (lane >> 4) + r, column 16 nt + (lane & 15).
+#define TW_RSL 4
+__global__ __launch_bounds__(64 * TW_RSL) void tailw_finalize_kernel(float* __restrict__ part, int xb, int MTA, const float* __restrict__ W,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
+                                                                     float* __restrict__ dbias) {
     NBSS_LDS(smem);
-    float (*red)[4][16] = reinterpret_cast<float (*)[4][16]>(smem);  // [2][4 waves][16 columns]
-    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    const int ntot = gridDim.x, tl = blockIdx.x, nt = tl / MTA, mt = tl % MTA;
-    const int x0 = (int)((long)xb * blockIdx.y / gridDim.y), x1 = (int)((long)xb * (blockIdx.y + 1) / gridDim.y);
-    const float* pt = part + (size_t)tl * 256 + tid;
+    float* red = reinterpret_cast<float*>(smem);  // [slice][64] D | [slice][64] bias sums (per thread: its row's)
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, r = blockIdx.x & 3, l15 = lane & 15, g4 = lane >> 4;
+    const int nsl = xb < TW_RSL ? xb : TW_RSL;
+    const int ntot = gridDim.x >> 2, tl = blockIdx.x >> 2, nt = tl / MTA, mt = tl % MTA;
+    const int x0 = sl < nsl ? (int)((long)xb * sl / nsl) : 0, x1 = sl < nsl ? (int)((long)xb * (sl + 1) / nsl) : 0;
+    const float* pt = part + (size_t)tl * 256 + r * 64 + lane;
     const float* pb = part + (size_t)xb * ntot * 256 + (size_t)mt * 16 + 4 * g4 + r;  // bias sums of tile (nt = 0, mt): rows 4 g4 + r
     const size_t xs = (size_t)ntot * 256, bs = (size_t)ntot * 16;
-    float s0 = 0.f, s1 = 0.f, b0 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, b0 = 0.f, b1 = 0.f;
     int x = x0;
-    for (; x + 2 <= x1; x += 2) {
+    for (; x + 4 <= x1; x += 4) {
         s0 += pt[(size_t)x * xs];
         s1 += pt[(size_t)(x + 1) * xs];
+        s2 += pt[(size_t)(x + 2) * xs];
+        s3 += pt[(size_t)(x + 3) * xs];
         b0 += pb[(size_t)x * bs] + pb[(size_t)(x + 1) * bs];
+        b1 += pb[(size_t)(x + 2) * bs] + pb[(size_t)(x + 3) * bs];
     }
     for (; x < x1; ++x) {
         s0 += pt[(size_t)x * xs];
         b0 += pb[(size_t)x * bs];
     }
-    const float D = s0 + s1;
+    red[sl * 64 + lane] = (s0 + s1) + (s2 + s3);
+    red[(TW_RSL + sl) * 64 + lane] = b0 + b1;
+    __syncthreads();  // (also: every slice has read workgroup 0's values of this block, whose slot receives the column sums below)
+    if (sl) return;
+    const float D = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    const float bsum = (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]);
     const int o = mt * 16 + 4 * g4 + r, i = nt * 16 + l15;
     const float w = W[(size_t)o * TW_H + i];
-    atomicAdd(dW + (size_t)o * TW_H + i, D * gamma[i] + b0 * beta[i]);
-    if (nt == 0 && l15 == 0) atomicAdd(dbias + o, b0);
-    // column sums over the tile's 16 rows (4 lane groups x 4 waves)
-    float tg = w * D, tb = w * b0;
+    dW[(size_t)o * TW_H + i] += D * gamma[i] + bsum * beta[i];
+    if (nt == 0 && l15 == 0) dbias[o] += bsum;
+    // column sums over the block's four rows (the lane groups)
+    float tg = w * D, tb = w * bsum;
     tg += __shfl_xor(tg, 16); tg += __shfl_xor(tg, 32);
     tb += __shfl_xor(tb, 16); tb += __shfl_xor(tb, 32);
-    if (g4 == 0) { red[0][r][l15] = tg; red[1][r][l15] = tb; }
-    __syncthreads();
-    if (tid < 16) {
-        atomicAdd(dgamma + nt * 16 + tid, (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]));
-        atomicAdd(dbeta + nt * 16 + tid, (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]));
+    if (g4 == 0) {
+        part[(size_t)tl * 256 + r * 64 + l15] = tg;
+        part[(size_t)tl * 256 + r * 64 + 16 + l15] = tb;
     }
+}
+// dgamma[i] += the column sums tailw_finalize_kernel left, over the MTA tiles of column tile i / 16 and their four blocks in (tile, r) order; dbeta
+// likewise (threads 96 ..)
+__global__ __launch_bounds__(192) void tailw_affine_kernel(const float* __restrict__ part, int MTA, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int k = threadIdx.x / TW_H, i = threadIdx.x % TW_H, nt = i >> 4, j = i & 15;
+    float s = 0.f;
+    for (int mt = 0; mt < MTA; ++mt) {
+        const float* p = part + (size_t)(nt * MTA + mt) * 256 + 16 * k + j;
+        s += (p[0] + p[64]) + (p[128] + p[192]);
+    }
+    (k ? dbeta : dgamma)[i] += s;
 }
 
 template <int MA, int NBUF, int NTW>
@@ -284,8 +307,9 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
     if (e) return e;
     const hipStream_t gs = side_fork(sd, st);
     if (gs_out) *gs_out = gs;
-    NBSS_LAUNCH(tailw_finalize_kernel, dim3(ntot, grid < TW_RSL ? grid : TW_RSL), dim3(256), 2 * 4 * 16 * sizeof(float), gs, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias,
-                dgamma, dbeta);
+    NBSS_LAUNCH(tailw_finalize_kernel, dim3(4 * ntot), dim3(64 * TW_RSL), 2 * TW_RSL * 64 * sizeof(float), gs, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH(tailw_affine_kernel, dim3(1), dim3(2 * TW_H), 0, gs, (const float*)wgpart, MA / 16, dgamma, dbeta);
     return NBSS_CHECK_LAUNCH();
 }
 

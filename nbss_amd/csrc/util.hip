@@ -12,11 +12,13 @@ int memset_async_impl(void* p, size_t bytes, hipStream_t st) {
 #endif
 }
 
-// G[seg offsets] += sum over workgroups of part[wg][e].  Block (x, y) sums slice y of the workgroups for 128 elements
-// (coalesced over e) and adds it with one atomicAdd per element; the first version walked all ~1000 workgroups in 2-5 blocks
-// and cost 49 us per call (2 ms per training step).
+// G[seg offsets] += sum over workgroups of part[wg][e], in a fixed order (bitwise repeatable; round 4's version ended in one atomicAdd per slice
+// and element).  Two launches: (1) block (x, y) sums slice y of the workgroups' rows for 128 elements (coalesced over e, four rows in flight) and
+// leaves the slice sum IN PLACE in the slice's first row — those entries were this block's alone to read; (2) one thread per element adds the
+// slices' sums in slice order and adds the result to G with a plain read-modify-write (one owner per element; gradient launches of one parameter
+// are stream-ordered).  The very first version walked all ~1000 workgroups in 2-5 blocks and cost 49 us per call (2 ms per training step).
 #define AFF_SLICES 64
-__global__ void affine_reduce_kernel(const float* __restrict__ part, int nwg, int naff, AffSegs segs, float* __restrict__ G) {
+__global__ void affine_slices_kernel(float* __restrict__ part, int nwg, int naff) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= naff) return;
     const int w0 = (int)((long)nwg * blockIdx.y / gridDim.y), w1 = (int)((long)nwg * (blockIdx.y + 1) / gridDim.y);
@@ -29,19 +31,38 @@ __global__ void affine_reduce_kernel(const float* __restrict__ part, int nwg, in
         s3 += part[(size_t)(w + 3) * naff + e];
     }
     for (; w < w1; ++w) s0 += part[(size_t)w * naff + e];
+    part[(size_t)w0 * naff + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ void affine_final_kernel(const float* __restrict__ part, int nwg, int naff, int nsl, AffSegs segs, float* __restrict__ G) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= naff) return;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    int y = 0;
+    for (; y + 4 <= nsl; y += 4) {  // four loads in flight; the order of the adds is fixed
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[k] += part[(size_t)((long)nwg * (y + k) / nsl) * naff + e];
+    }
+    for (; y < nsl; ++y) s4[0] += part[(size_t)((long)nwg * y / nsl) * naff + e];
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     int r = e;
     for (int i = 0; i < segs.n; ++i) {
         if (r < segs.cnt[i]) {
-            atomicAdd(G + segs.off[i] + r, (s0 + s1) + (s2 + s3));
+            G[segs.off[i] + r] += s;
             return;
         }
         r -= segs.cnt[i];
     }
 }
 
+// (the partial rows are consumed: `part` is scratch that the next backward call of the sub-block overwrites)
 int affine_reduce_launch(const float* part, int nwg, const AffSegs& segs, float* G, hipStream_t st) {
     int naff = 0;
     for (int i = 0; i < segs.n; ++i) naff += segs.cnt[i];
-    NBSS_LAUNCH(affine_reduce_kernel, dim3((naff + 127) / 128, nwg < AFF_SLICES ? nwg : AFF_SLICES), dim3(128), 0, st, part, nwg, naff, segs, G);
+    const int nsl = nwg < AFF_SLICES ? nwg : AFF_SLICES;
+    if (nsl < 1) return NBSS_OK;
+    NBSS_LAUNCH(affine_slices_kernel, dim3((naff + 127) / 128, nsl), dim3(128), 0, st, const_cast<float*>(part), nwg, naff);
+    int e = NBSS_CHECK_LAUNCH();
+    if (e) return e;
+    NBSS_LAUNCH(affine_final_kernel, dim3((naff + 127) / 128), dim3(128), 0, st, part, nwg, naff, nsl, segs, G);
     return NBSS_CHECK_LAUNCH();
 }

@@ -544,28 +544,38 @@ __global__ __launch_bounds__(WG_THREADS, NS > 14 ? 1 : 2) void wgrad_tr3_kernel(
 }
 
 
-// Second pass of the two-stage flush: block (tile, slice, y) sums its slice of the x-blocks' partial tiles and adds the result
-// to dW (WG_RSL atomicAdds per element instead of one per workgroup).
-#define WG_RSL 8
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb, int nt_major) {
-    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+// Second pass of the two-stage flush: ONE block per (tile, accumulator register r, y) folds all x-blocks' partial values of its 64 elements in a fixed
+// order — thread (slice, lane) sums its slice of the x-blocks with eight loads in flight, the four slices meet in LDS, slice 0 adds them in slice
+// order and adds the result to dW with a plain read-modify-write (every dW element belongs to exactly one (tile, register, lane); gradient launches of
+// one parameter are stream-ordered).  No float atomics: the parameter gradient is bitwise repeatable.  256-thread blocks on purpose: the fold runs on
+// the gradient stream beside the main stream's one-workgroup-per-CU kernels, and a 1024-thread block (one block per whole tile, the first version of
+// this fold) waits for a CU to drain (measured: step 663.9 -> 651.4 utt/s).  (Round 4's fold: 8 blocks per tile, each ending in an atomicAdd per element.)
+#define WG_RSL 4
+__global__ __launch_bounds__(64 * WG_RSL) void wgrad_reduce_kernel(WgradArgs a, int xb, int nt_major) {
+    NBSS_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);  // [slice][64] sums | [slice][16] bias sums
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, r = blockIdx.x & 3, l15 = lane & 15, g4 = lane >> 4;
+    const int nsl = xb < WG_RSL ? xb : WG_RSL;  // slices that have x-blocks
     const int mg = a.MA / a.groups, ng = a.NB / a.groups;
     const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
     const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
     const int tpg = mtiles * ntiles;
     const bool per_group = gridDim.z > 1;
     const int ntot = (per_group ? 1 : a.groups) * tpg;
-    const int tl = blockIdx.x, y = blockIdx.z;
-    const int x0 = (int)((long)xb * blockIdx.y / gridDim.y), x1 = (int)((long)xb * (blockIdx.y + 1) / gridDim.y);
-    const float* pt = a.part + ((size_t)y * xb * ntot + tl) * 256 + tid;
+    const int tl = blockIdx.x >> 2, y = blockIdx.z;
+    const int x0 = sl < nsl ? (int)((long)xb * sl / nsl) : 0, x1 = sl < nsl ? (int)((long)xb * (sl + 1) / nsl) : 0;
+    const float* pt = a.part + ((size_t)y * xb * ntot + tl) * 256 + r * 64 + lane;
     const size_t xs = (size_t)ntot * 256;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
     int x = x0;
-    for (; x + 4 <= x1; x += 4) {
-        s0 += pt[(size_t)x * xs]; s1 += pt[(size_t)(x + 1) * xs]; s2 += pt[(size_t)(x + 2) * xs]; s3 += pt[(size_t)(x + 3) * xs];
+    for (; x + 8 <= x1; x += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += pt[(size_t)(x + k) * xs];
     }
-    for (; x < x1; ++x) s0 += pt[(size_t)x * xs];
-    const float sum = (s0 + s1) + (s2 + s3);
+    for (; x < x1; ++x) s[0] += pt[(size_t)x * xs];
+    red[sl * 64 + lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     int g, mt, nt;
     if (nt_major) {  // wgrad_tr3_kernel: tl = nt * nfirst + g * mtiles + mt
         const int nfirst = ntot / ntiles, gm = tl % nfirst;
@@ -575,25 +585,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs a, int xb, 
         g = tl / tpg; mt = rem / ntiles; nt = rem % ntiles;
     }
     if (per_group) g += y;
+    const bool bias = a.dbias && nt == 0 && r == 0;  // the tile's 16 bias sums: the r = 0 block
+    if (bias && lane < 16) {
+        const float* pbias = a.part + (size_t)gridDim.z * xb * ntot * 256 + ((size_t)y * xb * ntot + tl) * 16 + lane;
+        float b0 = 0.f, b1 = 0.f;
+        int xx = x0;
+        for (; xx + 2 <= x1; xx += 2) {
+            b0 += pbias[(size_t)xx * ntot * 16];
+            b1 += pbias[(size_t)(xx + 1) * ntot * 16];
+        }
+        if (xx < x1) b0 += pbias[(size_t)xx * ntot * 16];
+        red[WG_RSL * 64 + sl * 16 + lane] = b0 + b1;
+    }
+    __syncthreads();
+    if (sl) return;
+    const float sum = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
     const int q = nt * 16 + l15;
     if (q < nexp) {
         const int tap = q / ng, i = q % ng, m = mt * 16 + 4 * g4 + r;
-        if (m < mv && i < nv) atomicAdd(a.dW + ((size_t)(g * mv + m) * nv + i) * a.taps + tap, sum);
+        if (m < mv && i < nv) a.dW[((size_t)(g * mv + m) * nv + i) * a.taps + tap] += sum;
     }
-    if (a.dbias && nt == 0 && tid < 16) {
-        const float* pbias = a.part + (size_t)gridDim.z * xb * ntot * 256 + ((size_t)y * xb * ntot + tl) * 16 + tid;
-        float b = 0.f;
-        for (int xx = x0; xx < x1; ++xx) b += pbias[(size_t)xx * ntot * 16];
-        const int m = mt * 16 + tid;
-        if (m < mv) atomicAdd(a.dbias + (size_t)g * mv + m, b);
+    if (bias && lane < 16) {
+        const float b = (red[WG_RSL * 64 + lane] + red[WG_RSL * 64 + 16 + lane]) + (red[WG_RSL * 64 + 32 + lane] + red[WG_RSL * 64 + 48 + lane]);
+        const int m = mt * 16 + lane;
+        if (m < mv) a.dbias[(size_t)g * mv + m] += b;
     }
 }
 
-// second pass alone, for kernels that write partial tiles in wgrad_tr3_kernel's layout themselves (tailw.hip)
-int wgrad_reduce_launch(const WgradArgs& a, int ntot, int xb, hipStream_t st) {
-    NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot, xb < WG_RSL ? xb : WG_RSL, 1), dim3(256), 0, st, a, xb, 1);
+static int wgrad_reduce_go(const WgradArgs& a, int ntot, int xb, int ybl, int nt_major, hipStream_t st) {
+    NBSS_LAUNCH(wgrad_reduce_kernel, dim3(4 * ntot, 1, ybl), dim3(64 * WG_RSL), WG_RSL * 80 * sizeof(float), st, a, xb, nt_major);
     return NBSS_CHECK_LAUNCH();
 }
+
+// second pass alone, for kernels that write partial tiles in wgrad_tr3_kernel's layout themselves (wgrad_g.hip)
+int wgrad_reduce_launch(const WgradArgs& a, int ntot, int xb, hipStream_t st) { return wgrad_reduce_go(a, ntot, xb, 1, 1, st); }
 
 template <class T>
 static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
@@ -640,8 +665,7 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
             if ((e3 = NBSS_SET_MAX_LDS((wgrad_tr3_kernel<32, 27>), lds3))) return e3;
             NBSS_LAUNCH((wgrad_tr3_kernel<32, 27>), dim3(xb, 1), dim3(WG_THREADS), lds3, st, a);
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
-            NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot3, xb < WG_RSL ? xb : WG_RSL, 1), dim3(256), 0, st, a, xb, 1);
-            return NBSS_CHECK_LAUNCH();
+            return wgrad_reduce_go(a, ntot3, xb, 1, 1, st);
         }
     }
     if (nz == 1 && sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
@@ -687,8 +711,7 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
 #undef W3_GO
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
             if (a3.part && !WG_PROBE_HOST(a3, 1)) {
-                NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot3, xb < WG_RSL ? xb : WG_RSL, ybl), dim3(256), 0, st, a3, xb, 1);
-                return NBSS_CHECK_LAUNCH();
+                return wgrad_reduce_go(a3, ntot3, xb, ybl, 1, st);
             }
             return NBSS_OK;
         }
@@ -723,8 +746,7 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
 #undef WK_GO
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     if (ak.part) {
-        NBSS_LAUNCH(wgrad_reduce_kernel, dim3(ntot_k, xbl < WG_RSL ? xbl : WG_RSL, ybl), dim3(256), 0, st, ak, xbl, 0);
-        return NBSS_CHECK_LAUNCH();
+        return wgrad_reduce_go(ak, ntot_k, xbl, ybl, 0, st);
     }
     return NBSS_OK;
 }
