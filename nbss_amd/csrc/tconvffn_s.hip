@@ -1171,7 +1171,15 @@ struct TvW {
 // wrote S; H holds token t at row t + 1 (rows 0 and NT + 1 are zero).
 NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, int NS, int NSL, int mt, f32x4 (&acc)[5], f32x4& bsum) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    // which frame of the 32-frame k-step a lane's transposing read starts at.  Any map works as long as BOTH operands use it (the contraction sums over
+    // the frames).  The natural one — 4 g4 + (l15 >> 2): a 16-lane group reads four CONSECUTIVE rows — puts those rows 52 dwords apart (208-byte image
+    // rows): bank offsets {0, 20, 8, 28}, and the 8-dword pieces of rows 0 and 3 overlap (SQ_LDS_BANK_CONFLICT 37 % of the kernel's LDS cycles,
+    // round 4).  With every second row per group the offsets are {0, 8, 16, 24}: conflict-free.
+#ifdef NBSS_TV_ROWS_NATURAL
     const int rowoff = 4 * g4 + (l15 >> 2);
+#else
+    const int rowoff = 8 * (g4 >> 1) + (g4 & 1) + 2 * (l15 >> 2);
+#endif
     int boff[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
