@@ -267,6 +267,25 @@ int nbss_nb_group_batch_norm_bwd(int dtype, int B, int F, int T, int C, const vo
 int64_t nbss_nb_attention_bwd_ws_bytes(int dtype, int64_t nseq, int T, int H, int heads);
 int nbss_nb_attention_bwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* d_o, void* dqkv, void* ws, void* stream);
 
+/* ---- ... and for training the narrow-band conformer NBC (autograd of the reference's NBC.py:73-237; sequenced by nbss_amd/nbc.py) --------------------------
+ * attention_relpos_train: the relative-position attention with attention dropout (NBC.py:137): keep_bits [nseq][heads][T][ceil(T / 32)] uint32 — bit (j & 31) of
+ *   word j >> 5 of row i = probability (i, j) kept — or NULL; kept probabilities are scaled by keep_scale = 1 / (1 - p).  The caller draws the bits (any RNG):
+ *   forward and backward read the same tensor.
+ * attention_relpos_bwd: dqkv [nseq][T][3H] from qkv, pos, the biases, the bits and d_o; dpos [2T - 1][H], du_bias / dv_bias [H] (fp32) ACCUMULATED (sums over
+ *   all sequences, fixed order: no atomics).  ws: nbss_nb_attention_relpos_bwd_ws_bytes() bytes.
+ * group_norm_train: group_norm that also keeps (mean, rstd) per (sequence, group) in stats [nseq * groups][2];  group_norm_bwd: gradient through
+ *   y = SiLU(GroupNorm(x)) IN PLACE (dy_dx holds dy on entry, dx on return); dgamma / dbeta [C] accumulated. */
+int nbss_nb_attention_relpos_train(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias,
+                                   float scale, const uint32_t* keep_bits, float keep_scale, void* o, void* stream);
+int64_t nbss_nb_attention_relpos_bwd_ws_bytes(int64_t nseq, int T, int H, int heads);
+int nbss_nb_attention_relpos_bwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias, float scale,
+                                 const uint32_t* keep_bits, float keep_scale, const void* d_o, void* dqkv, float* dpos, float* du_bias, float* dv_bias, void* ws,
+                                 void* stream);
+int nbss_nb_group_norm_train(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* gamma, const float* beta, int act_out, void* y, float* stats,
+                             void* stream);
+int nbss_nb_group_norm_bwd(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* stats, const float* gamma, const float* beta, void* dy_dx,
+                           float* dgamma, float* dbeta, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */

@@ -2,8 +2,8 @@
 NBC.py:73-293): same constructor, same forward [B,F,T,dim_input] -> [B,F,T,dim_output], same state_dict keys
 (`encoder`, `sa_layers.N.self_attn.{query,key,value,pos,out}_proj / u_bias / v_bias / rel_pos.pe`, `linear1/2`, `norm1/2`,
 `conv.*`, `decoder`).  The position term of the scores is computed as one [T, 2T-1] product per head followed by a gather along
-the relative offset (the reference materialises a [T, T, heads, d] tensor).  Plain PyTorch; inference on a HIP
-device takes the native path of nbss_amd/nbc.py (see NBC.forward)."""
+the relative offset (the reference materialises a [T, T, heads, d] tensor).  Plain PyTorch on the CPU; on a HIP
+device inference AND training take the native path of nbss_amd/nbc.py (see NBC.forward)."""
 import math
 import os
 import warnings
@@ -170,10 +170,11 @@ class NBC(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         B, Fq, T, _ = x.shape
-        # inference on a HIP device (eval mode: the dropouts of the block are inactive; no autograd): the native forward over the nbss_nb_* building blocks
-        # (verified on the device in round 5, tests/test_nbc_native.py; NBSS_NBC_NATIVE=0 switches it off).  Training, the CPU and shapes the kernels
-        # refuse run the torch.nn modules below — on a device with one warning naming the reason.
-        if x.is_cuda and not self.training and not torch.is_grad_enabled():
+        # on a HIP device: the native path over the nbss_nb_* building blocks — the forward under torch.no_grad() (validate / test / predict), the training
+        # path otherwise (one autograd.Function: parameter gradients from the HIP backward blocks, dropout masks drawn from torch's generator; verified on
+        # the device in round 5, tests/test_nbc_native.py).  NBSS_NBC_NATIVE=0 switches it off; the CPU and shapes the kernels refuse run the torch.nn
+        # modules below — on a device with one warning naming the reason.
+        if x.is_cuda:
             why = None
             if os.environ.get("NBSS_NBC_NATIVE", "1") == "0":
                 why = "NBSS_NBC_NATIVE=0"
@@ -188,7 +189,17 @@ class NBC(nn.Module):
             if why is None:
                 from nbss_amd._lib import NbssError
                 try:
-                    return self._native().forward(x.contiguous())
+                    if not torch.is_grad_enabled():
+                        if not self.training:
+                            return self._native().forward(x.contiguous())
+                        why = "training mode under torch.no_grad(): the dropouts are active and there is nothing to differentiate"
+                    else:
+                        from nbss_amd.nbc import train_supported
+                        why = train_supported(self)
+                        if why is None and x.requires_grad:
+                            why = "the input requires a gradient (the native backward produces parameter gradients only)"
+                        if why is None:
+                            return self._native().forward_train(x.contiguous())
                 except NbssError as e:  # (a shape the kernels refuse, e.g. fp32 with head width 48 beyond ~200 frames: LDS)
                     why = str(e)
             self._torch_path_note(why)

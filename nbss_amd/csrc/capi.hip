@@ -49,7 +49,14 @@ int nb_layernorm_impl(int dtype, long rows, int C, const void* x, const float* g
 int nb_gbn_impl(int dtype, int B, int F, int Tn, int C, const void* x, const float* gamma, const float* beta, float eps, int act, void* y, hipStream_t st);
 int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, void* o, hipStream_t st);
 int nb_attention_relpos_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o,
-                                 hipStream_t st);
+                                 hipStream_t st, const uint32_t* mask, float keep);
+size_t nb_relpos_bwd_ws_bytes_impl(long nseq, int Tn, int H, int heads);
+int nb_attention_relpos_bwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale,
+                                 const uint32_t* mask, float keep, const void* dO, void* dqkv, float* dpos, float* du, float* dvb, void* ws, hipStream_t st);
+int nb_group_norm_train_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, float* stats,
+                             hipStream_t st);
+int nb_group_norm_bwd_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* stats, const float* gamma, const float* beta, void* dy_dx,
+                           float* dgamma, float* dbeta, hipStream_t st);
 int nb_group_norm_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, hipStream_t st);
 size_t nb_bwd_ws_bytes_impl(int M, int K, int groups, int taps);
 int nb_conv_t_train_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
@@ -519,7 +526,7 @@ int nbss_nb_attention_fwd(int dtype, int64_t nseq, int T, int H, int heads, cons
 int nbss_nb_attention_relpos_fwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias, float scale,
                                  void* o, void* stream) {
     if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !pos || !u_bias || !v_bias || !o) return NBSS_EINVAL;
-    return nb_attention_relpos_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, pos, u_bias, v_bias, scale, o, (hipStream_t)stream);
+    return nb_attention_relpos_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, pos, u_bias, v_bias, scale, o, (hipStream_t)stream, nullptr, 1.0f);
 }
 int nbss_nb_group_norm(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* gamma, const float* beta, int act_out, void* y, void* stream) {
     if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq * (int64_t)(groups > 0 ? groups : 1) >= (1LL << 31) || T <= 0 || C <= 0 || !x || !y || !gamma || !beta) return NBSS_EINVAL;
@@ -560,6 +567,37 @@ int64_t nbss_nb_attention_bwd_ws_bytes(int dtype, int64_t nseq, int T, int H, in
 int nbss_nb_attention_bwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* d_o, void* dqkv, void* ws, void* stream) {
     if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !d_o || !dqkv || !ws) return NBSS_EINVAL;
     return nb_attention_bwd_impl(dtype, (long)nseq, T, H, heads, qkv, d_o, dqkv, ws, (hipStream_t)stream);
+}
+int nbss_nb_attention_relpos_train(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias,
+                                   float scale, const uint32_t* keep_bits, float keep_scale, void* o, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !pos || !u_bias || !v_bias || !o) return NBSS_EINVAL;
+    return nb_attention_relpos_fwd_impl(dtype, (long)nseq, T, H, heads, qkv, pos, u_bias, v_bias, scale, o, (hipStream_t)stream, keep_bits, keep_bits ? keep_scale : 1.0f);
+}
+int64_t nbss_nb_attention_relpos_bwd_ws_bytes(int64_t nseq, int T, int H, int heads) {
+    if (nseq <= 0 || T <= 0 || H <= 0 || heads <= 0 || H % heads) return -1;
+    return (int64_t)nb_relpos_bwd_ws_bytes_impl((long)nseq, T, H, heads);
+}
+int nbss_nb_attention_relpos_bwd(int dtype, int64_t nseq, int T, int H, int heads, const void* qkv, const void* pos, const float* u_bias, const float* v_bias, float scale,
+                                 const uint32_t* keep_bits, float keep_scale, const void* d_o, void* dqkv, float* dpos, float* du_bias, float* dv_bias, void* ws,
+                                 void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= 65536 * 32768LL || T <= 0 || H <= 0 || !qkv || !pos || !u_bias || !v_bias || !d_o || !dqkv || !dpos || !du_bias ||
+        !dv_bias || !ws)
+        return NBSS_EINVAL;
+    return nb_attention_relpos_bwd_impl(dtype, (long)nseq, T, H, heads, qkv, pos, u_bias, v_bias, scale, keep_bits, keep_bits ? keep_scale : 1.0f, d_o, dqkv, dpos, du_bias,
+                                        dv_bias, ws, (hipStream_t)stream);
+}
+int nbss_nb_group_norm_train(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* gamma, const float* beta, int act_out, void* y, float* stats,
+                             void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq * (int64_t)(groups > 0 ? groups : 1) >= (1LL << 31) || T <= 0 || C <= 0 || !x || !y || !gamma || !beta || !stats)
+        return NBSS_EINVAL;
+    return nb_group_norm_train_impl(dtype, (long)nseq, T, C, groups, x, gamma, beta, act_out, y, stats, (hipStream_t)stream);
+}
+int nbss_nb_group_norm_bwd(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* stats, const float* gamma, const float* beta, void* dy_dx,
+                           float* dgamma, float* dbeta, void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq * (int64_t)(groups > 0 ? groups : 1) >= (1LL << 31) || T <= 0 || C <= 0 || !x || !stats || !gamma || !beta || !dy_dx ||
+        !dgamma || !dbeta)
+        return NBSS_EINVAL;
+    return nb_group_norm_bwd_impl(dtype, (long)nseq, T, C, groups, x, stats, gamma, beta, dy_dx, dgamma, dbeta, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {

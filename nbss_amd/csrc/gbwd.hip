@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_k_kernel(const T* __restri
 // along the diagonal r' = i - j + 15 (the reference materialises the whole [T][2T - 1] product and gathers).  T <= 256, DH in {24, 48}.
 template <class T, int DH>
 __global__ __launch_bounds__(GB_THREADS) void gb_attn_relpos_kernel(const T* __restrict__ qkv, const T* __restrict__ pos, const float* __restrict__ ub,
-                                                                    const float* __restrict__ vb, T* __restrict__ O, float scale, int Tn, int H, int heads) {
+                                                                    const float* __restrict__ vb, T* __restrict__ O, float scale, int Tn, int H, int heads,
+                                                                    const uint32_t* __restrict__ mask, float keep) {
     constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NTM = GA_TMAX / 16;
     NBSS_LDS(smem);
     const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32), NR = 2 * Tn - 1, RP = 32 * cdiv(NR + 32, 32);
@@ -1124,6 +1125,9 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_relpos_kernel(const T* __r
             }
         sum = wave_sum16(sum);
         const float inv = 1.0f / sum;
+        // training with attention dropout (NBC.py:137): keep-bits [nseq][heads][T][ceil(T / 32)], bit (j & 31) of word j >> 5 = key j of this query kept;
+        // kept probabilities are scaled by keep = 1 / (1 - p)
+        const uint32_t* mrow = mask ? mask + (((size_t)seq * heads + head) * Tn + (qv ? q : 0)) * ((Tn + 31) >> 5) : nullptr;
         f32x4 oacc[MTD];
 #pragma unroll
         for (int mt = 0; mt < MTD; ++mt) oacc[mt] = F32X4_ZERO;
@@ -1131,10 +1135,11 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_relpos_kernel(const T* __r
         for (int kk = 0; kk < NTM / 2; ++kk) {
             if (2 * kk < NT) {
                 f32x4 a0, a1;
+                const uint32_t mw = mrow ? mrow[kk] : 0xFFFFFFFFu;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a0[r] = st[2 * kk][r] * inv;
-                    a1[r] = st[2 * kk + 1][r] * inv;
+                    a0[r] = ((mw >> (4 * g4 + r)) & 1u) ? st[2 * kk][r] * inv * keep : 0.f;
+                    a1[r] = ((mw >> (16 + 4 * g4 + r)) & 1u) ? st[2 * kk + 1][r] * inv * keep : 0.f;
                 }
                 Frag<T> pf;
                 frag_from_c2(pf, a0, a1);
@@ -1153,6 +1158,509 @@ __global__ __launch_bounds__(GB_THREADS) void gb_attn_relpos_kernel(const T* __r
                 if (d < DH) store4(O + nq * H + head * DH + d, oacc[mt][0], oacc[mt][1], oacc[mt][2], oacc[mt][3]);
             }
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Backward of the relative-position attention (training of the narrow-band conformer NBC; reference models/arch/NBC.py:106-143 under autograd):
+//   S_ij = ((q_i + u) . k_j + (q_i + v) . P[i - j + T - 1]) scale,  p = softmax_j S,  pd = dropout(p) (keep-bits, x keep),  o_i = sum_j pd_ij v_j
+//   dpd_ij = dO_i . v_j     D_i = sum_j pd_ij dpd_ij     dS_ij = p_ij (m_ij keep dpd_ij - D_i) scale
+//   dv_j = sum_i pd_ij dO_i            dk_j = sum_i dS_ij (q_i + u)            dq_i = sum_j dS_ij (k_j + P[i - j + T - 1])
+//   du = sum_i sum_j dS_ij k_j         dvb = sum_i sum_j dS_ij P[i - j + T - 1]           dP[r] = sum_{i - j + T - 1 = r} dS_ij (q_i + v)
+// Three kernels per (sequence, head), each recomputing the 16 x 16 score tiles it needs in the loop order that keeps ITS accumulators in registers
+// (no atomics anywhere: every output has one owner, partial sums over the sequences are folded in a fixed order):
+//   rel_bwd_q: a wave owns 16 queries (softmax over the keys in registers, as the forward kernel): lse, D, dq and the per-(sequence, head) sums du / dvb;
+//   rel_bwd_k: a wave owns 16 keys: dk, dv (P rebuilt from lse);
+//   rel_bwd_r: a wave owns 16 offsets i - j in [16 b, 16 b + 15]: the tiles of the two tile diagonals b and b + 1 that hold them -> dP rows.
+// The position term of a score tile is the forward kernel's: two MFMA tiles M[r'][i] = P[rb + r'] . (q_i + v) through 2 KB of wave-private LDS, read
+// along the diagonal r' = i - j + 15.  Its transpose in the gradients — dS entries regrouped by offset — goes the other way through a wave-private
+// tile E: entries are scattered to (query, offset) resp. (offset, query) positions, read back as MFMA operands.
+// P lives in LDS behind 32 zero rows (and ahead of at least 48): row rb + r' always exists, rows outside the table meet zero dS entries.
+#define RB_PAD 32
+NBSS_HD int rel_rpp(int Tn) { return 32 * cdiv(RB_PAD + 2 * Tn - 1 + 48, 32); }
+template <class T, int DH>
+NBSS_DEV void rel_stage_pos(T* Ps, const T* __restrict__ pos, int H, int head, int Tn) {
+    const int RPP = rel_rpp(Tn);
+    for (int i = threadIdx.x; i < RB_PAD * DH; i += GB_THREADS) store1(Ps + i, 0.f);
+    ga_stage<T, DH>(Ps + RB_PAD * DH, pos + head * DH, H, 2 * Tn - 1, RPP - RB_PAD);
+}
+// rows t of the head's q slice + a per-head bias [DH] (q + u, q + v: rounded to the stream dtype like the forward's fragments), zero rows up to TP
+template <class T, int DH>
+NBSS_DEV void rel_stage_qb(T* img, const T* __restrict__ src, int ld, const float* __restrict__ bias, int Tn, int TP) {
+    for (int e = threadIdx.x; e < TP * DH; e += GB_THREADS) {
+        const int t = e / DH, d = e % DH;
+        store1(img + e, t < Tn ? load1(src + (size_t)t * ld + d) + bias[d] : 0.f);
+    }
+}
+// position term of the score tile (query tile it, key tile jt): M tiles of the offsets rbp .. rbp + 31 (rbp: padded P row of offset i - j = -15 of the tile
+// pair) for the 16 queries whose (q + v) fragments are qp -> Mb [32][16] fp32 (wave-private)
+template <class T, int DH>
+NBSS_DEV void rel_pos_tiles(const T* Ps, int rbp, const Frag<T>* qp, float* Mb) {
+    constexpr int KS = (DH + 31) / 32;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    f32x4 m0 = F32X4_ZERO, m1 = F32X4_ZERO;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = 32 * ks + 8 * g4;
+        Frag<T> p0, p1;
+        frag_zero(p0); frag_zero(p1);
+        if (d0 < DH) {
+            frag_load(p0, Ps + (size_t)(rbp + l15) * DH + d0);
+            frag_load(p1, Ps + (size_t)(rbp + 16 + l15) * DH + d0);
+        }
+        m0 = mma(p0, qp[ks], m0);
+        m1 = mma(p1, qp[ks], m1);
+    }
+    wave_lds_sync();  // (the previous tile's reads of Mb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Mb[(4 * g4 + r) * 16 + l15] = m0[r];
+        Mb[(16 + 4 * g4 + r) * 16 + l15] = m1[r];
+    }
+    wave_lds_sync();
+}
+NBSS_DEV bool rel_keep(const uint32_t* mrow, int key) { return !mrow || ((mrow[key >> 5] >> (key & 31)) & 1u); }
+
+struct RelBwd {
+    const void *qkv, *pos, *dO;
+    const float *ub, *vb;
+    const uint32_t* mask;
+    void* dqkv;
+    float *lse, *Dv, *duv_part, *dpos_part;
+    float scale, keep;
+    int Tn, H, heads;
+};
+
+template <class T, int DH>
+__global__ __launch_bounds__(GB_THREADS) void rel_bwd_q_kernel(RelBwd a) {
+    constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NTM = GA_TMAX / 16, NW = GB_THREADS / 64;
+    NBSS_LDS(smem);
+    const int Tn = a.Tn, H = a.H, heads = a.heads;
+    const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32), RPP = rel_rpp(Tn), MW = (Tn + 31) >> 5;
+    T* Ks = reinterpret_cast<T*>(smem);   // [TP][DH]
+    T* Vs = Ks + (size_t)TP * DH;         // [TP][DH]
+    T* Ps = Vs + (size_t)TP * DH;         // [RPP][DH]
+    float* Mb = reinterpret_cast<float*>(Ps + (size_t)RPP * DH) + wave_id() * 32 * 16;       // [32 offsets][16 queries] per wave
+    T* Eb = reinterpret_cast<T*>(reinterpret_cast<float*>(Ps + (size_t)RPP * DH) + NW * 32 * 16) + wave_id() * 16 * 32;  // [16 queries][32 offsets] per wave
+    float* red = reinterpret_cast<float*>(reinterpret_cast<T*>(reinterpret_cast<float*>(Ps + (size_t)RPP * DH) + NW * 32 * 16) + NW * 16 * 32);  // [NW][2][64]
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)seq * Tn;
+    const int ld = 3 * H;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const T* dO = reinterpret_cast<const T*>(a.dO);
+    T* dqkv = reinterpret_cast<T*>(a.dqkv);
+    ga_stage<T, DH>(Ks, qkv + n0 * ld + H + head * DH, ld, Tn, TP);
+    ga_stage<T, DH>(Vs, qkv + n0 * ld + 2 * H + head * DH, ld, Tn, TP);
+    rel_stage_pos<T, DH>(Ps, reinterpret_cast<const T*>(a.pos), H, head, Tn);
+    __syncthreads();
+    const float scale = a.scale, keep = a.keep;
+    f32x4 usum[MTD], vsum[MTD];  // sums over this wave's queries of the content / position parts of dq: the (sequence, head) share of du / dvb
+#pragma unroll
+    for (int mt = 0; mt < MTD; ++mt) usum[mt] = vsum[mt] = F32X4_ZERO;
+    for (int qt = w; qt < NT; qt += NW) {
+        const int q = qt * 16 + l15;
+        const bool qv = q < Tn;
+        const size_t nq = n0 + (qv ? q : 0);
+        const uint32_t* mrow = a.mask ? a.mask + (((size_t)seq * heads + head) * Tn + (qv ? q : 0)) * MW : nullptr;
+        Frag<T> qc[KS], qp[KS], dof[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = 32 * ks + 8 * g4;
+            frag_zero(qc[ks]); frag_zero(qp[ks]); frag_zero(dof[ks]);
+            if (qv && d0 < DH) {
+                float qf[8];
+                load8(qkv + nq * ld + head * DH + d0, qf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    frag_set(qc[ks], j, qf[j] + a.ub[head * DH + d0 + j]);
+                    frag_set(qp[ks], j, qf[j] + a.vb[head * DH + d0 + j]);
+                }
+                frag_load(dof[ks], dO + nq * H + head * DH + d0);
+            }
+        }
+        // S^T and dPd^T tiles: rows = keys 16 jt + 4 g4 + r, column = the lane's query
+        f32x4 st[NTM], dp[NTM];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt) {
+            st[jt] = F32X4_ZERO;
+            dp[jt] = F32X4_ZERO;
+            if (jt < NT) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d0 = 32 * ks + 8 * g4;
+                    Frag<T> kf, vf;
+                    frag_zero(kf); frag_zero(vf);
+                    if (d0 < DH) {
+                        frag_load(kf, Ks + (size_t)(16 * jt + l15) * DH + d0);
+                        frag_load(vf, Vs + (size_t)(16 * jt + l15) * DH + d0);
+                    }
+                    st[jt] = mma(kf, qc[ks], st[jt]);
+                    dp[jt] = mma(vf, dof[ks], dp[jt]);
+                }
+                rel_pos_tiles<T, DH>(Ps, RB_PAD + 16 * qt - 16 * jt - 15 + Tn - 1, qp, Mb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool kv = 16 * jt + 4 * g4 + r < Tn;
+                    const float pt = Mb[(l15 - (4 * g4 + r) + 15) * 16 + l15];
+                    st[jt][r] = kv ? (st[jt][r] + pt) * scale : -3.0e38f;
+                    mx = fmaxf(mx, st[jt][r]);
+                }
+            }
+        }
+        mx = wave_max16(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kv = jt < NT && 16 * jt + 4 * g4 + r < Tn;
+                st[jt][r] = kv ? __expf(st[jt][r] - mx) : 0.f;
+                sum += st[jt][r];
+            }
+        sum = wave_sum16(sum);
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NTM; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[jt][r] *= inv;  // p^T
+                const bool kp = jt < NT && rel_keep(mrow, 16 * jt + 4 * g4 + r < Tn ? 16 * jt + 4 * g4 + r : 0);
+                dp[jt][r] = kp ? dp[jt][r] * keep : 0.f;  // m keep dpd
+                dsum += st[jt][r] * dp[jt][r];
+            }
+        dsum = wave_sum16(dsum);  // D = rowsum(pd dpd) = dO . o
+        if (qv && g4 == 0) {
+            a.lse[nq * heads + head] = mx + __logf(sum);
+            a.Dv[nq * heads + head] = dsum;
+        }
+        f32x4 qc_acc[MTD], qp_acc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) qc_acc[mt] = qp_acc[mt] = F32X4_ZERO;
+#pragma unroll
+        for (int kk = 0; kk < NTM / 2; ++kk) {
+            if (2 * kk < NT) {
+                f32x4 ds[2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ds[0][r] = st[2 * kk][r] * (dp[2 * kk][r] - dsum) * scale;
+                    ds[1][r] = st[2 * kk + 1][r] * (dp[2 * kk + 1][r] - dsum) * scale;
+                }
+                Frag<T> dsf;
+                frag_from_c2(dsf, ds[0], ds[1]);
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) {
+                    Frag<T> kt;
+                    ga_frag_t<T, DH>(kt, Ks, 32 * kk, mt);
+                    qc_acc[mt] = mma(kt, dsf, qc_acc[mt]);
+                }
+                // position part, tile by tile: E[query][offset r' = i - j + 15] = dS -> dq += P[rb + r']^T E
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int jt = 2 * kk + h2;
+                    if (jt < NT) {
+                        wave_lds_sync();
+                        for (int i = lane; i < 16 * 32; i += 64) store1(Eb + i, 0.f);
+                        wave_lds_sync();
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) store1(Eb + l15 * 32 + (l15 - (4 * g4 + r) + 15), ds[h2][r]);
+                        wave_lds_sync();
+                        Frag<T> ef;
+                        frag_load_lo(ef, Eb + l15 * 32 + 4 * g4);
+                        frag_load_hi(ef, Eb + l15 * 32 + 16 + 4 * g4);
+                        const int rbp = RB_PAD + 16 * qt - 16 * jt - 15 + Tn - 1;
+#pragma unroll
+                        for (int mt = 0; mt < MTD; ++mt) {
+                            Frag<T> pt;
+                            ga_frag_t<T, DH>(pt, Ps, rbp, mt);
+                            qp_acc[mt] = mma(pt, ef, qp_acc[mt]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) {
+            const int d = 16 * mt + 4 * g4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                usum[mt][r] += qc_acc[mt][r];
+                vsum[mt][r] += qp_acc[mt][r];
+            }
+            if (qv && d < DH)
+                store4(dqkv + nq * ld + head * DH + d, qc_acc[mt][0] + qp_acc[mt][0], qc_acc[mt][1] + qp_acc[mt][1], qc_acc[mt][2] + qp_acc[mt][2],
+                       qc_acc[mt][3] + qp_acc[mt][3]);
+        }
+    }
+    // du / dvb share of this (sequence, head): rows d = 16 mt + 4 g4 + r summed over the lanes' queries, then over the waves in wave order
+#pragma unroll
+    for (int mt = 0; mt < MTD; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float us = row_sum16(usum[mt][r]), vs = row_sum16(vsum[mt][r]);
+            if (l15 == 0) {
+                red[(w * 2 + 0) * 64 + 16 * mt + 4 * g4 + r] = us;
+                red[(w * 2 + 1) * 64 + 16 * mt + 4 * g4 + r] = vs;
+            }
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * DH; i += GB_THREADS) {
+        const int k = i / DH, d = i % DH;
+        float v = 0.f;
+        for (int ww = 0; ww < NW; ++ww) v += red[(ww * 2 + k) * 64 + d];
+        a.duv_part[(((size_t)seq * heads + head) * 2 + k) * DH + d] = v;
+    }
+}
+
+// shared by rel_bwd_k / rel_bwd_r: dS and pd of the score tile (queries 16 it + 4 g4 + r, key 16 jt + l15) from the LDS images
+template <class T, int DH>
+struct RelImg {
+    const T *Qu, *Qv, *dOs, *Ps;  // LDS images (Qu / dOs: rel_bwd_k only)
+    const T *gq, *gk, *gv, *gdo;  // rel_bwd_r: the head's q / k / v rows (stride 3 H) and dO rows (stride H) of this sequence in global memory (L2-resident:
+    const float* ub;              //   five more [T][dh] images would not fit the LDS beside P in the fp32 stream); ub: the head's u bias
+    int H;
+    const float *ls, *Ds;
+    const uint32_t* Mk;  // [Tn][MW] keep-bits of this (sequence, head) or nullptr
+    float* Mb;
+    int Tn, MW;
+    float scale, keep;
+};
+// KEYS_IN_REGS (rel_bwd_k): kfr / vfr are the key tile's fragments (natural K = d order) and the query-side operands come from the LDS images; else
+// (rel_bwd_r) everything but (q + v) is read from global memory
+template <class T, int DH, bool KEYS_IN_REGS>
+NBSS_DEV void rel_tile_ds(const RelImg<T, DH>& g, int it, int jt, const Frag<T>* kfr, const Frag<T>* vfr, f32x4& pd, f32x4& ds) {
+    constexpr int KS = (DH + 31) / 32;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
+    Frag<T> qvf[KS];
+    f32x4 s = F32X4_ZERO, dpv = F32X4_ZERO;
+    const int qrow = 16 * it + l15, krow = 16 * jt + l15;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = 32 * ks + 8 * g4;
+        Frag<T> quf, dof, kf, vf;
+        frag_zero(quf); frag_zero(dof); frag_zero(qvf[ks]); frag_zero(kf); frag_zero(vf);
+        if (d0 < DH) {
+            frag_load(qvf[ks], g.Qv + (size_t)qrow * DH + d0);
+            if (KEYS_IN_REGS) {
+                frag_load(quf, g.Qu + (size_t)qrow * DH + d0);
+                frag_load(dof, g.dOs + (size_t)qrow * DH + d0);
+            } else {
+                if (qrow < g.Tn) {
+                    float qf[8];
+                    load8(g.gq + (size_t)qrow * 3 * g.H + d0, qf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) frag_set(quf, j, qf[j] + g.ub[d0 + j]);
+                    frag_load(dof, g.gdo + (size_t)qrow * g.H + d0);
+                }
+                if (krow < g.Tn) {
+                    frag_load(kf, g.gk + (size_t)krow * 3 * g.H + d0);
+                    frag_load(vf, g.gv + (size_t)krow * 3 * g.H + d0);
+                }
+            }
+        }
+        s = mma(quf, KEYS_IN_REGS ? kfr[ks] : kf, s);
+        dpv = mma(dof, KEYS_IN_REGS ? vfr[ks] : vf, dpv);
+    }
+    rel_pos_tiles<T, DH>(g.Ps, RB_PAD + 16 * it - 16 * jt - 15 + g.Tn - 1, qvf, g.Mb);
+    const int key = 16 * jt + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iloc = 4 * g4 + r, q = 16 * it + iloc;
+        const bool ok = key < g.Tn && q < g.Tn;
+        const float pt = g.Mb[(iloc - l15 + 15) * 16 + iloc];
+        const float p = ok ? __expf((s[r] + pt) * g.scale - g.ls[q]) : 0.f;
+        const bool kp = ok && (!g.Mk || ((g.Mk[(size_t)q * g.MW + (key >> 5)] >> (key & 31)) & 1u));
+        const float dm = kp ? dpv[r] * g.keep : 0.f;
+        pd[r] = kp ? p * g.keep : 0.f;
+        ds[r] = p * (dm - g.Ds[q]) * g.scale;
+    }
+}
+template <class T, int DH>
+NBSS_DEV void rel_stage_common(const RelBwd& a, int seq, int head, T* Qu, T* Qv, T* dOs, T* Ps, float* ls, float* Ds, uint32_t* Mk) {
+    const int Tn = a.Tn, H = a.H, heads = a.heads, TP = 32 * cdiv(Tn, 32) + 16, MW = (Tn + 31) >> 5;
+    const size_t n0 = (size_t)seq * Tn;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    if (Qu) rel_stage_qb<T, DH>(Qu, qkv + n0 * 3 * H + head * DH, 3 * H, a.ub + head * DH, Tn, TP);
+    rel_stage_qb<T, DH>(Qv, qkv + n0 * 3 * H + head * DH, 3 * H, a.vb + head * DH, Tn, TP);
+    if (dOs) ga_stage<T, DH>(dOs, reinterpret_cast<const T*>(a.dO) + n0 * H + head * DH, H, Tn, TP);
+    rel_stage_pos<T, DH>(Ps, reinterpret_cast<const T*>(a.pos), H, head, Tn);
+    for (int t = threadIdx.x; t < TP; t += GB_THREADS) {
+        ls[t] = t < Tn ? a.lse[(n0 + t) * heads + head] : 0.f;
+        Ds[t] = t < Tn ? a.Dv[(n0 + t) * heads + head] : 0.f;
+    }
+    if (a.mask)
+        for (int i = threadIdx.x; i < Tn * MW; i += GB_THREADS) Mk[i] = a.mask[((size_t)seq * heads + head) * Tn * MW + i];
+}
+
+template <class T, int DH>
+__global__ __launch_bounds__(GB_THREADS) void rel_bwd_k_kernel(RelBwd a) {
+    constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NW = GB_THREADS / 64;
+    NBSS_LDS(smem);
+    const int Tn = a.Tn, H = a.H;
+    const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32) + 16, RPP = rel_rpp(Tn), MW = (Tn + 31) >> 5;
+    T* Qu = reinterpret_cast<T*>(smem);
+    T* Qv = Qu + (size_t)TP * DH;
+    T* dOs = Qv + (size_t)TP * DH;
+    T* Ps = dOs + (size_t)TP * DH;
+    float* ls = reinterpret_cast<float*>(Ps + (size_t)RPP * DH);
+    float* Ds = ls + TP;
+    float* Mball = Ds + TP;
+    uint32_t* Mk = reinterpret_cast<uint32_t*>(Mball + NW * 32 * 16);
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)seq * Tn;
+    const int ld = 3 * H;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    T* dqkv = reinterpret_cast<T*>(a.dqkv);
+    rel_stage_common<T, DH>(a, seq, head, Qu, Qv, dOs, Ps, ls, Ds, Mk);
+    __syncthreads();
+    RelImg<T, DH> g = {Qu, Qv, dOs, Ps, nullptr, nullptr, nullptr, nullptr, nullptr, H, ls, Ds, a.mask ? Mk : nullptr, Mball + w * 32 * 16, Tn, MW, a.scale, a.keep};
+    for (int kt = w; kt < NT; kt += NW) {
+        const int key = kt * 16 + l15;
+        const bool kv = key < Tn;
+        const size_t nk = n0 + (kv ? key : 0);
+        Frag<T> kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = 32 * ks + 8 * g4;
+            frag_zero(kf[ks]); frag_zero(vf[ks]);
+            if (kv && d0 < DH) {
+                frag_load(kf[ks], qkv + nk * ld + H + head * DH + d0);
+                frag_load(vf[ks], qkv + nk * ld + 2 * H + head * DH + d0);
+            }
+        }
+        f32x4 kacc[MTD], vacc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) kacc[mt] = vacc[mt] = F32X4_ZERO;
+        for (int kk = 0; 2 * kk < NT; ++kk) {
+            f32x4 pd[2], ds[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) rel_tile_ds<T, DH, true>(g, 2 * kk + h2, kt, kf, vf, pd[h2], ds[h2]);  // (a query tile past NT: all entries masked)
+            Frag<T> pf, dsf;
+            frag_from_c2(pf, pd[0], pd[1]);
+            frag_from_c2(dsf, ds[0], ds[1]);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                Frag<T> dot, qt;
+                ga_frag_t<T, DH>(dot, dOs, 32 * kk, mt);
+                ga_frag_t<T, DH>(qt, Qu, 32 * kk, mt);
+                vacc[mt] = mma(dot, pf, vacc[mt]);
+                kacc[mt] = mma(qt, dsf, kacc[mt]);
+            }
+        }
+        if (kv) {
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int d = 16 * mt + 4 * g4;
+                if (d < DH) {
+                    store4(dqkv + nk * ld + H + head * DH + d, kacc[mt][0], kacc[mt][1], kacc[mt][2], kacc[mt][3]);
+                    store4(dqkv + nk * ld + 2 * H + head * DH + d, vacc[mt][0], vacc[mt][1], vacc[mt][2], vacc[mt][3]);
+                }
+            }
+        }
+    }
+}
+
+// dP rows: wave = offset block b (offsets 16 b .. 16 b + 15, b = -NT .. NT - 1).  They live in the tiles of the diagonals it - jt = b (entries with
+// i_loc >= j_loc: offset 16 b + i_loc - j_loc) and it - jt = b + 1 (entries with i_loc < j_loc: offset 16 (b + 1) + i_loc - j_loc).  Two tiles of a diagonal
+// at a time: Et[offset][32 queries] (wave-private), dP^T[d][offset] += (q + v)^T[d][32 queries] Et^T — K = the 32 queries.
+// Output: dpos_part[seq][head][32 NT offsets rows: offset + 16 NT][DH] (every row has one owner; folded over the sequences by rel_fold_kernel).
+template <class T, int DH>
+__global__ __launch_bounds__(GB_THREADS) void rel_bwd_r_kernel(RelBwd a) {
+    constexpr int KS = (DH + 31) / 32, MTD = (DH + 15) / 16, NW = GB_THREADS / 64;
+    NBSS_LDS(smem);
+    const int Tn = a.Tn, heads = a.heads;
+    const int NT = cdiv(Tn, 16), TP = 32 * cdiv(Tn, 32) + 16, RPP = rel_rpp(Tn), MW = (Tn + 31) >> 5;
+    T* Qv = reinterpret_cast<T*>(smem);
+    T* Ps = Qv + (size_t)TP * DH;
+    float* ls = reinterpret_cast<float*>(Ps + (size_t)RPP * DH);
+    float* Ds = ls + TP;
+    float* Mball = Ds + TP;
+    uint32_t* Mk = reinterpret_cast<uint32_t*>(Mball + NW * 32 * 16);
+    T* Et = reinterpret_cast<T*>(Mk + (a.mask ? (Tn * MW + 3) & ~3 : 0)) + wave_id() * 16 * 32;  // (16-byte aligned: vector reads)
+    const int seq = blockIdx.x, head = blockIdx.y, H = a.H;
+    const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
+    const size_t n0 = (size_t)seq * Tn;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv) + n0 * 3 * H + head * DH;
+    rel_stage_common<T, DH>(a, seq, head, (T*)nullptr, Qv, (T*)nullptr, Ps, ls, Ds, Mk);
+    __syncthreads();
+    RelImg<T, DH> g = {nullptr, Qv, nullptr, Ps, qkv, qkv + H, qkv + 2 * H, reinterpret_cast<const T*>(a.dO) + n0 * H + head * DH, a.ub + head * DH, H,
+                       ls, Ds, a.mask ? Mk : nullptr, Mball + w * 32 * 16, Tn, MW, a.scale, a.keep};
+    float* out = a.dpos_part + ((size_t)seq * heads + head) * 32 * NT * DH;
+    for (int b = -NT + w; b < NT; b += NW) {
+        f32x4 acc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) acc[mt] = F32X4_ZERO;
+        for (int dg = 0; dg < 2; ++dg) {
+            const int delta = b + dg;  // it - jt
+            const int it_lo = delta > 0 ? delta : 0, it_hi = delta > 0 ? NT : NT + delta;  // tiles (it, it - delta) with both indices in [0, NT)
+            for (int it = it_lo & ~1; it < it_hi; it += 2) {  // pairs (it, it + 1): the K = 32 queries 16 it .. 16 it + 31
+                wave_lds_sync();
+                for (int i = lane; i < 16 * 32; i += 64) store1(Et + i, 0.f);
+                wave_lds_sync();
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int i2 = it + h2, jt = i2 - delta;
+                    if (i2 >= it_lo && i2 < it_hi) {
+                        f32x4 pd, ds;
+                        rel_tile_ds<T, DH, false>(g, i2, jt, nullptr, nullptr, pd, ds);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int iloc = 4 * g4 + r;
+                            const int off = dg == 0 ? iloc - l15 : 16 + iloc - l15;  // offset inside the block
+                            if (off >= 0 && off < 16) store1(Et + off * 32 + 16 * h2 + iloc, ds[r]);
+                        }
+                    }
+                }
+                wave_lds_sync();
+                Frag<T> ef;
+                frag_load_lo(ef, Et + l15 * 32 + 4 * g4);
+                frag_load_hi(ef, Et + l15 * 32 + 16 + 4 * g4);
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) {
+                    Frag<T> qt;
+                    ga_frag_t<T, DH>(qt, Qv, 16 * it, mt);
+                    acc[mt] = mma(qt, ef, acc[mt]);
+                }
+            }
+        }
+        // acc[mt][r]: channel d = 16 mt + 4 g4 + r, offset 16 b + l15
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * mt + 4 * g4 + r;
+                if (d < DH) out[(size_t)(16 * (b + NT) + l15) * DH + d] = acc[mt][r];
+            }
+    }
+}
+
+// fold over the sequences, in sequence order: dpos[r][head DH + d] += sum_seq dpos_part[seq][head][r - (Tn - 1) + 16 NT][d];  du / dvb [head][DH] likewise
+__global__ void rel_fold_kernel(const float* __restrict__ dpos_part, const float* __restrict__ duv_part, long nseq, int Tn, int H, int heads, float* __restrict__ dpos,
+                                float* __restrict__ du, float* __restrict__ dvb) {
+    const int DH = H / heads, NT = cdiv(Tn, 16), NR = 2 * Tn - 1;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x, npos = (long)NR * H;
+    if (e < npos) {
+        const int r = (int)(e / H), c = (int)(e % H), head = c / DH, d = c % DH;
+        const float* p = dpos_part + ((size_t)head * 32 * NT + (r - (Tn - 1) + 16 * NT)) * DH + d;
+        const size_t ss = (size_t)heads * 32 * NT * DH;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long q = 0;
+        for (; q + 4 <= nseq; q += 4) {
+            s0 += p[q * ss]; s1 += p[(q + 1) * ss]; s2 += p[(q + 2) * ss]; s3 += p[(q + 3) * ss];
+        }
+        for (; q < nseq; ++q) s0 += p[q * ss];
+        dpos[e] += (s0 + s1) + (s2 + s3);
+    } else if (e < npos + 2 * H) {
+        const int i = (int)(e - npos), k = i / H, c = i % H, head = c / DH, d = c % DH;
+        const float* p = duv_part + ((size_t)head * 2 + k) * DH + d;
+        const size_t ss = (size_t)heads * 2 * DH;
+        float s = 0.f;
+        for (long q = 0; q < nseq; ++q) s += p[q * ss];
+        (k ? dvb : du)[c] += s;
     }
 }
 
@@ -1782,24 +2290,95 @@ int nb_attention_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const 
 }
 
 template <class T, int DH>
-static int nb_attn_relpos(long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o, hipStream_t st) {
+static int nb_attn_relpos(long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o, hipStream_t st,
+                          const uint32_t* mask, float keep) {
     const int TP = 32 * cdiv(Tn, 32), RP = 32 * cdiv(2 * Tn - 1 + 32, 32);
     const size_t lds = (size_t)(2 * TP + RP) * DH * sizeof(T) + (size_t)(GB_THREADS / 64) * 32 * 16 * sizeof(float) + 64;
     if (Tn > GA_TMAX || lds > 160 * 1024) return NBSS_EUNSUPPORTED;
     int e = NBSS_SET_MAX_LDS((gb_attn_relpos_kernel<T, DH>), lds);
     if (e) return e;
-    NBSS_LAUNCH((gb_attn_relpos_kernel<T, DH>), dim3((unsigned)nseq, heads), dim3(GB_THREADS), lds, st, (const T*)qkv, (const T*)pos, ub, vb, (T*)o, scale, Tn, H, heads);
+    NBSS_LAUNCH((gb_attn_relpos_kernel<T, DH>), dim3((unsigned)nseq, heads), dim3(GB_THREADS), lds, st, (const T*)qkv, (const T*)pos, ub, vb, (T*)o, scale, Tn, H, heads, mask,
+                keep);
     return NBSS_CHECK_LAUNCH();
 }
 int nb_attention_relpos_fwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale, void* o,
-                                 hipStream_t st) {
+                                 hipStream_t st, const uint32_t* mask, float keep) {
     if (heads <= 0 || H % heads) return NBSS_EINVAL;
     const int dh = H / heads;
     if (dh == 48)
-        return dtype == NBSS_BF16 ? nb_attn_relpos<bf16_t, 48>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st) : nb_attn_relpos<float, 48>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st);
+        return dtype == NBSS_BF16 ? nb_attn_relpos<bf16_t, 48>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st, mask, keep)
+                                  : nb_attn_relpos<float, 48>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st, mask, keep);
     if (dh == 24)
-        return dtype == NBSS_BF16 ? nb_attn_relpos<bf16_t, 24>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st) : nb_attn_relpos<float, 24>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st);
+        return dtype == NBSS_BF16 ? nb_attn_relpos<bf16_t, 24>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st, mask, keep)
+                                  : nb_attn_relpos<float, 24>(nseq, Tn, H, heads, qkv, pos, ub, vb, scale, o, st, mask, keep);
     return NBSS_EUNSUPPORTED;
+}
+// backward of the relative-position attention: ws = lse [N][heads] | D [N][heads] | du/dvb shares [nseq][heads][2][dh] | dP shares [nseq][heads][32 NT][dh] (fp32)
+size_t nb_relpos_bwd_ws_bytes_impl(long nseq, int Tn, int H, int heads) {
+    const size_t N = (size_t)nseq * Tn, NT = cdiv(Tn, 16);
+    return 2 * ws_align(N * heads * sizeof(float)) + ws_align((size_t)nseq * 2 * H * sizeof(float)) + ws_align((size_t)nseq * 32 * NT * H * sizeof(float));
+}
+template <class T, int DH>
+static int nb_relpos_bwd(long nseq, const RelBwd& a0, float* dpos, float* du, float* dvb, void* ws, hipStream_t st) {
+    RelBwd a = a0;
+    const int Tn = a.Tn, H = a.H, heads = a.heads, NW = GB_THREADS / 64;
+    const size_t N = (size_t)nseq * Tn, NT = cdiv(Tn, 16);
+    char* w = (char*)ws;
+    a.lse = (float*)w; w += ws_align(N * heads * sizeof(float));
+    a.Dv = (float*)w; w += ws_align(N * heads * sizeof(float));
+    a.duv_part = (float*)w; w += ws_align((size_t)nseq * 2 * H * sizeof(float));
+    a.dpos_part = (float*)w;
+    const size_t TPq = 32 * cdiv(Tn, 32), TP = TPq + 16, RPP = rel_rpp(Tn), MW = (Tn + 31) / 32, mk = a.mask ? (((size_t)Tn * MW + 3) & ~(size_t)3) * 4 : 0;
+    const size_t lq = (2 * TPq + RPP) * DH * sizeof(T) + NW * 512 * sizeof(float) + NW * 512 * sizeof(T) + NW * 2 * 64 * sizeof(float);
+    const size_t lk = (3 * TP + RPP) * DH * sizeof(T) + 2 * TP * sizeof(float) + NW * 512 * sizeof(float) + mk;
+    const size_t lr = (TP + RPP) * DH * sizeof(T) + 2 * TP * sizeof(float) + NW * 512 * sizeof(float) + mk + NW * 512 * sizeof(T);
+    if (Tn > GA_TMAX || lq > 160 * 1024 || lk > 160 * 1024 || lr > 160 * 1024) return NBSS_EUNSUPPORTED;
+    int e;
+    if ((e = NBSS_SET_MAX_LDS((rel_bwd_q_kernel<T, DH>), lq))) return e;
+    if ((e = NBSS_SET_MAX_LDS((rel_bwd_k_kernel<T, DH>), lk))) return e;
+    if ((e = NBSS_SET_MAX_LDS((rel_bwd_r_kernel<T, DH>), lr))) return e;
+    const dim3 grid((unsigned)nseq, heads), block(GB_THREADS);
+    NBSS_LAUNCH((rel_bwd_q_kernel<T, DH>), grid, block, lq, st, a);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH((rel_bwd_k_kernel<T, DH>), grid, block, lk, st, a);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    NBSS_LAUNCH((rel_bwd_r_kernel<T, DH>), grid, block, lr, st, a);
+    if ((e = NBSS_CHECK_LAUNCH())) return e;
+    const long nel = (long)(2 * Tn - 1) * H + 2 * H;
+    NBSS_LAUNCH(rel_fold_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, (const float*)a.dpos_part, (const float*)a.duv_part, nseq, Tn, H, heads, dpos, du, dvb);
+    return NBSS_CHECK_LAUNCH();
+}
+int nb_attention_relpos_bwd_impl(int dtype, long nseq, int Tn, int H, int heads, const void* qkv, const void* pos, const float* ub, const float* vb, float scale,
+                                 const uint32_t* mask, float keep, const void* dO, void* dqkv, float* dpos, float* du, float* dvb, void* ws, hipStream_t st) {
+    if (heads <= 0 || H % heads) return NBSS_EINVAL;
+    const int dh = H / heads;
+    RelBwd a = {qkv, pos, dO, ub, vb, mask, dqkv, nullptr, nullptr, nullptr, nullptr, scale, keep, Tn, H, heads};
+    if (dh == 48) return dtype == NBSS_BF16 ? nb_relpos_bwd<bf16_t, 48>(nseq, a, dpos, du, dvb, ws, st) : nb_relpos_bwd<float, 48>(nseq, a, dpos, du, dvb, ws, st);
+    if (dh == 24) return dtype == NBSS_BF16 ? nb_relpos_bwd<bf16_t, 24>(nseq, a, dpos, du, dvb, ws, st) : nb_relpos_bwd<float, 24>(nseq, a, dpos, du, dvb, ws, st);
+    return NBSS_EUNSUPPORTED;
+}
+// GroupNorm forward that keeps its (mean, rstd) per (sequence, group) for nb_group_norm_bwd_impl (dx in place of dy; dgamma / dbeta accumulated)
+int nb_group_norm_train_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, float* stats,
+                             hipStream_t st) {
+    if (groups <= 0 || C % groups) return NBSS_EINVAL;
+    const int CG = C / groups;
+    if (dtype == NBSS_BF16)
+        NBSS_LAUNCH((gb_gn_fwd_kernel<bf16_t>), dim3((unsigned)(nseq * groups)), dim3(GB_THREADS), 8 * sizeof(float), st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, stats, Tn, C, CG, act);
+    else
+        NBSS_LAUNCH((gb_gn_fwd_kernel<float>), dim3((unsigned)(nseq * groups)), dim3(GB_THREADS), 8 * sizeof(float), st, (const float*)x, gamma, beta, (float*)y, stats, Tn, C, CG, act);
+    return NBSS_CHECK_LAUNCH();
+}
+int nb_group_norm_bwd_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* stats, const float* gamma, const float* beta, void* dy_dx,
+                           float* dgamma, float* dbeta, hipStream_t st) {
+    if (groups <= 0 || C % groups) return NBSS_EINVAL;
+    const int CG = C / groups;
+    if (CG > 64) return NBSS_EUNSUPPORTED;
+    const size_t lds = (8 + 128) * sizeof(float);
+    if (dtype == NBSS_BF16)
+        NBSS_LAUNCH((gb_gn_bwd_kernel<bf16_t>), dim3((unsigned)(nseq * groups)), dim3(GB_THREADS), lds, st, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)dy_dx, dgamma, dbeta, Tn, C, CG);
+    else
+        NBSS_LAUNCH((gb_gn_bwd_kernel<float>), dim3((unsigned)(nseq * groups)), dim3(GB_THREADS), lds, st, (const float*)x, stats, gamma, beta, (float*)dy_dx, dgamma, dbeta, Tn, C, CG);
+    return NBSS_CHECK_LAUNCH();
 }
 // GroupNorm(groups, C) over (C / groups x T) per sequence (eps 1e-5), optional SiLU: x, y [nseq][T][C]
 int nb_group_norm_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, hipStream_t st) {

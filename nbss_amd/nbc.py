@@ -151,3 +151,267 @@ class NativeNBC:
             bdec[:Cout] = f32(net.decoder.bias)
         out = conv(z, T, H, H, Co8, 1, K1, wdec, bdec)
         return out[..., :Cout].reshape(B, F, T, Cout).to(x.dtype).contiguous()
+
+
+# ---- training (round 5): one autograd.Function whose backward walks the blocks in reverse over the nbss_nb_*_bwd building blocks, the relative-position
+# attention through nbss_nb_attention_relpos_train / _bwd.  The reference's NBC trains with dropout 0.1 everywhere (NBC.py:83,168: not a constructor
+# argument): the three element-wise dropouts of a block are torch ops on the device between the kernels (masks kept for backward), the attention dropout is
+# a bit tensor [nseq][heads][T][ceil(T / 32)] drawn here with torch's generator and read by the forward AND the backward kernels. --------------------------------
+def _param_list(net):
+    ps = [net.encoder.weight, net.encoder.bias]
+    for b in net.sa_layers:
+        a = b.self_attn
+        ps += [b.norm1.weight, b.norm1.bias, a.query_proj.weight, a.query_proj.bias, a.key_proj.weight, a.key_proj.bias, a.value_proj.weight, a.value_proj.bias,
+               a.pos_proj.weight, a.u_bias, a.v_bias, a.out_proj.weight, a.out_proj.bias, b.norm2.weight, b.norm2.bias, b.linear1.weight, b.linear1.bias]
+        for m in b.conv:
+            if isinstance(m, (torch.nn.Conv1d, torch.nn.GroupNorm)):
+                ps += [m.weight, m.bias]
+        ps += [b.linear2.weight, b.linear2.bias]
+    ps.append(net.decoder.weight)
+    if net.decoder.bias is not None:
+        ps.append(net.decoder.bias)
+    return ps
+
+
+def train_supported(net) -> Optional[str]:
+    why = supported(net)
+    if why is not None:
+        return why
+    if net.encoder.bias is None:
+        return "encoder without bias"
+    for b in net.sa_layers:
+        a = b.self_attn
+        if any(l.bias is None for l in (a.query_proj, a.key_proj, a.value_proj, a.out_proj, b.linear1, b.linear2)) or a.pos_proj.bias is not None:
+            return "projections must have biases (pos_proj none)"
+        for gn in (m for m in b.conv if isinstance(m, torch.nn.GroupNorm)):
+            if (b.linear1.out_features // gn.num_groups) > 64:
+                return "GroupNorm groups wider than 64 channels"
+    if len(set(id(p) for p in _param_list(net))) != len(list(net.parameters())):
+        return "parameters outside the native path"
+    return None
+
+
+class _NBCTrainFn(torch.autograd.Function):
+    """out = NBC(x) with the gradients of every parameter from the HIP building blocks.  inputs: (runner, x, *parameters in _param_list order)"""
+
+    @staticmethod
+    def forward(ctx, runner, x, *params):
+        out, saved = runner._forward_train(x)
+        ctx.runner, ctx.saved = runner, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.runner._backward_train(ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return (None, None, *grads)
+
+
+def _keep_bits(shape, p: float, dev) -> Tensor:
+    """attention-dropout keep-bits for [nseq, heads, T, T] probabilities: int32 words [nseq, heads, T, ceil(T / 32)], bit (j & 31) of word j >> 5 = (i, j) kept"""
+    nseq, heads, T, _ = shape
+    MW = (T + 31) // 32
+    keep = torch.rand(nseq, heads, T, MW * 32, device=dev) >= p
+    w = (keep.view(nseq, heads, T, MW, 32).to(torch.int64) << torch.arange(32, device=dev, dtype=torch.int64)).sum(-1)
+    return (w - ((w >> 31) << 32)).to(torch.int32).contiguous()
+
+
+def forward_train(self, x: Tensor) -> Tensor:
+    """training-mode forward with autograd: x [B,F,T,dim_input] -> [B,F,T,dim_output]; parameter gradients come from the HIP backward blocks"""
+    why = train_supported(self.net)
+    if why is not None:
+        raise NbssError(f"NBC native training: {why}")
+    return _NBCTrainFn.apply(self, x, *_param_list(self.net))
+
+
+def _forward_train(self, x: Tensor):
+    net, lib, p = self.net, self.lib, self._p
+    B, F, T, Cin = x.shape
+    K = net.encoder.kernel_size[0]
+    Ti = T - K + 1
+    if Ti < 1 or T > 256:
+        raise NbssError(f"NBC native training: {T} frames (kernel {K}; the attention kernels keep a sequence and its offsets table in LDS: <= 256)")
+    dt = NBSS_BF16 if x.dtype == torch.bfloat16 else NBSS_F32
+    td = x.dtype if dt == NBSS_BF16 else torch.float32
+    dev, nseq = x.device, B * F
+    st = ops._stream(lib, x)
+    H = net.encoder.out_channels
+    blocks = list(net.sa_layers)
+    FFN, heads, Cout = blocks[0].linear1.out_features, blocks[0].self_attn.num_heads, net.decoder.out_channels
+    Cin8, Co8, K1 = (Cin + 7) // 8 * 8, (Cout + 7) // 8 * 8, K + 1
+    cv0 = [m for m in blocks[0].conv if isinstance(m, torch.nn.Conv1d)][0]
+    g, ks = cv0.groups, cv0.kernel_size[0]
+    shapes = ((H, Cin8, 1, K1), (3 * H, H, 1, 1), (H, H, 1, 1), (FFN, H, 1, 1), (FFN, FFN, g, ks), (H, FFN, 1, 1), (Co8, H, 1, K1))
+    ws = torch.empty(max(lib._dll.nbss_nb_bwd_ws_bytes(*a) for a in shapes), dtype=torch.uint8, device=dev)
+    training = net.training
+    keep = []  # converted copies stay alive until this call returns
+
+    def f32(t):
+        v = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(v)
+        return v
+
+    def conv(xin, rows_t, cin, ldx, cout, groups, taps, w, b, y2=False, n=nseq):
+        y = torch.empty(n, rows_t, cout, dtype=td, device=dev)
+        ys = torch.empty_like(y) if y2 else None
+        w, b = f32(w), (f32(b) if b is not None else None)
+        lib.call("nbss_nb_conv_t_train", dt, n, rows_t, cin, ldx, cout, groups, taps, p(xin), p(w), p(b), p(y), p(ys), None, p(ws), st)
+        return (y, ys) if y2 else y
+
+    def layernorm(h, mod, rows):
+        u, stats = torch.empty_like(h), torch.empty(rows, 2, dtype=torch.float32, device=dev)
+        lib.call("nbss_nb_layernorm", dt, rows, H, p(h), p(f32(mod.weight)), p(f32(mod.bias)), p(u), p(stats), st)
+        return u, stats
+
+    def dropout(t, mod):
+        """-> (dropped tensor, mask scaled by 1 / (1 - p) in the stream dtype, or None)"""
+        if not training or mod.p == 0.0:
+            return t, None
+        m = (torch.rand_like(t, dtype=torch.float32) >= mod.p).to(td) * (1.0 / (1.0 - mod.p))
+        return t * m, m
+
+    xin = torch.zeros(nseq, T, Cin8, dtype=td, device=dev)
+    xin[..., :Cin] = x.reshape(nseq, T, Cin).to(td)
+    wenc = torch.zeros(H, Cin8, K1, dtype=torch.float32, device=dev)
+    wenc[:, :Cin, :K] = f32(net.encoder.weight)
+    h = conv(xin, T, Cin8, Cin8, H, 1, K1, wenc, net.encoder.bias)[:, K // 2: K // 2 + Ti].contiguous()
+    N = nseq * Ti
+    per = []
+    for b in blocks:
+        a = b.self_attn
+        u, st1 = layernorm(h, b.norm1, N)
+        wqkv = torch.cat([f32(a.query_proj.weight), f32(a.key_proj.weight), f32(a.value_proj.weight)], 0)[..., None].contiguous()
+        bqkv = torch.cat([f32(a.query_proj.bias), f32(a.key_proj.bias), f32(a.value_proj.bias)], 0)
+        qkv = conv(u, Ti, H, H, 3 * H, 1, 1, wqkv, bqkv)
+        pe = a.rel_pos.pe[0, a.rel_pos.zero_index - (Ti - 1): a.rel_pos.zero_index + Ti].to(device=dev, dtype=td).contiguous()[None]
+        pos = conv(pe, 2 * Ti - 1, H, H, H, 1, 1, f32(a.pos_proj.weight)[..., None].contiguous(), None, n=1)
+        pa = a.dropout.p if training else 0.0
+        bits = _keep_bits((nseq, heads, Ti, Ti), pa, dev) if pa > 0 else None
+        o = torch.empty_like(h)
+        ub, vb = f32(a.u_bias), f32(a.v_bias)
+        lib.call("nbss_nb_attention_relpos_train", dt, nseq, Ti, H, heads, p(qkv), p(pos), p(ub), p(vb), 1.0 / a.sqrt_dim, p(bits), 1.0 / (1.0 - pa), p(o), st)
+        att = conv(o, Ti, H, H, H, 1, 1, f32(a.out_proj.weight)[..., None].contiguous(), a.out_proj.bias)
+        att, m1 = dropout(att, b.dropout1)
+        h1 = h + att
+        v, st2 = layernorm(h1, b.norm2, N)
+        a1, c = conv(v, Ti, H, H, FFN, 1, 1, f32(b.linear1.weight)[..., None].contiguous(), b.linear1.bias, y2=True)
+        mods = list(b.conv)
+        chain = []  # per conv step: (input c_prev, pre-norm z, GroupNorm stats)
+        for i in range(0, len(mods), 3):
+            cv, gn = mods[i], mods[i + 1]
+            z = conv(c, Ti, FFN, FFN, FFN, cv.groups, cv.kernel_size[0], cv.weight, cv.bias)
+            y = torch.empty_like(z)
+            gst = torch.empty(nseq * gn.num_groups, 2, dtype=torch.float32, device=dev)
+            lib.call("nbss_nb_group_norm_train", dt, nseq, Ti, FFN, gn.num_groups, p(z), p(f32(gn.weight)), p(f32(gn.bias)), 1, p(y), p(gst), st)
+            chain.append((c, z, gst))
+            c = y
+        cd, md = dropout(c, b.dropout)
+        f = conv(cd, Ti, FFN, FFN, H, 1, 1, f32(b.linear2.weight)[..., None].contiguous(), b.linear2.bias)
+        f, m2 = dropout(f, b.dropout2)
+        h2 = h1 + f
+        per.append(dict(h=h, u=u, st1=st1, qkv=qkv, pe=pe, pos=pos, bits=bits, pa=pa, o=o, m1=m1, h1=h1, v=v, st2=st2, a1=a1, chain=chain, cd=cd, md=md, m2=m2))
+        h = h2
+    z = torch.zeros(nseq, T, H, dtype=td, device=dev)
+    z[:, K // 2 - 1: K // 2 - 1 + Ti] = h
+    wdec = torch.zeros(Co8, H, K1, dtype=torch.float32, device=dev)
+    wdec[:Cout, :, :K] = f32(net.decoder.weight).permute(1, 0, 2).flip(-1)
+    bdec = torch.zeros(Co8, dtype=torch.float32, device=dev)
+    if net.decoder.bias is not None:
+        bdec[:Cout] = f32(net.decoder.bias)
+    out = conv(z, T, H, H, Co8, 1, K1, wdec, bdec)
+    saved = dict(per=per, xin=xin, z=z, wenc=wenc, wdec=wdec, geo=(B, F, T, Ti, K, K1, Cin, Cin8, Cout, Co8, H, FFN, heads, g, ks, dt, td), ws=ws)
+    return out[..., :Cout].reshape(B, F, T, Cout).to(x.dtype).contiguous(), saved
+
+
+def _backward_train(self, sv, dout: Tensor):
+    net, lib, p = self.net, self.lib, self._p
+    B, F, T, Ti, K, K1, Cin, Cin8, Cout, Co8, H, FFN, heads, g, ks, dt, td = sv["geo"]
+    dev, nseq, N = dout.device, B * F, B * F * Ti
+    st = ops._stream(lib, dout)
+    ws = sv["ws"]
+    aws = torch.empty(lib._dll.nbss_nb_attention_relpos_bwd_ws_bytes(nseq, Ti, H, heads), dtype=torch.uint8, device=dev)
+    blocks = list(net.sa_layers)
+    keep = []
+
+    def f32(t):
+        v = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(v)
+        return v
+
+    def conv_bwd(xin, rows_t, cin, ldx, cout, groups, taps, w, dy, x_pre=None, need_dx=True, bias=True, n=nseq):
+        """-> (dx or None, dw, db)"""
+        dx = torch.empty(n, rows_t, ldx, dtype=td, device=dev) if need_dx else None
+        dw = torch.zeros(cout * (cin // groups) * taps, dtype=torch.float32, device=dev)
+        db = torch.zeros(cout, dtype=torch.float32, device=dev) if bias else None
+        lib.call("nbss_nb_conv_t_bwd", dt, n, rows_t, cin, ldx, cout, groups, taps, p(xin), p(f32(w)), p(dy), p(x_pre), p(dx), p(dw), p(db), p(ws), st)
+        return dx, dw, db
+
+    def ln_bwd(xin, stats, mod, dy, dres):
+        dx = torch.empty_like(xin)
+        dg, db = torch.zeros(H, dtype=torch.float32, device=dev), torch.zeros(H, dtype=torch.float32, device=dev)
+        lib.call("nbss_nb_layernorm_bwd", dt, N, H, p(xin), p(stats), p(f32(mod.weight)), p(dy), p(dres), p(dx), p(dg), p(db), st)
+        return dx, dg, db
+
+    # decoder (a transposed conv = the "same" conv of the zero-extended sequence with the taps flipped)
+    d8 = torch.zeros(nseq, T, Co8, dtype=td, device=dev)
+    d8[..., :Cout] = dout.reshape(nseq, T, Cout).to(td)
+    dz, dwd, dbd = conv_bwd(sv["z"], T, H, H, Co8, 1, K1, sv["wdec"], d8)
+    dh = dz[:, K // 2 - 1: K // 2 - 1 + Ti].contiguous()
+    g_dec = [dwd.view(Co8, H, K1)[:Cout, :, :K].flip(-1).permute(1, 0, 2).contiguous()]
+    if net.decoder.bias is not None:
+        g_dec.append(dbd[:Cout])
+    per_grads = []
+    for b, s in zip(reversed(blocks), reversed(sv["per"])):
+        a = b.self_attn
+        # feed-forward branch: h2 = h1 + dropout2(linear2(dropout(chain(SiLU(linear1(LN2(h1)))))))
+        df = dh * s["m2"] if s["m2"] is not None else dh
+        dcd, dw2, db2 = conv_bwd(s["cd"], Ti, FFN, FFN, H, 1, 1, f32(b.linear2.weight)[..., None].contiguous(), df.contiguous())
+        dc = dcd * s["md"] if s["md"] is not None else dcd
+        mods = list(b.conv)
+        chain_grads = []
+        steps = [(mods[i], mods[i + 1]) for i in range(0, len(mods), 3)]
+        for idx in range(len(steps) - 1, -1, -1):
+            cv, gn = steps[idx]
+            c_prev, z, gst = s["chain"][idx]
+            dg, dbt = torch.zeros(FFN, dtype=torch.float32, device=dev), torch.zeros(FFN, dtype=torch.float32, device=dev)
+            dzz = dc.contiguous()  # (ours alone: a conv_bwd output or the product with the dropout mask; the kernel works in place)
+            lib.call("nbss_nb_group_norm_bwd", dt, nseq, Ti, FFN, gn.num_groups, p(z), p(gst), p(f32(gn.weight)), p(f32(gn.bias)), p(dzz), p(dg), p(dbt), st)
+            # c_prev = SiLU(a1) for the first conv (x_pre: the gradient comes back multiplied by SiLU'(a1)), the previous step's output otherwise
+            dc, dwc, dbc = conv_bwd(c_prev, Ti, FFN, FFN, FFN, cv.groups, cv.kernel_size[0], cv.weight, dzz, x_pre=s["a1"] if idx == 0 else None)
+            chain_grads.append([dwc.reshape(cv.weight.shape), dbc, dg, dbt])
+        dv, dw1, db1 = conv_bwd(s["v"], Ti, H, H, FFN, 1, 1, f32(b.linear1.weight)[..., None].contiguous(), dc)
+        dh1, dg2, db2n = ln_bwd(s["h1"], s["st2"], b.norm2, dv, dh)
+        # attention branch: h1 = h + dropout1(out_proj(attention(...)))
+        da = dh1 * s["m1"] if s["m1"] is not None else dh1
+        do, dwo, dbo = conv_bwd(s["o"], Ti, H, H, H, 1, 1, f32(a.out_proj.weight)[..., None].contiguous(), da.contiguous())
+        dqkv = torch.empty_like(s["qkv"])
+        dpos = torch.zeros(2 * Ti - 1, H, dtype=torch.float32, device=dev)
+        dub, dvb = torch.zeros(H, dtype=torch.float32, device=dev), torch.zeros(H, dtype=torch.float32, device=dev)
+        ub, vb = f32(a.u_bias), f32(a.v_bias)
+        lib.call("nbss_nb_attention_relpos_bwd", dt, nseq, Ti, H, heads, p(s["qkv"]), p(s["pos"]), p(ub), p(vb), 1.0 / a.sqrt_dim, p(s["bits"]), 1.0 / (1.0 - s["pa"]),
+                 p(do), p(dqkv), p(dpos), p(dub), p(dvb), p(aws), st)
+        _, dwp, _ = conv_bwd(s["pe"], 2 * Ti - 1, H, H, H, 1, 1, f32(a.pos_proj.weight)[..., None].contiguous(), dpos.to(td)[None].contiguous(), need_dx=False, bias=False, n=1)
+        wqkv = torch.cat([f32(a.query_proj.weight), f32(a.key_proj.weight), f32(a.value_proj.weight)], 0)[..., None].contiguous()
+        du, dwi, dbi = conv_bwd(s["u"], Ti, H, H, 3 * H, 1, 1, wqkv, dqkv)
+        dh, dg1, db1n = ln_bwd(s["h"], s["st1"], b.norm1, du, dh1)
+        dwi = dwi.view(3, H, H)
+        gl = [dg1, db1n, dwi[0], dbi[:H], dwi[1], dbi[H:2 * H], dwi[2], dbi[2 * H:], dwp.view(H, H), dub.view(a.u_bias.shape), dvb.view(a.v_bias.shape),
+              dwo.view(H, H), dbo, dg2, db2n, dw1.view(FFN, H), db1]
+        for cg in reversed(chain_grads):
+            gl += cg
+        gl += [dw2.view(H, FFN), db2]
+        per_grads.append(gl)
+    # encoder (no input gradient): the "valid" conv = rows K/2 .. of the zero-padded odd-kernel conv
+    dfull = torch.zeros(nseq, T, H, dtype=td, device=dev)
+    dfull[:, K // 2: K // 2 + Ti] = dh
+    _, dwe, dbe = conv_bwd(sv["xin"], T, Cin8, Cin8, H, 1, K1, sv["wenc"], dfull, need_dx=False)
+    grads = [dwe.view(H, Cin8, K1)[:, :Cin, :K].contiguous(), dbe]
+    for gl in reversed(per_grads):
+        grads += gl
+    grads += g_dec
+    return [gr.reshape(prm.shape).to(prm.dtype) for gr, prm in zip(grads, _param_list(net))]
+
+
+NativeNBC.forward_train = forward_train
+NativeNBC._forward_train = _forward_train
+NativeNBC._backward_train = _backward_train
