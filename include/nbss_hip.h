@@ -286,6 +286,19 @@ int nbss_nb_group_norm_train(int dtype, int64_t nseq, int T, int C, int groups, 
 int nbss_nb_group_norm_bwd(int dtype, int64_t nseq, int T, int C, int groups, const void* x, const float* stats, const float* gamma, const float* beta, void* dy_dx,
                            float* dgamma, float* dbeta, void* stream);
 
+/* ---- the narrow-band BiLSTM (reference models/arch/blstm2_fc1.py:45-68: nn.LSTM(bidirectional) per frequency bin; sequenced by nbss_amd/blstm.py) ------------
+ * One bidirectional layer's recurrences, all T steps in one persistent launch (a workgroup per tile of sequences and direction; gates GEMM on MFMA, h in LDS,
+ * c in registers).  gx [nseq][T][ldg]: W_ih x + b_ih + b_hh of both directions (direction d at columns d * 4 hidden; gate order i | f | g | o), from
+ * nbss_nb_conv_t.  w_hh / w_hh_reverse [4 hidden][hidden] fp32.  y [nseq][T][2 hidden] (direction d at columns d * hidden).  save (training; or NULL):
+ * [2][nseq][T][5 hidden] i | f | g | o | c, stream dtype.  hidden in {128, 256}.  ws: nbss_nb_blstm_ws_bytes() bytes (the packed recurrent weights).
+ * blstm_bwd: dg [nseq][T][8 hidden] = gradient w.r.t. the gate pre-activations of both directions from dy (gradient w.r.t. y) and save; the weight, bias and
+ *   input gradients are dense contractions of dg (nbss_nb_conv_t_bwd). */
+int64_t nbss_nb_blstm_ws_bytes(int dtype, int hidden);
+int nbss_nb_blstm_fwd(int dtype, int64_t nseq, int T, int hidden, int ldg, const void* gx, const float* w_hh, const float* w_hh_reverse, void* y, void* save, void* ws,
+                      void* stream);
+int nbss_nb_blstm_bwd(int dtype, int64_t nseq, int T, int hidden, const void* dy, const void* save, const float* w_hh, const float* w_hh_reverse, void* dg, void* ws,
+                      void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------*/
 /* D = A(16x32) * B(32x16) through the same MFMA fragment helpers the kernels use
  * (natural or permuted K order); used by the tests to pin the gfx950 fragment layouts. */

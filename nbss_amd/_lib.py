@@ -97,6 +97,9 @@ SIGNATURES = {
     "nbss_nb_attention_relpos_bwd": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P, _P, C.c_float, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "nbss_nb_group_norm_train": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     "nbss_nb_group_norm_bwd": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_nb_blstm_ws_bytes": (C.c_int64, [_I, _I]),
+    "nbss_nb_blstm_fwd": (_I, [_I, C.c_int64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "nbss_nb_blstm_bwd": (_I, [_I, C.c_int64, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "nbss_clip_adam_step": (_I, [C.c_int64, _P, _P, _P, _P, _P] + [C.c_float] * 7 + [_I, _I, _P]),
     "nbss_clip_adam_step_dev": (_I, [C.c_int64, _P, _P, _P, _P, _P, _P] + [C.c_float] * 6 + [_I, _P]),
     "nbss_adam_hyper": (_I, [_I, C.c_float, C.c_float, C.c_float, _P]),

@@ -58,6 +58,9 @@ int nb_group_norm_train_impl(int dtype, long nseq, int Tn, int C, int groups, co
 int nb_group_norm_bwd_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* stats, const float* gamma, const float* beta, void* dy_dx,
                            float* dgamma, float* dbeta, hipStream_t st);
 int nb_group_norm_impl(int dtype, long nseq, int Tn, int C, int groups, const void* x, const float* gamma, const float* beta, int act, void* y, hipStream_t st);
+size_t blstm_ws_bytes_impl(int HD, int dtype);
+int blstm_fwd_impl(int dtype, long n, int Tn, int HD, int ldg, const void* gx, const float* whh0, const float* whh1, void* y, void* save, void* ws, hipStream_t st);
+int blstm_bwd_impl(int dtype, long n, int Tn, int HD, const void* dy, const void* save, const float* whh0, const float* whh1, void* dg, void* ws, hipStream_t st);
 size_t nb_bwd_ws_bytes_impl(int M, int K, int groups, int taps);
 int nb_conv_t_train_impl(int dtype, long nseq, int Tn, int Cin, int ldx, int Cout, int groups, int taps, const void* x, const float* w, const float* bias, void* y,
                          void* y2, const void* residual, void* ws, hipStream_t st);
@@ -598,6 +601,20 @@ int nbss_nb_group_norm_bwd(int dtype, int64_t nseq, int T, int C, int groups, co
         !dgamma || !dbeta)
         return NBSS_EINVAL;
     return nb_group_norm_bwd_impl(dtype, (long)nseq, T, C, groups, x, stats, gamma, beta, dy_dx, dgamma, dbeta, (hipStream_t)stream);
+}
+int64_t nbss_nb_blstm_ws_bytes(int dtype, int hidden) {
+    if (!nb_dtype_ok(dtype) || (hidden != 128 && hidden != 256)) return -1;
+    return (int64_t)blstm_ws_bytes_impl(hidden, dtype);
+}
+int nbss_nb_blstm_fwd(int dtype, int64_t nseq, int T, int hidden, int ldg, const void* gx, const float* w_hh, const float* w_hh_reverse, void* y, void* save, void* ws,
+                      void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= ((int64_t)1 << 31) || T <= 0 || ldg < 8 * hidden || !gx || !w_hh || !w_hh_reverse || !y || !ws) return NBSS_EINVAL;
+    return blstm_fwd_impl(dtype, (long)nseq, T, hidden, ldg, gx, w_hh, w_hh_reverse, y, save, ws, (hipStream_t)stream);
+}
+int nbss_nb_blstm_bwd(int dtype, int64_t nseq, int T, int hidden, const void* dy, const void* save, const float* w_hh, const float* w_hh_reverse, void* dg, void* ws,
+                      void* stream) {
+    if (!nb_dtype_ok(dtype) || nseq <= 0 || nseq >= ((int64_t)1 << 31) || T <= 0 || !dy || !save || !w_hh || !w_hh_reverse || !dg || !ws) return NBSS_EINVAL;
+    return blstm_bwd_impl(dtype, (long)nseq, T, hidden, dy, save, w_hh, w_hh_reverse, dg, ws, (hipStream_t)stream);
 }
 
 int nbss_selftest_mma(int dtype, int kperm, const float* A, const float* B, float* D, void* stream) {
