@@ -24,9 +24,11 @@ EMU_LIB = EMUDIR / "libnbss_emu.so"
 
 # The SLP vectoriser turns adjacent f32 adds / multiplies into v_pk_*_f32.  On gfx950 a packed f32 instruction issues no faster than its two
 # scalar halves (SIMD-32: 157 TFLOP/s IS the unpacked rate) and constrains register pairing; measured per kernel in one call (profiles/README.md,
-# round 5): full_bwd 766 -> 716 us, mhsa_bwd 1417 -> 1406 without it, fconv_bwd within noise, the T-ConvFFN kernels 4 % SLOWER (fewer issue slots
-# matter there) — so it is switched off per file.
-PER_FILE_FLAGS = {k: ["-fno-slp-vectorize"] for k in ("full", "mhsa", "mhsa_bwd")}
+# round 5): mhsa_bwd 1417 -> 1406 us without it, fconv_bwd within noise, the T-ConvFFN kernels 4 % SLOWER (fewer issue slots matter there), full_bwd
+# 766 -> 716 us (+1 % on the step) — but full.hip stays vectorised: without it one tensor of tests/test_bf16_vs_reference.py (layers.1.squeeze.0.bias,
+# a heavily cancelling sum) lands at 1.58x the reference's own bf16 error instead of 1.45x (other FMA contractions, same algorithm), above the 1.5x bar,
+# and the bar is not what gets moved.
+PER_FILE_FLAGS = {k: ["-fno-slp-vectorize"] for k in ("mhsa", "mhsa_bwd")}
 
 
 def _sources():
