@@ -16,6 +16,7 @@
 #include "wgrad.h"
 #include "blocks.h"
 #include "side.h"
+#include <cstdlib>
 
 #define TF_H 96
 #define TF_FFN 192
@@ -1115,7 +1116,24 @@ static int tconvffn_bwd_t(const nbss_cfg& c, const float* P, float* part, const 
 int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_da1,
                           hipStream_t st);
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave);
-int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, hipStream_t st);
+int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, bool with_w2, hipStream_t st);
+int tconvffn_bwd_q_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5, void* op_da1,
+                          hipStream_t st);
+#ifndef NBSS_TCF_BWD_DEFAULT_Q
+#define NBSS_TCF_BWD_DEFAULT_Q 1
+#endif
+// which data-gradient kernel of tconvffn_s.hip: 1 = tconvffn_bwd_q (a sequence's group pairs: two workgroups per CU; h5 operand + wgrad.hip for W2),
+// 0 = tconvffn_bwd_v (four groups per workgroup, the W2 weight gradient contracted inside).  NBSS_TCF_BWD=v|q overrides (A/B; read once per process).
+// Same-box measurements (profiles/README.md, round 5): the sub-block (data-gradient kernel + tail kernel) 11.2 ms per step with v, 9.6 with q; the step
+// 656-660 utt/s with v, 661-662 with q (in order 656.7 / 656.2): q's W2 weight gradient is a launch of its own again (147 us in order) — contracting it in
+// the tail kernel instead (four images per chunk) made THAT kernel 160-250 us slower, in bwd_v it costs what it saves.
+static bool tcf_use_q() {
+    static const int v = [] {
+        const char* e = getenv("NBSS_TCF_BWD");
+        return e ? (e[0] == 'q' ? 1 : 0) : NBSS_TCF_BWD_DEFAULT_Q;
+    }();
+    return v != 0;
+}
 
 // bf16 stream, from the pre-activations a training-mode forward saved (tconvffn_s.hip): data gradient + the three T-conv weight gradients + the
 // W2 weight gradient in one kernel, the tail + W1 weight gradient in tailw.hip, one fold of the per-sequence partial rows
@@ -1124,19 +1142,22 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     const LayerPtrs lp = layer_ptrs(c, P, layer);
     const size_t N = (size_t)c.B * c.F * c.T;
     char* base = (char*)ws + ws_align(N * 2 * sizeof(float));
+    void* op_h5 = base + (size_t)3 * ws_align(N * TF_FFN * 2);
     void* op_da1 = base + (size_t)4 * ws_align(N * TF_FFN * 2);
     float* part = (float*)((char*)ws + ws_tcpart_offset(c));
     float* wgpart = (float*)((char*)ws + ws_wgpart_offset(c));
+    const bool q = tcf_use_q();
     int e;
     hipStream_t gs = st;  // parameter-gradient launches (side.h): everything behind the tail kernel
     {
         ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
-        if ((e = tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_da1, st))) return e;
+        if ((e = q ? tconvffn_bwd_q_launch(c, lp, part, packed, layer, dy, tsave, op_h5, op_da1, st) : tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_da1, st)))
+            return e;
         if ((e = tailw_tconvffn(c, lp, packed, layer, x, dy, dx, tconvffn_save_ln_stats(c, tsave), op_da1, wgpart, G, P, st, sd, &gs))) return e;
     }
     const int convW[3] = {P_TF_C1W, P_TF_C2W, P_TF_C3W}, convBias[3] = {P_TF_C1B, P_TF_C2B, P_TF_C3B};
-    AffSegs sg;  // fp32 rows: GroupNorm affine sums + the three conv bias sums + W2's bias sums
-    sg.n = 6;
+    AffSegs sg;  // fp32 rows: GroupNorm affine sums + the three conv bias sums (+ W2's bias sums from the four-group kernel)
+    sg.n = q ? 5 : 6;
     sg.off[0] = param_off(c, layer, P_TF_GN_W); sg.cnt[0] = TF_FFN;
     sg.off[1] = param_off(c, layer, P_TF_GN_B); sg.cnt[1] = TF_FFN;
     for (int k = 0; k < 3; ++k) { sg.off[2 + k] = param_off(c, layer, convBias[k]); sg.cnt[2 + k] = TF_FFN; }
@@ -1144,7 +1165,18 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     if ((e = affine_reduce_launch(part, c.B * c.F, sg, G, gs))) return e;
     const long long woffs[4] = {param_off(c, layer, convW[0]), param_off(c, layer, convW[1]), param_off(c, layer, convW[2]), param_off(c, layer, P_TF_W2)};
     // (the slice sums of the fold live in the wgrad partial-tile region, idle between this sub-block's wgrad launches: 64 x 59 904 floats = 15.3 MB)
-    return tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN + TF_H), wgpart, G, woffs, gs);
+    if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN + (q ? 0 : TF_H)), wgpart, G, woffs, !q, gs))) return e;
+    if (!q) return NBSS_OK;
+    // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
+    WgradArgs a;
+    a.part = wgpart;
+    a.mvalid = 0; a.nvalid = 0;
+    a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0;
+    a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+    a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = op_h5; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
+    a.b_gw = TF_CG; a.b_gs = (int)(N * TF_CG);
+    a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
+    return wgrad_launch(a, c.dtype, gs);
 }
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,

@@ -561,14 +561,14 @@ NBSS_DEV void p6_gload(const bf16_t* __restrict__ g, P6& p) {
 // ONE contiguous run (48 bytes per frame), read back by the wave that has just written the rows (same wave: LDS executes in order).
 // The lane-wise form (p6_gstore: three 8-byte stores per lane, each instruction covering 16 of every 48 bytes of a 1.5 KB span) cost a
 // quarter of the kernel: knocked out, tconvffn_bwd went from 12.8 to 10.3 ms per step.
-template <int NPMAX>
-NBSS_DEV void rows_gstore(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) {
+template <int NPMAX, int RS>
+NBSS_DEV void rows_gstore_t(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) {
     const int lane = lane_id();
 #pragma unroll
     for (int k = 0; k < (NPMAX + 63) / 64; ++k) {
         const int i = lane + 64 * k, tok = i / 3, part = i - 3 * tok;
         if (i < 3 * nrows && tok < nvalid) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + (size_t)tok * TB_RS + 8 * part);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + (size_t)tok * RS + 8 * part);
 #ifndef NBSS_EMU
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part));
 #else
@@ -577,6 +577,8 @@ NBSS_DEV void rows_gstore(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nro
         }
     }
 }
+template <int NPMAX>
+NBSS_DEV void rows_gstore(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) { rows_gstore_t<NPMAX, TB_RS>(gdst, lsrc, nrows, nvalid); }
 
 // sum over the 32 lanes of each wave half (lanes sharing lane >> 5)
 NBSS_DEV float half_sum32(float v) {
@@ -1165,11 +1167,15 @@ struct TvW {
 #define TV_CONVW (TS_FFN * TS_CG * 3)                 // one conv weight [192][24][3]
 #define TV_PSTRIDE (2 * TS_FFN + 3 * TS_FFN + TS_H)    // floats per fp32 `part` row: GN w | GN b | conv1 b | conv2 b | conv3 b | W2 b
 #define TV_P16 (3 * TV_CONVW + TS_FFN * TS_H)          // bf16 per `part16` row: the three conv weight gradients, each as [tap][in][out], then dW2 as [FFN channel][H output]
+#define TQ_RS 56                                       // image row stride of the group-pair kernel (112 B: 48 channels + 8; conflict-free 16-byte row reads)
+#define TQ_PSTRIDE (5 * TS_FFN)                        // its fp32 `part` row: GN w | GN b | conv1 b | conv2 b | conv3 b
+#define TQ_P16 (3 * TV_CONVW)                          // its bf16 row: the three conv weight gradients
 #define TV_DRS 100                                     // dy image row stride in elements (200 B; with 208 B the three images miss the 160 KB by 176 bytes)
 
 // dW tile accumulation of one conv group over the whole sequence.  Sg = &S[0][24 gl], Hg = &H[0][24 gl]; bases (bl, bu) as in the stage that
 // wrote S; H holds token t at row t + 1 (rows 0 and NT + 1 are zero).
-NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, int NS, int NSL, int mt, f32x4 (&acc)[5], f32x4& bsum) {
+template <int RS>
+NBSS_DEV void tv_contract_t(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, int NS, int NSL, int mt, f32x4 (&acc)[5], f32x4& bsum) {
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4;
     // which frame of the 32-frame k-step a lane's transposing read starts at.  Any map works as long as BOTH operands use it (the contraction sums over
     // the frames).  The natural one — 4 g4 + (l15 >> 2): a 16-lane group reads four CONSECUTIVE rows — puts those rows 52 dwords apart (208-byte image
@@ -1186,9 +1192,9 @@ NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, in
         int pc = 4 * j + (l15 & 3);
         pc = pc < 18 ? pc : 17;  // (the last tile's two dummy pieces re-read a valid one; their columns are never flushed)
         const int tap = pc / 6, ch4 = pc - 6 * tap;
-        boff[j] = (tap + rowoff) * TB_RS + 4 * ch4;
+        boff[j] = (tap + rowoff) * RS + 4 * ch4;
     }
-    const int aoff = rowoff * TB_RS + 16 * mt + 4 * (l15 & 3);
+    const int aoff = rowoff * RS + 16 * mt + 4 * (l15 & 3);
     Frag<bf16_t> ones;
 #pragma unroll
     for (int jq = 0; jq < 8; ++jq) frag_set(ones, jq, 1.0f);
@@ -1198,13 +1204,16 @@ NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, in
     for (int ks = 0; ks < NS; ++ks) {
         const int base = (ks < NSL ? bl : bu) + 32 * ks;
         Frag<bf16_t> fa, fb[5];
-        frag_load_tr(fa, Sg + (size_t)base * TB_RS + aoff, TB_RS);
+        frag_load_tr(fa, Sg + (size_t)base * RS + aoff, RS);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) frag_load_tr(fb[j], Hg + (size_t)(32 * ks) * TB_RS + boff[j], TB_RS);
+        for (int j = 0; j < 5; ++j) frag_load_tr(fb[j], Hg + (size_t)(32 * ks) * RS + boff[j], RS);
         bsum = mma(fa, ones, bsum);
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[j] = mma(fa, fb[j], acc[j]);
     }
+}
+NBSS_DEV void tv_contract(const bf16_t* Sg, const bf16_t* Hg, int bl, int bu, int NS, int NSL, int mt, f32x4 (&acc)[5], f32x4& bsum) {
+    tv_contract_t<TB_RS>(Sg, Hg, bl, bu, NS, NSL, mt, acc, bsum);
 }
 // The per-sequence partial of a conv weight gradient leaves in bf16, as [tap][input channel][output channel] (a lane's four output channels are one
 // 8-byte store); tconv_part_reduce_kernel sums the rows in fp32 and writes the parameter's own [out][in][tap] order.  (Under the reference's
@@ -1236,9 +1245,9 @@ NBSS_DEV void tv_flush(bf16_t* __restrict__ w16, float* __restrict__ brow, int g
 // four rows in flight per thread) into slices[y][e] (fp32); (2) one thread per element sums the slices and adds the result to the parameter's own
 // [out][in][tap] order in G.  (The first version — 4-byte loads, two rows in flight, 1.3 M atomicAdds — took 130 us for 0.34 GB.)
 #define TV_RSL 64
-__global__ __launch_bounds__(256) void tconv_part_reduce1_kernel(const bf16_t* __restrict__ part16, int nrows, float* __restrict__ slices) {
+__global__ __launch_bounds__(256) void tconv_part_reduce1_kernel(const bf16_t* __restrict__ part16, int nrows, float* __restrict__ slices, int P16) {
     const int e8 = blockIdx.x * 256 + threadIdx.x;  // group of 8 elements
-    if (e8 >= TV_P16 / 8) return;
+    if (e8 >= P16 / 8) return;
     const int r0 = (int)((long)nrows * blockIdx.y / gridDim.y), r1 = (int)((long)nrows * (blockIdx.y + 1) / gridDim.y);
     const u32x4* p = reinterpret_cast<const u32x4*>(part16) + e8;
     float acc[8];
@@ -1253,27 +1262,27 @@ __global__ __launch_bounds__(256) void tconv_part_reduce1_kernel(const bf16_t* _
     };
     int r = r0;
     for (; r + 4 <= r1; r += 4) {
-        const u32x4 a = p[(size_t)r * (TV_P16 / 8)], b = p[(size_t)(r + 1) * (TV_P16 / 8)], c = p[(size_t)(r + 2) * (TV_P16 / 8)], d = p[(size_t)(r + 3) * (TV_P16 / 8)];
+        const u32x4 a = p[(size_t)r * (P16 / 8)], b = p[(size_t)(r + 1) * (P16 / 8)], c = p[(size_t)(r + 2) * (P16 / 8)], d = p[(size_t)(r + 3) * (P16 / 8)];
         add(a); add(b); add(c); add(d);
     }
-    for (; r < r1; ++r) add(p[(size_t)r * (TV_P16 / 8)]);
-    float* out = slices + (size_t)blockIdx.y * TV_P16 + (size_t)e8 * 8;
+    for (; r < r1; ++r) add(p[(size_t)r * (P16 / 8)]);
+    float* out = slices + (size_t)blockIdx.y * P16 + (size_t)e8 * 8;
     store4(out, acc[0], acc[1], acc[2], acc[3]);
     store4(out + 4, acc[4], acc[5], acc[6], acc[7]);
 }
 __global__ __launch_bounds__(256) void tconv_part_reduce2_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ G, long long off0, long long off1, long long off2,
-                                                                 long long off3) {
+                                                                 long long off3, int P16) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= TV_P16) return;
+    if (e >= P16) return;
     float a = 0.f, b = 0.f, c2 = 0.f, d = 0.f;
     int y = 0;
     for (; y + 4 <= nsl; y += 4) {
-        a += slices[(size_t)y * TV_P16 + e];
-        b += slices[(size_t)(y + 1) * TV_P16 + e];
-        c2 += slices[(size_t)(y + 2) * TV_P16 + e];
-        d += slices[(size_t)(y + 3) * TV_P16 + e];
+        a += slices[(size_t)y * P16 + e];
+        b += slices[(size_t)(y + 1) * P16 + e];
+        c2 += slices[(size_t)(y + 2) * P16 + e];
+        d += slices[(size_t)(y + 3) * P16 + e];
     }
-    for (; y < nsl; ++y) a += slices[(size_t)y * TV_P16 + e];
+    for (; y < nsl; ++y) a += slices[(size_t)y * P16 + e];
     const float sum = (a + b) + (c2 + d);
     if (e >= 3 * TV_CONVW) {  // dW2 partial: [FFN channel][H output] -> the parameter's [H][FFN]
         const int q = e - 3 * TV_CONVW, ch = q / TS_H, o = q - ch * TS_H;
@@ -1749,16 +1758,422 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
     }
     PHASE_END();
 }
+
+// The same backward with HALF the workgroup (round 5): one workgroup = one sequence x TWO conv groups (4 waves = (group, half of the frames)), the images
+// 112-byte rows, 58 KB of LDS — two workgroups share a CU, so one's cold start (the prologue's memory round trip, 10 % of the big kernel's wave time) and
+// barrier waits overlap the other's math.  The strip phase takes two strips per wave; dy is read by four workgroups per sequence (L2).  No room for the
+// dy image beside two resident workgroups: this variant emits the h5 operand and the W2 weight gradient is wgrad.hip's, as in round 4.
+__global__ __launch_bounds__(256, 2) void tconvffn_bwd_q_kernel(nbss_cfg c, LayerPtrs lp, TvW W, TvIn sv, const bf16_t* __restrict__ dy, float* __restrict__ part,
+                                                                bf16_t* __restrict__ part16, bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1) {
+    NBSS_LDS(smem);
+    const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
+    bf16_t* S = reinterpret_cast<bf16_t*>(smem);         // [NT + TB_PAD][TQ_RS]  the gradient chain, in place
+    bf16_t* H = S + (size_t)(NT + TB_PAD) * TQ_RS;      // [NT + 2][TQ_RS]       the activation of the current stage (first: the W2^T window)
+    const size_t h_el = (size_t)(NT + 2) * TQ_RS > (size_t)12 * 512 ? (size_t)(NT + 2) * TQ_RS : (size_t)12 * 512;
+    float* red = reinterpret_cast<float*>(H + h_el);     // [2 groups][2 halves][2]
+    float* gnp = red + 8;                                // [2 halves][2 kinds][48] GroupNorm affine partial sums
+    bf16_t* mbox = reinterpret_cast<bf16_t*>(gnp + 4 * 48);  // [4 waves][24]
+    bf16_t* wl = H;
+    PHASE_BEGIN(mbox + 4 * TS_CG);
+    const TsLane L;
+    const int w = wave_id_u(), tid = threadIdx.x;
+    const int row = blockIdx.x >> 2, gq = blockIdx.x & 3;  // the sequence, its group pair (conv groups 2 gq, 2 gq + 1)
+    const size_t n0 = (size_t)row * T_, ntok = (size_t)c.B * c.F * T_;
+    const bf16_t* dyb = dy + n0 * TS_H;
+
+    // group-phase roles (wave = (group gl, half th)) — needed already here: the FIRST group stage's input (a3 of the wave's own strips)
+    // is requested together with the strip phase's inputs
+    const int gl = w >> 1, th = w & 1, g = 2 * gq + gl;
+    const int s_beg = th ? NSL : 0, s_end = th ? NS : NSL, nblk = (s_end - s_beg + TB_SB - 1) / TB_SB;
+    const size_t gsv = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;  // this lane's piece of token 0 in a saved [G][N][24] tensor
+    P6 pn0, pn1, pn2, pn3, pd0, pd1, pd2, pd3, ra0, ra1, ra2, ra3;
+#define TV_LOADA(k, src, dst)                                                        \
+    {                                                                                \
+        const int t_ = 32 * (s_beg + (k)) + L.n, tc_ = t_ < T_ ? t_ : T_ - 1;        \
+        if (s_beg + (k) < s_end) p6_gload((src) + gsv + (size_t)tc_ * TS_CG, dst);   \
+        else                                                                         \
+            for (int i_ = 0; i_ < 6; ++i_) dst.d[i_] = 0u;                           \
+    }
+#define TV_LOADA4(src) TV_LOADA(0, src, ra0) TV_LOADA(1, src, ra1) TV_LOADA(2, src, ra2) TV_LOADA(3, src, ra3)
+    // ---- strip phase: dh5 = W2^T dy -> S at bases (1,7) (it becomes da5 in place once a5 has been rebuilt from h4, stage 1b) --------------------
+    {
+        u32x4 wr[3];  // 12 W2^T fragments of this workgroup's two groups
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wr[i] = reinterpret_cast<const u32x4*>(W.W2T + (size_t)gq * 12 * 512)[tid + i * 256];
+        // four waves, up to eight strips: wave w takes strips w and w + 4 (both requested before the first wait)
+        u32x4 rawd[2][6];
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int t = 32 * (w + 4 * k2) + L.n, tc = t < T_ ? t : T_ - 1;
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) rawd[k2][ks] = *reinterpret_cast<const u32x4*>(dyb + (size_t)tc * TS_H + 16 * ks + 8 * L.h);
+        }
+        TV_LOADA4(sv.a3)
+        for (int i = tid; i < 4 * TQ_RS / 2; i += 256) reinterpret_cast<uint32_t*>(S)[i] = 0u;
+        for (int i = tid; i < 5 * TQ_RS / 2; i += 256) reinterpret_cast<uint32_t*>(S + (size_t)(NT + 4) * TQ_RS)[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) reinterpret_cast<u32x4*>(wl)[tid + i * 256] = wr[i];
+        PHASE(0);
+        lds_barrier();
+        PHASE(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int sw = w + 4 * k2, t = 32 * sw + L.n;
+            if (sw < NS) {
+                const uint32_t vm = lane_mask(t < T_);
+                FragH dq[6];
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) dq[ks].v = __builtin_bit_cast(s16x8, rawd[k2][ks]);
+                bf16_t* srow = S + (size_t)((sw < NSL ? 1 : 7) + t) * TQ_RS + 4 * L.h;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    FragH w2t[6];
+                    load_wfrags<6>(w2t, wl, q, L.lane);
+                    f32x16 d5 = mma32(w2t[0], dq[0], f32x16_zero());
+#pragma unroll
+                    for (int ks = 1; ks < 6; ++ks) d5 = mma32(w2t[ks], dq[ks], d5);
+                    float dv[12];
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) dv[r] = d5[r];
+                    P6 pd;
+                    p6_pack(dv, vm, pd);
+                    p6_store(srow + q * TS_CG, pd);
+                }
+            }
+        }
+    }
+    PHASE(2);
+
+    // ---- group phases: wave = (group gl, half th) ------------------------------------------------------------------------------------------------
+    bf16_t* Sc = S + gl * TS_CG;
+    bf16_t* Hc = H + gl * TS_CG;
+    const int run0 = 32 * s_beg, nrun = 32 * (s_end - s_beg);
+    auto rowp = [&](int tt, int bl, int bu) -> const bf16_t* { return Sc + (size_t)((tt < TS ? bl : bu) + tt) * TQ_RS; };
+    auto orow = [&](int tt, int bl, int bu) -> bf16_t* { return Sc + (size_t)((th ? bu : bl) + tt) * TQ_RS + 4 * L.h; };
+    bf16_t* mb = mbox + w * TS_CG;
+    auto fetch_cross = [&](int bl, int bu) {  // (see tconvffn_bwd_s_kernel: the one row a wave reads across the middle is copied before the stage writes)
+        const bf16_t* src = Sc + (size_t)(th ? bl + TS - 1 : bu + TS) * TQ_RS;
+        if (L.lane < 6) *reinterpret_cast<u32x2*>(mb + 4 * L.lane) = *reinterpret_cast<const u32x2*>(src + 4 * L.lane);
+        lds_barrier();
+    };
+    auto rowx = [&](int tt, int bl, int bu) -> const bf16_t* {
+        const bool lower = tt < TS;
+        const bf16_t* r = Sc + (size_t)((lower ? bl : bu) + tt) * TQ_RS;
+        return lower != (th == 0) ? mb : r;
+    };
+    float gw[12], gb[12];
+    chan_vec12(lp.p[P_TF_GN_W] + g * TS_CG, L.h, gw);
+    chan_vec12(lp.p[P_TF_GN_B] + g * TS_CG, L.h, gb);
+    const float cnt = (float)(TS_CG * T_);
+    const float gmean = sv.gn[((size_t)row * TS_G + g) * 2], grstd = sv.gn[((size_t)row * TS_G + g) * 2 + 1];
+    float* prow = part + (size_t)row * TQ_PSTRIDE + 2 * TS_FFN;   // conv bias blocks of the fp32 row
+    bf16_t* prow16 = part16 + (size_t)row * TQ_P16;
+
+    FragH wt[5];
+    load_wfrags<5>(wt, W.C3T, g, L.lane);
+    // per-strip parks pn* / pd* / ra*: named registers + per-dword selects (indexed structs become scratch arrays, see the kernel above)
+#define TV_PICK(dst, k_, hib_, q0, q1, q2, q3)                                                            \
+    for (int i_ = 0; i_ < 6; ++i_) {                                                                      \
+        const uint32_t lo_ = (k_) == 0 ? q0.d[i_] : q1.d[i_], hi_ = (k_) == 0 ? q2.d[i_] : q3.d[i_];      \
+        dst.d[i_] = (hib_) ? hi_ : lo_;                                                                   \
+    }
+#define TB_BLOCKS(fwd_dir)                                                   \
+    for (int bi_ = 0; bi_ < nblk; ++bi_)                                     \
+        for (int s0 = s_beg + TB_SB * (((fwd_dir) == (th == 0)) ? bi_ : nblk - 1 - bi_), once_ = 1; once_; once_ = 0)
+
+    // stage 1: a3 -> a3hat (parked), h4 = SiLU(a3hat gw + gb) -> H, SiLU' parked
+    lds_barrier();  // S = da5 is complete; the weight window (aliasing H) is dead
+    PHASE(3);
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(Hc + (size_t)(th ? NT + 1 : 0) * TQ_RS + 4 * L.lane) = (u32x2){0u, 0u};  // H's halo rows
+#define TV_STAGE1(k, RA, PN, PD)                                                          \
+    if (s_beg + (k) < s_end) {                                                            \
+        const int t = 32 * (s_beg + (k)) + L.n;                                           \
+        const uint32_t vm = lane_mask(t < T_);                                            \
+        float a3[12], hv[12], dv[12];                                                     \
+        p6_unpack(RA, a3);                                                                \
+        for (int q = 0; q < 12; ++q) a3[q] = (a3[q] - gmean) * grstd;                     \
+        p6_pack(a3, vm, PN);                                                              \
+        p6_unpack(PN, a3);                                                                \
+        for (int q = 0; q < 12; ++q) silu_dsilu(a3[q] * gw[q] + gb[q], hv[q], dv[q]);     \
+        P6 ph;                                                                            \
+        p6_pack(hv, vm, ph);                                                              \
+        p6_pack(dv, vm, PD);                                                              \
+        p6_store(Hc + (size_t)(1 + t) * TQ_RS + 4 * L.h, ph);                             \
+    } else {                                                                              \
+        for (int i_ = 0; i_ < 6; ++i_) PN.d[i_] = PD.d[i_] = 0u;                          \
+    }
+    TV_STAGE1(0, ra0, pn0, pd0)
+    TV_STAGE1(1, ra1, pn1, pd1)
+    TV_STAGE1(2, ra2, pn2, pd2)
+    TV_STAGE1(3, ra3, pn3, pd3)
+#undef TV_STAGE1
+    TV_LOADA4(sv.a2)  // needed in B3b: requested now, AHEAD of the contraction's partial-row stores (loads and stores share vmcnt)
+    PHASE(4);
+    lds_barrier();
+    // stage 1b: a5 = conv3(h4) rebuilt from H (own strips; neighbours' rows are complete), (h5, SiLU'(a5)) from one sigmoid: h5 -> operand,
+    // da5 = dh5 * SiLU'(a5) in place in S (this lane's own piece)
+    {
+        FragH wf[5];
+        load_wfrags<5>(wf, W.C3, g, L.lane);
+#pragma unroll 1
+        for (int s0 = s_beg; s0 < s_end; s0 += TB_SB) {
+            FragH b[TB_SB][5];
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const bf16_t* r1 = Hc + (size_t)(1 + 32 * (s0 + k) + L.n) * TQ_RS;
+                    conv_bfrags3(L, r1 - TQ_RS, r1, r1 + TQ_RS, b[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    const bool tv = t < T_;
+                    const uint32_t vm = lane_mask(tv);
+                    const f32x16 a5 = conv_mma(wf, b[k]);
+                    bf16_t* r = orow(t, 1, 7);
+                    P6 p5, ph, pd;
+                    p6_load(r, p5);
+                    float hv[12], dv[12], d5[12];
+                    p6_unpack(p5, d5);
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {
+                        silu_dsilu(a5[q], hv[q], dv[q]);
+                        dv[q] *= d5[q];
+                    }
+                    p6_pack(hv, vm, ph);
+                    p6_pack(dv, vm, pd);
+                    p6_store(r, pd);
+                    p6_gstore(op_h5 + gsv + (size_t)t * TS_CG, ph, tv, true);
+                }
+        }
+    }
+    lds_barrier();
+    PHASE(5);
+    // stage 2: conv3 weight gradient: da5 (1,7) x h4
+    {
+        f32x4 acc[5], bsum;
+        tv_contract_t<TQ_RS>(Sc, Hc, 1, 7, NS, NSL, th, acc, bsum);
+        tv_flush(prow16 + 2 * TV_CONVW, prow + 2 * TS_FFN, g, th, acc, bsum);
+    }
+    PHASE(6);
+    // B3: conv3^T: da5 (1,7) -> dh4; dn3 = dh4 * SiLU'(n3) -> S (2,6); GroupNorm backward sums and affine gradients
+    fetch_cross(1, 7);
+    PHASE(7);
+    {
+        float sa = 0.f, sb = 0.f, dgw[12], dgb[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) dgw[r] = dgb[r] = 0.f;
+#pragma unroll 1
+        TB_BLOCKS(false) {
+            FragH b[TB_SB][5];
+            const bool hib = s0 - s_beg >= 2;
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    conv_bfrags3(L, rowx(t - 1, 1, 7), rowp(t, 1, 7), rowx(t + 1, 1, 7), b[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < TB_SB; ++k)
+                if (s0 + k < s_end) {
+                    const int t = 32 * (s0 + k) + L.n;
+                    const uint32_t vm = lane_mask(t < T_);
+                    const f32x16 dh4 = conv_mma(wt, b[k]);
+                    P6 pn, pdv, pd;
+                    TV_PICK(pn, k, hib, pn0, pn1, pn2, pn3)
+                    TV_PICK(pdv, k, hib, pd0, pd1, pd2, pd3)
+                    float ah[12], d4[12], dn[12];
+                    p6_unpack(pn, ah);
+                    p6_unpack(pdv, d4);
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) dn[r] = dh4[r] * d4[r];
+                    p6_pack(dn, vm, pd);
+                    p6_unpack(pd, dn);  // masked, bf16 (what the next stage reads back)
+#pragma unroll
+                    for (int r = 0; r < 12; ++r) {
+                        dgw[r] += dn[r] * ah[r];
+                        dgb[r] += dn[r];
+                        sa += gw[r] * dn[r];
+                        sb += gw[r] * dn[r] * ah[r];
+                    }
+                    p6_store(orow(t, 2, 6), pd);
+                }
+        }
+        sa = wave_sum64(sa);
+        sb = wave_sum64(sb);
+        if (L.lane == 0) {
+            red[(gl * 2 + th) * 2] = sa;
+            red[(gl * 2 + th) * 2 + 1] = sb;
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const float a = half_sum32(dgw[r]), bq = half_sum32(dgb[r]);
+            if (L.n == 0) {
+                const int ch = gl * TS_CG + (r & 3) + 8 * (r >> 2) + 4 * L.h;
+                gnp[(th * 2 + 0) * 48 + ch] = a;
+                gnp[(th * 2 + 1) * 48 + ch] = bq;
+            }
+        }
+        if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 6 : 1) * TQ_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    }
+    load_wfrags<5>(wt, W.C2T, g, L.lane);
+    PHASE(8);
+    lds_barrier();
+    PHASE(9);
+    // B3b (in place, own values): da3 = rstd (gw dn3 - mean(gw dn3) - a3hat mean(gw dn3 a3hat)) -> S (2,6);
+    // and the next activation: (h2, SiLU'(a2)) from the saved a2: h2 -> H (every wave is past its conv3 contraction), SiLU' parked
+    {
+        const float msa = (red[gl * 4] + red[gl * 4 + 2]) / cnt, msb = (red[gl * 4 + 1] + red[gl * 4 + 3]) / cnt;
+#define TV_STAGE3B(k, RA, PN, PD)                                                         \
+    if (s_beg + (k) < s_end) {                                                            \
+        const int t = 32 * (s_beg + (k)) + L.n;                                           \
+        const uint32_t vm = lane_mask(t < T_);                                            \
+        bf16_t* r = orow(t, 2, 6);                                                        \
+        P6 pdn, po, ph;                                                                   \
+        p6_load(r, pdn);                                                                  \
+        float dn[12], ah[12], a2[12], hv[12], dv[12];                                     \
+        p6_unpack(pdn, dn);                                                               \
+        p6_unpack(PN, ah);                                                                \
+        for (int q = 0; q < 12; ++q) dn[q] = grstd * (gw[q] * dn[q] - msa - ah[q] * msb); \
+        p6_pack(dn, vm, po);                                                              \
+        p6_store(r, po);                                                                  \
+        p6_unpack(RA, a2);                                                                \
+        for (int q = 0; q < 12; ++q) silu_dsilu(a2[q], hv[q], dv[q]);                     \
+        p6_pack(hv, vm, ph);                                                              \
+        p6_pack(dv, vm, PD);                                                              \
+        p6_store(Hc + (size_t)(1 + t) * TQ_RS + 4 * L.h, ph);                             \
+    }
+        TV_STAGE3B(0, ra0, pn0, pd0)
+        TV_STAGE3B(1, ra1, pn1, pd1)
+        TV_STAGE3B(2, ra2, pn2, pd2)
+        TV_STAGE3B(3, ra3, pn3, pd3)
+#undef TV_STAGE3B
+        TV_LOADA4(sv.a1)  // needed at the end of B2: requested ahead of the conv2 contraction's stores
+    }
+    PHASE(10);
+    lds_barrier();
+    PHASE(11);
+    // conv2 weight gradient: da3 (2,6) x h2
+    {
+        f32x4 acc[5], bsum;
+        tv_contract_t<TQ_RS>(Sc, Hc, 2, 6, NS, NSL, th, acc, bsum);
+        tv_flush(prow16 + 1 * TV_CONVW, prow + 1 * TS_FFN, g, th, acc, bsum);
+    }
+    PHASE(12);
+    // B2: conv2^T: da3 (2,6) -> dh2; da2 = dh2 * SiLU'(a2) (parked) -> S (3,5)
+    fetch_cross(2, 6);
+    PHASE(13);
+#pragma unroll 1
+    TB_BLOCKS(false) {
+        FragH b[TB_SB][5];
+        const bool hib = s0 - s_beg >= 2;
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowx(t - 1, 2, 6), rowp(t, 2, 6), rowx(t + 1, 2, 6), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const uint32_t vm = lane_mask(t < T_);
+                const f32x16 dh2 = conv_mma(wt, b[k]);
+                P6 pdv, po;
+                TV_PICK(pdv, k, hib, pd0, pd1, pd2, pd3)
+                float d2[12], o[12];
+                p6_unpack(pdv, d2);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) o[r] = dh2[r] * d2[r];
+                p6_pack(o, vm, po);
+                p6_store(orow(t, 3, 5), po);
+            }
+    }
+    if (L.lane < 6) *reinterpret_cast<u32x2*>(Sc + (size_t)(th ? NT + 5 : 2) * TQ_RS + 4 * L.lane) = (u32x2){0u, 0u};
+    load_wfrags<5>(wt, W.C1T, g, L.lane);
+    // (h1, SiLU'(a1)) from the saved a1: h1 -> H (every wave passed fetch_cross' barrier, i.e. its conv2 contraction), SiLU' parked in pn*
+#define TV_STAGE5(k, RA, PN)                                                              \
+    if (s_beg + (k) < s_end) {                                                            \
+        const int t = 32 * (s_beg + (k)) + L.n;                                           \
+        const uint32_t vm = lane_mask(t < T_);                                            \
+        float a1[12], hv[12], dv[12];                                                     \
+        P6 ph;                                                                            \
+        p6_unpack(RA, a1);                                                                \
+        for (int q = 0; q < 12; ++q) silu_dsilu(a1[q], hv[q], dv[q]);                     \
+        p6_pack(hv, vm, ph);                                                              \
+        p6_pack(dv, vm, PN);                                                              \
+        p6_store(Hc + (size_t)(1 + t) * TQ_RS + 4 * L.h, ph);                             \
+    }
+    TV_STAGE5(0, ra0, pn0)
+    TV_STAGE5(1, ra1, pn1)
+    TV_STAGE5(2, ra2, pn2)
+    TV_STAGE5(3, ra3, pn3)
+#undef TV_STAGE5
+    PHASE(14);
+    lds_barrier();
+    PHASE(15);
+    // conv1 weight gradient: da2 (3,5) x h1
+    {
+        f32x4 acc[5], bsum;
+        tv_contract_t<TQ_RS>(Sc, Hc, 3, 5, NS, NSL, th, acc, bsum);
+        tv_flush(prow16, prow, g, th, acc, bsum);
+    }
+    PHASE(16);
+    // B1: conv1^T: da2 (3,5) -> dh1; da1 = dh1 * SiLU'(a1) (parked) -> S (4,4) -> operand (whole rows, this wave's own run)
+    fetch_cross(3, 5);
+    PHASE(17);
+#pragma unroll 1
+    TB_BLOCKS(false) {
+        FragH b[TB_SB][5];
+        const bool hib = s0 - s_beg >= 2;
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                conv_bfrags3(L, rowx(t - 1, 3, 5), rowp(t, 3, 5), rowx(t + 1, 3, 5), b[k]);
+            }
+#pragma unroll
+        for (int k = 0; k < TB_SB; ++k)
+            if (s0 + k < s_end) {
+                const int t = 32 * (s0 + k) + L.n;
+                const uint32_t vm = lane_mask(t < T_);
+                const f32x16 dh1 = conv_mma(wt, b[k]);
+                P6 pdv, po;
+                TV_PICK(pdv, k, hib, pn0, pn1, pn2, pn3)
+                float d1[12], o[12];
+                p6_unpack(pdv, d1);
+#pragma unroll
+                for (int r = 0; r < 12; ++r) o[r] = dh1[r] * d1[r];
+                p6_pack(o, vm, po);
+                p6_store(orow(t, 4, 4), po);
+            }
+    }
+    wave_lds_sync();
+    rows_gstore_t<128 * 3, TQ_RS>(op_da1 + ((size_t)g * ntok + n0 + run0) * TS_CG, Sc + (size_t)(4 + run0) * TQ_RS, nrun, T_ - run0);
+    PHASE(18);
+#undef TB_BLOCKS
+#undef TV_PICK
+#undef TV_LOADA4
+#undef TV_LOADA
+    // GroupNorm affine partial sums of this workgroup's 96 channels -> the sequence's `part` row (written in B3, two barriers ago)
+    for (int i = tid; i < 2 * 48; i += 256) {
+        const int kind = i / 48, ch = i % 48;
+        part[(size_t)row * TQ_PSTRIDE + kind * TS_FFN + gq * 48 + ch] = gnp[(0 * 2 + kind) * 48 + ch] + gnp[(1 * 2 + kind) * 48 + ch];
+    }
+    PHASE_END();
+}
 PHASE_READER(nbss_phase_read_tconvffn_bwd_v)
 
 size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV_PSTRIDE * sizeof(float) + TV_P16 * sizeof(bf16_t)); }
 // fold of the bf16 weight-gradient partial rows into G (fp32); offs = flat-gradient offsets of the three conv weights and of W2; `slices`: TV_RSL x TV_P16 floats of scratch
-int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, hipStream_t st) {
-    const int nrows = c.B * c.F, nsl = nrows < TV_RSL ? nrows : TV_RSL;
-    NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((TV_P16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices);
+// with_w2: the rows carry the dW2 block behind the three conv blocks (tconvffn_bwd_v_kernel) or not (tconvffn_bwd_q_kernel)
+int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, bool with_w2, hipStream_t st) {
+    const int nrows = c.B * c.F, nsl = nrows < TV_RSL ? nrows : TV_RSL, p16 = with_w2 ? TV_P16 : TQ_P16;
+    NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;
-    NBSS_LAUNCH(tconv_part_reduce2_kernel, dim3((TV_P16 + 255) / 256), dim3(256), 0, st, (const float*)slices, nsl, G, offs[0], offs[1], offs[2], offs[3]);
+    NBSS_LAUNCH(tconv_part_reduce2_kernel, dim3((p16 + 255) / 256), dim3(256), 0, st, (const float*)slices, nsl, G, offs[0], offs[1], offs[2], offs[3], p16);
     return NBSS_CHECK_LAUNCH();
 }
 size_t tconvffn_v_slices_bytes() { return (size_t)TV_RSL * TV_P16 * sizeof(float); }
@@ -1779,6 +2194,23 @@ int tconvffn_bwd_v_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     int e = NBSS_SET_MAX_LDS(tconvffn_bwd_v_kernel, lds);
     if (e) return e;
     NBSS_LAUNCH(tconvffn_bwd_v_kernel, dim3(2 * c.B * c.F), dim3(512), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_da1);
+    return NBSS_CHECK_LAUNCH();
+}
+int tconvffn_bwd_q_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, const void* packed, int layer, const void* dy, void* tsave, void* op_h5, void* op_da1,
+                          hipStream_t st) {
+    bf16_t* part16 = reinterpret_cast<bf16_t*>(part + (size_t)c.B * c.F * TQ_PSTRIDE);
+    if (c.dtype != NBSS_BF16 || c.T > 256 || !tsave) return NBSS_EUNSUPPORTED;
+    const size_t NT = (size_t)((c.T + 31) / 32) * 32;
+    const size_t h_el = (NT + 2) * TQ_RS > (size_t)12 * 512 ? (NT + 2) * TQ_RS : (size_t)12 * 512;
+    const size_t lds = ((NT + TB_PAD) * TQ_RS + h_el) * sizeof(bf16_t) + (8 + 4 * 48) * sizeof(float) + 4 * TS_CG * sizeof(bf16_t) + PHASE_LDS_BYTES;
+    const bf16_t* pk = (const bf16_t*)packed;
+    TvW W = {pk + pack_off(c, layer, K_TS_W2_T), pk + pack_off(c, layer, K_TS_C1_T), pk + pack_off(c, layer, K_TS_C2_T), pk + pack_off(c, layer, K_TS_C3_T),
+             pk + pack_off(c, layer, K_TS_C3)};
+    const TsSave s = ts_save_ptrs(c, tsave);
+    TvIn in = {s.a1, s.a2, s.a3, s.gn};
+    int e = NBSS_SET_MAX_LDS(tconvffn_bwd_q_kernel, lds);
+    if (e) return e;
+    NBSS_LAUNCH(tconvffn_bwd_q_kernel, dim3(4 * c.B * c.F), dim3(256), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_h5, (bf16_t*)op_da1);
     return NBSS_CHECK_LAUNCH();
 }
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave) { return ts_save_ptrs(c, tsave).ln; }
