@@ -4,6 +4,7 @@ usage: python tools/nbc2_throughput.py [batch] [reps]"""
 import json
 import sys
 import time
+import warnings
 from pathlib import Path
 
 import torch
@@ -36,7 +37,7 @@ def main():
     assert runner is not None
 
     def use_native(on):
-        M._NATIVE[net] = runner if on else None
+        M._NATIVE[net] = (runner if on else None, None if on else "switched off by tools/nbc2_throughput.py")
 
     # inference
     with torch.no_grad():
@@ -66,4 +67,5 @@ def main():
 
 
 if __name__ == "__main__":
+    warnings.simplefilter("ignore")  # (the module reports its torch.nn path once per reason)
     main()
