@@ -720,7 +720,15 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
     return NBSS_CHECK_LAUNCH();
 }
 
-#define FC_BWD_TT 2  // frames per workgroup of the bf16 backward (measured: 2 frames, one workgroup per CU beats 1 frame, two per CU by 2.2x in wave time)
+// frames per workgroup of the bf16 backward.  Round 5: ONE — the images are 62 KB, the 8-wave instance holds 122 VGPRs: two workgroups share a CU and one's
+// prologue (the slab's memory round trip, a third of the wave time) overlaps the other's math: 403 -> 294 us per launch in order, the step 657 -> 688 utt/s
+// (same box).  (Rounds 1-4 ran two frames per workgroup, one per CU: measured 2.2x better in round 1, before the LDS-DMA prologue and the fused weight gradient;
+// -DNBSS_FC_TT2 builds that variant.)  Twice the partial rows for the fold (one [96][12][5] weight gradient per workgroup): 197 MB per launch at batch 32.
+#ifdef NBSS_FC_TT2
+#define FC_BWD_TT 2
+#else
+#define FC_BWD_TT 1
+#endif
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                    void* ws, hipStream_t st, const Side* sd) {
@@ -732,7 +740,9 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
 #ifdef NBSS_FC_NW8
     const bool nine = false;
 #else
-    const bool nine = (cdiv(c.F, 16) * FC_BWD_TT) % 9 == 0;
+    // nine waves when the row phases have a multiple of nine units AND the instance is alone on its CU (two-frame slabs); one-frame slabs: two 8-wave
+    // workgroups per CU at <= 128 VGPRs (two of nine waves would not fit the register file)
+    const bool nine = FC_BWD_TT == 2 && (cdiv(c.F, 16) * FC_BWD_TT) % 9 == 0;
 #endif
     // (F > 160, the 16-kHz geometry: the two images of a 2-frame slab no longer fit the LDS -> one frame per workgroup; the fp32 stream
     //  images of even one frame are 229 KB at F = 257: fconv_bwd_t returns NBSS_EUNSUPPORTED there, fp32 TRAINING stops at F = 160)
