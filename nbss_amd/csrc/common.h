@@ -234,6 +234,27 @@ NBSS_DEV float row_reduce16x16(const float (&v)[16]) {
     for (int i = 0; i < 2; ++i) c[i] = (c2 ? b[2 + i] : b[i]) + row_pair<2>(c2 ? b[i] : b[2 + i]);
     return (c3 ? c[1] : c[0]) + row_pair<3>(c3 ? c[0] : c[1]);
 }
+// Strided fold in a fixed order with N loads in flight: sum of p[x * stride] over x0 <= x < x1 — accumulator k takes x = x0 + k (mod N), the accumulators
+// meet in a pairwise tree.  The folds of the partial parameter gradients are chains of dependent HBM / L2 round trips (64 rows per thread at four in
+// flight: 16 round trips, 9 - 17 us per launch and ~100 launches per step — a quarter of a batch-2 step): N = 16 quarters the chain.
+template <int N>
+NBSS_DEV float fold_strided(const float* p, size_t stride, int x0, int x1) {
+    float s[N], v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) s[k] = 0.f;
+    for (int x = x0; x < x1; x += N) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = x + k < x1 ? p[(size_t)(x + k) * stride] : 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s[k] += v[k];
+    }
+#pragma unroll
+    for (int h = N / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int k = 0; k < h; ++k) s[k] += s[k + h];
+    }
+    return s[0];
+}
 NBSS_DEV float wave_sum64(float v) {
     v = row_sum16(v);
     v += __shfl_xor(v, 16);

@@ -531,14 +531,15 @@ __global__ void full_sq_finalize_kernel(const float* __restrict__ tmp, const flo
     if (i < FL_SQ) dbs[i] += tmp[FL_SQ * FL_H + i];
 }
 
-// frames per slab: the largest of 8 / 4 / 2 that still gives every CU a workgroup.  The LinearGroup passes cost the same per slab whatever its
+// frames per slab: the largest of 8 / 4 / 2 that still gives (nearly) every CU a workgroup.  The LinearGroup passes cost the same per slab whatever its
 // width (their MFMA N dimension is 16 frames wide either way), the row passes scale with it: at batch 2 (64 slabs of 8 frames on 256 CUs) the
-// backward kernel took 158 us per launch, 4.8 x its share of the batch-32 launch
+// backward kernel took 158 us per launch, 4.8 x its share of the batch-32 launch.  "Nearly": batch 4 x 251 frames is 252 slabs of 4 frames — 468 -> 490
+// utt/s against 504 slabs of 2 (round 5)
 static int full_tt(const nbss_cfg& c) {
     static const int forced = [] { const char* e = getenv("NBSS_FULL_TT"); return e ? atoi(e) : 0; }();  // tuning / test knob: 8, 4 or 2
     if (forced == 8 || forced == 4 || forced == 2) return forced;
     for (int tt = FL_TT_MAX; tt > 2; tt >>= 1)
-        if (c.B * cdiv(c.T, tt) >= 256) return tt;
+        if (c.B * cdiv(c.T, tt) >= 240) return tt;
     return 2;
 }
 

@@ -231,22 +231,8 @@ __global__ __launch_bounds__(64 * TW_RSL) void tailw_finalize_kernel(float* __re
     const float* pt = part + (size_t)tl * 256 + r * 64 + lane;
     const float* pb = part + (size_t)xb * ntot * 256 + (size_t)mt * 16 + 4 * g4 + r;  // bias sums of tile (nt = 0, mt): rows 4 g4 + r
     const size_t xs = (size_t)ntot * 256, bs = (size_t)ntot * 16;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, b0 = 0.f, b1 = 0.f;
-    int x = x0;
-    for (; x + 4 <= x1; x += 4) {
-        s0 += pt[(size_t)x * xs];
-        s1 += pt[(size_t)(x + 1) * xs];
-        s2 += pt[(size_t)(x + 2) * xs];
-        s3 += pt[(size_t)(x + 3) * xs];
-        b0 += pb[(size_t)x * bs] + pb[(size_t)(x + 1) * bs];
-        b1 += pb[(size_t)(x + 2) * bs] + pb[(size_t)(x + 3) * bs];
-    }
-    for (; x < x1; ++x) {
-        s0 += pt[(size_t)x * xs];
-        b0 += pb[(size_t)x * bs];
-    }
-    red[sl * 64 + lane] = (s0 + s1) + (s2 + s3);
-    red[(TW_RSL + sl) * 64 + lane] = b0 + b1;
+    red[sl * 64 + lane] = fold_strided<16>(pt, xs, x0, x1);
+    red[(TW_RSL + sl) * 64 + lane] = fold_strided<16>(pb, bs, x0, x1);
     __syncthreads();  // (also: every slice has read workgroup 0's values of this block, whose slot receives the column sums below)
     if (sl) return;
     const float D = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);

@@ -1274,16 +1274,7 @@ __global__ __launch_bounds__(256) void tconv_part_reduce2_kernel(const float* __
                                                                  long long off3, int P16) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= P16) return;
-    float a = 0.f, b = 0.f, c2 = 0.f, d = 0.f;
-    int y = 0;
-    for (; y + 4 <= nsl; y += 4) {
-        a += slices[(size_t)y * P16 + e];
-        b += slices[(size_t)(y + 1) * P16 + e];
-        c2 += slices[(size_t)(y + 2) * P16 + e];
-        d += slices[(size_t)(y + 3) * P16 + e];
-    }
-    for (; y < nsl; ++y) a += slices[(size_t)y * P16 + e];
-    const float sum = (a + b) + (c2 + d);
+    const float sum = fold_strided<16>(slices + e, (size_t)P16, 0, nsl);
     if (e >= 3 * TV_CONVW) {  // dW2 partial: [FFN channel][H output] -> the parameter's [H][FFN]
         const int q = e - 3 * TV_CONVW, ch = q / TS_H, o = q - ch * TS_H;
         G[off3 + (size_t)o * TS_FFN + ch] += sum;

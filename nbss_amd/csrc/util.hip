@@ -22,28 +22,27 @@ __global__ void affine_slices_kernel(float* __restrict__ part, int nwg, int naff
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= naff) return;
     const int w0 = (int)((long)nwg * blockIdx.y / gridDim.y), w1 = (int)((long)nwg * (blockIdx.y + 1) / gridDim.y);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = w0;
-    for (; w + 4 <= w1; w += 4) {
-        s0 += part[(size_t)w * naff + e];
-        s1 += part[(size_t)(w + 1) * naff + e];
-        s2 += part[(size_t)(w + 2) * naff + e];
-        s3 += part[(size_t)(w + 3) * naff + e];
-    }
-    for (; w < w1; ++w) s0 += part[(size_t)w * naff + e];
-    part[(size_t)w0 * naff + e] = (s0 + s1) + (s2 + s3);
+    const float s = fold_strided<16>(part + e, (size_t)naff, w0, w1);
+    part[(size_t)w0 * naff + e] = s;
 }
 __global__ void affine_final_kernel(const float* __restrict__ part, int nwg, int naff, int nsl, AffSegs segs, float* __restrict__ G) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= naff) return;
-    float s4[4] = {0.f, 0.f, 0.f, 0.f};
-    int y = 0;
-    for (; y + 4 <= nsl; y += 4) {  // four loads in flight; the order of the adds is fixed
+    float s16[16], v16[16];  // sixteen loads in flight; the order of the adds is fixed
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s4[k] += part[(size_t)((long)nwg * (y + k) / nsl) * naff + e];
+    for (int k = 0; k < 16; ++k) s16[k] = 0.f;
+    for (int y = 0; y < nsl; y += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v16[k] = y + k < nsl ? part[(size_t)((long)nwg * (y + k) / nsl) * naff + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s16[k] += v16[k];
     }
-    for (; y < nsl; ++y) s4[0] += part[(size_t)((long)nwg * y / nsl) * naff + e];
-    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+#pragma unroll
+    for (int h = 8; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int k = 0; k < h; ++k) s16[k] += s16[k + h];
+    }
+    const float s = s16[0];
     int r = e;
     for (int i = 0; i < segs.n; ++i) {
         if (r < segs.cnt[i]) {

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(WG_THREADS, NS > 14 ? 1 : 2) void wgrad_tr3_kernel(
 
 
 // Second pass of the two-stage flush: ONE block per (tile, accumulator register r, y) folds all x-blocks' partial values of its 64 elements in a fixed
-// order — thread (slice, lane) sums its slice of the x-blocks with eight loads in flight, the four slices meet in LDS, slice 0 adds them in slice
+// order — thread (slice, lane) sums its slice of the x-blocks with sixteen loads in flight (fold_strided), the four slices meet in LDS, slice 0 adds them in slice
 // order and adds the result to dW with a plain read-modify-write (every dW element belongs to exactly one (tile, register, lane); gradient launches of
 // one parameter are stream-ordered).  No float atomics: the parameter gradient is bitwise repeatable.  256-thread blocks on purpose: the fold runs on
 // the gradient stream beside the main stream's one-workgroup-per-CU kernels, and a 1024-thread block (one block per whole tile, the first version of
@@ -566,16 +566,7 @@ __global__ __launch_bounds__(64 * WG_RSL) void wgrad_reduce_kernel(WgradArgs a, 
     const int x0 = sl < nsl ? (int)((long)xb * sl / nsl) : 0, x1 = sl < nsl ? (int)((long)xb * (sl + 1) / nsl) : 0;
     const float* pt = a.part + ((size_t)y * xb * ntot + tl) * 256 + r * 64 + lane;
     const size_t xs = (size_t)ntot * 256;
-    float s[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] = 0.f;
-    int x = x0;
-    for (; x + 8 <= x1; x += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += pt[(size_t)(x + k) * xs];
-    }
-    for (; x < x1; ++x) s[0] += pt[(size_t)x * xs];
-    red[sl * 64 + lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[sl * 64 + lane] = fold_strided<16>(pt, xs, x0, x1);
     int g, mt, nt;
     if (nt_major) {  // wgrad_tr3_kernel: tl = nt * nfirst + g * mtiles + mt
         const int nfirst = ntot / ntiles, gm = tl % nfirst;
@@ -588,14 +579,7 @@ __global__ __launch_bounds__(64 * WG_RSL) void wgrad_reduce_kernel(WgradArgs a, 
     const bool bias = a.dbias && nt == 0 && r == 0;  // the tile's 16 bias sums: the r = 0 block
     if (bias && lane < 16) {
         const float* pbias = a.part + (size_t)gridDim.z * xb * ntot * 256 + ((size_t)y * xb * ntot + tl) * 16 + lane;
-        float b0 = 0.f, b1 = 0.f;
-        int xx = x0;
-        for (; xx + 2 <= x1; xx += 2) {
-            b0 += pbias[(size_t)xx * ntot * 16];
-            b1 += pbias[(size_t)(xx + 1) * ntot * 16];
-        }
-        if (xx < x1) b0 += pbias[(size_t)xx * ntot * 16];
-        red[WG_RSL * 64 + sl * 16 + lane] = b0 + b1;
+        red[WG_RSL * 64 + sl * 16 + lane] = fold_strided<16>(pbias, (size_t)ntot * 16, x0, x1);
     }
     __syncthreads();
     if (sl) return;
