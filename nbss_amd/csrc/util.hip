@@ -18,10 +18,12 @@ int memset_async_impl(void* p, size_t bytes, hipStream_t st) {
 // slices' sums in slice order and adds the result to G with a plain read-modify-write (one owner per element; gradient launches of one parameter
 // are stream-ordered).  The very first version walked all ~1000 workgroups in 2-5 blocks and cost 49 us per call (2 ms per training step).
 #define AFF_SLICES 64
+// first row of slice y: nwg y / nsl without a division (nsl is AFF_SLICES, or nwg itself when there are fewer rows than slices)
+NBSS_DEV int aff_row0(int nwg, int nsl, int y) { return nsl == AFF_SLICES ? (int)(((unsigned)nwg * (unsigned)y) >> 6) : y; }
 __global__ void affine_slices_kernel(float* __restrict__ part, int nwg, int naff) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= naff) return;
-    const int w0 = (int)((long)nwg * blockIdx.y / gridDim.y), w1 = (int)((long)nwg * (blockIdx.y + 1) / gridDim.y);
+    const int w0 = aff_row0(nwg, gridDim.y, blockIdx.y), w1 = aff_row0(nwg, gridDim.y, blockIdx.y + 1);
     const float s = fold_strided<16>(part + e, (size_t)naff, w0, w1);
     part[(size_t)w0 * naff + e] = s;
 }
@@ -33,7 +35,7 @@ __global__ void affine_final_kernel(const float* __restrict__ part, int nwg, int
     for (int k = 0; k < 16; ++k) s16[k] = 0.f;
     for (int y = 0; y < nsl; y += 16) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v16[k] = y + k < nsl ? part[(size_t)((long)nwg * (y + k) / nsl) * naff + e] : 0.f;
+        for (int k = 0; k < 16; ++k) v16[k] = y + k < nsl ? part[(size_t)aff_row0(nwg, nsl, y + k) * naff + e] : 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) s16[k] += v16[k];
     }
@@ -53,6 +55,9 @@ __global__ void affine_final_kernel(const float* __restrict__ part, int nwg, int
     }
 }
 
+// (Tried, round 5: both passes in ONE launch — the block of an element range that draws the last ticket of a counter adds the slice sums.  The
+//  device-scope release / acquire around the ticket is a write-back + invalidate of the XCD's whole L2 on gfx950 (buffer_wbl2 sc1 / buffer_inv sc1), per
+//  block, beside the main stream's kernels: the step went 690 -> 623 utt/s at batch 32, 340 -> 228 at batch 2.  Two launches it stays.)
 // (the partial rows are consumed: `part` is scratch that the next backward call of the sub-block overwrites)
 int affine_reduce_launch(const float* part, int nwg, const AffSegs& segs, float* G, hipStream_t st) {
     int naff = 0;

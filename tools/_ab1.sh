@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-bash tools/ab_env.sh "32" 10 "NBSS_HIP_FLAVOUR=prev NBSS_X=cur NBSS_HIP_FLAVOUR=prev NBSS_X=cur NBSS_HIP_FLAVOUR=prev NBSS_X=cur"
-export NBSS_SIDE_STREAM=0
-bash tools/ab_env.sh "32" 10 "NBSS_HIP_FLAVOUR=prev NBSS_X=cur NBSS_HIP_FLAVOUR=prev NBSS_X=cur"
-unset NBSS_SIDE_STREAM
-bash tools/ab_env.sh "4 16" 20 "NBSS_HIP_FLAVOUR=prev NBSS_X=cur"
+bash tools/ab_env.sh "2 8" 20 "NBSS_FOLD_TWO_PASS=1 NBSS_FOLD_TWO_PASS=0 NBSS_FOLD_TWO_PASS=1 NBSS_FOLD_TWO_PASS=0"
+bash tools/ab_env.sh "32" 10 "NBSS_FOLD_TWO_PASS=1 NBSS_FOLD_TWO_PASS=0 NBSS_FOLD_TWO_PASS=1 NBSS_FOLD_TWO_PASS=0"
+timeout 300 python -m pytest tests/test_determinism.py tests/test_train_step.py -m gpu -x -q 2>&1 | tail -3
