@@ -9,10 +9,12 @@ timeout 600 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_ou
 bash tools/r05_trace.sh ${TAG} > /dev/null 2>&1; head -14 gpurun_out/${TAG}_rocprof_inorder.md | tail -6 | cut -c1-110
 for b in 2 4 8 16 31 32 48; do timeout 120 python bench.py --steps 5 --warmup 3 --batch $b --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['batch_per_gpu'], round(d['value'],1), 'utt/s', round(d['ms_per_step'],2), 'ms/step')"; done | tee gpurun_out/${TAG}_batch_sweep.txt
+if [ -z "$NBSS_FINAL_LITE" ]; then   # (NBSS_FINAL_LITE=1: the headline path only — the rows around it keep their earlier artefacts)
 timeout 120 python tools/sim_throughput.py 32 12 2>/dev/null | tail -1 > gpurun_out/${TAG}_sim_throughput.json; cut -c1-200 gpurun_out/${TAG}_sim_throughput.json
 timeout 120 python tools/online_throughput.py 16 32 2>/dev/null | tail -1 > gpurun_out/${TAG}_online_throughput.json; cut -c1-300 gpurun_out/${TAG}_online_throughput.json
 timeout 200 python tools/nbc2_throughput.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_nbc2_throughput.json; cut -c1-300 gpurun_out/${TAG}_nbc2_throughput.json
 timeout 200 bash tools/large_prof.sh 4 > /dev/null 2>&1; cp gpurun_out/large_rocprof.md gpurun_out/${TAG}_large_rocprof.md; head -12 gpurun_out/${TAG}_large_rocprof.md | tail -5 | cut -c1-110
+fi
 bash tools/pmc_traffic.sh 32 > /dev/null 2>&1; python tools/pmc_traffic.py 32 | grep -E "ratio|_bwd|_fwd" | head -12; rm -rf gpurun_out/traffic
 bash tools/pmc_mfma.sh 32 > /dev/null 2>&1; python tools/pmc_mfma.py 32 | tail -12; rm -rf gpurun_out/mfma
 python - <<PY
