@@ -425,19 +425,21 @@ def main():
                 roof["frac_in_order"] = None
                 roof["in_order_error"] = str(e)[:200]
         if world == 1 and not args.no_cpu_baseline:
-            # utterances/s at the other per-GPU batches of SURVEY.md §8(d) (short runs: 1 warm-up + 3 timed steps each)
+            # utterances/s at the other per-GPU batches of SURVEY.md §8(d) (short runs: 3 warm-up + 8 timed steps each — with 1 + 3 the first steps
+            # at a new shape (workspace re-sizing, allocator) weighed on the figure: batch 8 read 562 here against 585 in a run of its own)
             sweep = {str(B): round(B * args.steps / dt, 1)}
             for b2 in (2, 8, 32):
                 if b2 == B:
                     continue
                 x2, y2 = synth_batch(b2, 6, 2, 32000, 77, dev)
-                ts.step(x2, y2)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
                 for _ in range(3):
                     ts.step(x2, y2)
                 torch.cuda.synchronize()
-                sweep[str(b2)] = round(b2 * 3 / (time.perf_counter() - t1), 1)
+                t1 = time.perf_counter()
+                for _ in range(8):
+                    ts.step(x2, y2)
+                torch.cuda.synchronize()
+                sweep[str(b2)] = round(b2 * 8 / (time.perf_counter() - t1), 1)
             large = large_train_rate(lib, dev)
             if large and "value" in large:  # ... and at twice the batch (one more ~0.3 s of steps)
                 l8 = large_train_rate(lib, dev, batch=8, steps=2)
