@@ -145,6 +145,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "online96":
         assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
         return online_native_width()
+    if len(sys.argv) > 1 and sys.argv[1] == "nbnative":
+        assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
+        return nb_models_native_width()
     if len(sys.argv) > 1 and sys.argv[1] == "large16k":
         assert REF.exists(), "the reference tree is needed to (re)generate the fixtures"
         return large_16k()
@@ -298,6 +301,60 @@ def nb_models():
         for k, p in net.named_parameters():
             out[f"{name}/grad/{k}"] = p.grad.numpy()
     np.savez_compressed(HERE / "nb_models_tiny.npz", **out)
+
+
+def nb_models_native_width():
+    """The reference's three narrow-band networks at the SMALLEST widths the native HIP paths take (attention heads 24 wide, conv groups 8 / 16 wide, LSTM
+    hidden size 128), run in fp64: input, parameters, output and the gradient of sum(y * r) w.r.t. every parameter -> nb_models_native.npz.  The native
+    paths (nbss_amd/nbc2.py, nbc.py, blstm.py) are compared with THESE numbers directly (tests/test_nb_native_vs_reference.py), not through the repo's own
+    torch.nn modules.  Not stored: NBC's sinusoid tables (rel_pos.pe: a constructor constant); of the BiLSTM's four big matrices every eighth row of the
+    gradient (the parameters are rounded to fp16 values first and stored as fp16: 1 MB instead of 4)."""
+    import types
+    for m in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[m]
+    sys.path.insert(0, str(REF))
+    tm = types.ModuleType("torchmetrics"); tmf = types.ModuleType("torchmetrics.functional"); tma = types.ModuleType("torchmetrics.functional.audio")
+    tma.permutation_invariant_training = tma.scale_invariant_signal_distortion_ratio = lambda *a, **k: None
+    sys.modules.update({"torchmetrics": tm, "torchmetrics.functional": tmf, "torchmetrics.functional.audio": tma})
+    from models.arch.blstm2_fc1 import BLSTM2_FC1  # noqa: E402  (reference)
+    from models.arch.NBC import NBC  # noqa: E402
+    from models.arch.NBC2 import NBC2  # noqa: E402
+    assert "/root/reference" in sys.modules["models.arch.NBC2"].__file__
+    torch.manual_seed(11)
+    torch.set_num_threads(1)
+    bk = {"n_heads": 2, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 4, "norms": ("LN", "GBN", "GBN"),
+          "group_batch_norm_kwargs": {"share_along_sequence_dim": False}}
+    cases = {
+        "nbc2": (NBC2(dim_input=4, dim_output=4, n_layers=2, dim_hidden=48, dim_ffn=64, num_freqs=5, block_kwargs=bk), torch.randn(2, 5, 11, 4)),
+        "nbc": (NBC(dim_input=4, dim_output=4, n_layers=2, encoder_kernel_size=4, n_heads=2, hidden_size=48, ffn_size=64), torch.randn(2, 3, 13, 4)),
+        "blstm": (BLSTM2_FC1(dim_input=4, dim_output=4, hidden_size=(128, 128)), torch.randn(1, 3, 6, 4)),
+    }
+    out = {}
+    for name, (net, x) in cases.items():
+        net.eval()  # (NBC's blocks carry dropout 0.1: eval mode makes the fixture deterministic; none of the three has mode-dependent statistics)
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.dim() == 1:
+                    p.add_(0.1 * torch.randn_like(p))
+                if name == "blstm":
+                    p.copy_(p.half().float())
+        sd32 = {k: v.clone() for k, v in net.state_dict().items()}
+        net = net.double()
+        y = net(x.double())
+        r = torch.randn(y.shape)
+        (y * r.double()).sum().backward()
+        out[f"{name}/x"], out[f"{name}/y"], out[f"{name}/r"] = x.numpy(), y.detach().float().numpy(), r.numpy()
+        for k, v in sd32.items():
+            if k.endswith("rel_pos.pe"):
+                continue
+            out[f"{name}/param/{k}"] = v.numpy().astype(np.float16) if name == "blstm" else v.numpy()
+        for k, p in net.named_parameters():
+            g = p.grad.float().numpy()
+            if name == "blstm" and g.ndim == 2 and g.shape[0] >= 512:
+                g = g[::8]
+            out[f"{name}/grad/{k}"] = g
+    np.savez_compressed(HERE / "nb_models_native.npz", **out)
+    print("written: nb_models_native.npz", sum(v.nbytes for v in out.values()) // 1024, "KB uncompressed")
 
 
 if __name__ == "__main__":
