@@ -144,7 +144,8 @@ class NativeBLSTM:
             ws = torch.empty(lib._dll.nbss_nb_blstm_ws_bytes(dt, HD), dtype=torch.uint8, device=dev)
             dg = torch.empty(n, T, 8 * HD, dtype=td, device=dev)
             whh0, whh1 = f32(rnn.weight_hh_l0), f32(rnn.weight_hh_l0_reverse)
-            lib.call("nbss_nb_blstm_bwd", dt, n, T, HD, p(dy.contiguous()), p(L["save"]), p(whh0), p(whh1), p(dg), p(ws), st)
+            dyc = dy.contiguous()  # (named: a temporary would be returned to the allocator before the call that reads it is made)
+            lib.call("nbss_nb_blstm_bwd", dt, n, T, HD, p(dyc), p(L["save"]), p(whh0), p(whh1), p(dg), p(ws), st)
             dx, dwih, dbih = dense_bwd(L["x"], I8, 8 * HD, L["wih"], dg, need_dx=need_dx)
             # recurrent weights: dW_hh = sum over (sequence, frame) of dG_t^T h_{t-1}; h_{t-1} = the direction's output one frame earlier in ITS order
             y = L["y"]
