@@ -90,8 +90,8 @@ def gen_diffuse_noise(noise: Tensor, L: int, Cs: Tensor, nfft: int = 256) -> Ten
     return _istft_scipy(X, nfft)[..., :L]
 
 
-def mix_batch(cleans: Tensor, rir: Tensor, Cs: Tensor, sir_db: Optional[Tensor], snr_db: Tensor, gen: torch.Generator, rir_target: Optional[Tensor] = None,
-              nfft: int = 256) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
+def mix_batch(cleans: Tensor, rir: Tensor, Cs: Tensor, sir_db: Optional[Tensor], snr_db: Tensor, gen: Optional[torch.Generator], rir_target: Optional[Tensor] = None,
+              nfft: int = 256, white: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
     """cleans [B,S,N] dry sources, rir [B,S,M,L] -> (mix [B,M,N], targets [B,S,M,N], paras): steps 5-7 of SmsWsjPlusDataset.__getitem__
     (full overlap) for a whole batch on the device of `cleans`"""
     B, S, N = cleans.shape
@@ -102,7 +102,8 @@ def mix_batch(cleans: Tensor, rir: Tensor, Cs: Tensor, sir_db: Optional[Tensor],
         scale = torch.stack([torch.ones_like(coeff), coeff], 1)[:, :, None, None]
         rvbt, tgt = rvbt * scale, tgt * scale
     mix = rvbt.sum(1)
-    white = torch.randn(B, M, N, generator=gen, device=cleans.device, dtype=cleans.dtype)
+    if white is None:
+        white = torch.randn(B, M, N, generator=gen, device=cleans.device, dtype=cleans.dtype)
     noise = gen_diffuse_noise(white, N, Cs.to(cleans.device), nfft)
     noise = noise * energy_ratio_coeff(mix, noise, snr_db)[:, None, None]
     snr_real = 10 * torch.log10(mix.pow(2).sum((1, 2)) / noise.pow(2).sum((1, 2)))

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 
+_TRAIN_OK = weakref.WeakKeyDictionary()  # NBC module -> ((n parameters, n modules), nbss_amd.nbc.train_supported's answer)
 _NATIVE = weakref.WeakKeyDictionary()  # NBC module -> (nbss_amd.nbc.NativeNBC or None, reason it is None)
 _NOTED = weakref.WeakKeyDictionary()   # NBC module -> reasons already reported
 
@@ -161,6 +162,17 @@ class NBC(nn.Module):
             _NATIVE[self] = (runner, why)
         return _NATIVE[self][0]
 
+    def _train_supported(self) -> Optional[str]:
+        """nbss_amd.nbc.train_supported(self), evaluated once per module structure (it walks every block and builds an id-set of all parameters: host
+        work that does not belong in every training step); re-evaluated when the number of parameters or sub-modules changes"""
+        key = (sum(1 for _ in self.parameters()), sum(1 for _ in self.modules()))
+        hit = _TRAIN_OK.get(self)
+        if hit is None or hit[0] != key:
+            from nbss_amd.nbc import train_supported
+            hit = (key, train_supported(self))
+            _TRAIN_OK[self] = hit
+        return hit[1]
+
     def _torch_path_note(self, why: str) -> None:
         """one warning per module and reason: a user on a HIP device can tell which path ran"""
         seen = _NOTED.setdefault(self, set())
@@ -194,8 +206,7 @@ class NBC(nn.Module):
                             return self._native().forward(x.contiguous())
                         why = "training mode under torch.no_grad(): the dropouts are active and there is nothing to differentiate"
                     else:
-                        from nbss_amd.nbc import train_supported
-                        why = train_supported(self)
+                        why = self._train_supported()
                         if why is None and x.requires_grad:
                             why = "the input requires a gradient (the native backward produces parameter gradients only)"
                         if why is None:

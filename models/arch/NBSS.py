@@ -52,7 +52,10 @@ class NBSS(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         B, C, N = x.shape
         io = self._io()
-        native_io = x.is_cuda and io.hip_ok  # HIP device: the DFT-as-GEMM kernels of nbss_amd/csrc/signal.hip (models/io/stft.py); else torch.stft / istft
+        # HIP device: the DFT-as-GEMM kernels of nbss_amd/csrc/signal.hip (models/io/stft.py) — libnbss_hip.so is MANDATORY there, like under SpatialNet:
+        # a missing / unloadable library raises (nbss_amd._lib.hip) instead of silently running torch.stft, so that a GPU run never reports numbers of a
+        # path that is not the product's.  Host tensors and STFT geometries outside the kernels' set (hip_ok) take torch.stft / istft.
+        native_io = x.is_cuda and io.hip_ok
         if native_io:
             X = io.stft(x.reshape(B * C, N))[0]
         else:

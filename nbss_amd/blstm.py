@@ -4,6 +4,8 @@ registers), and in training the reverse walk (nbss_nb_blstm_bwd) followed by den
 The module keeps its nn.LSTM parameters (state_dict keys unchanged); they are read at every call."""
 from typing import Optional
 
+import weakref
+
 import torch
 from torch import Tensor
 
@@ -37,11 +39,12 @@ class _BLSTMTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, x, *params):
         out, saved = runner._run(x, train=True)
-        ctx.runner, ctx.saved = runner, saved
+        ops.graph_guard_save(ctx, runner, saved, params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        ops.graph_guard_check(ctx, "NB-BLSTM native training")
         grads = ctx.runner._backward(ctx.saved, dout.contiguous())
         ctx.saved = None
         return (None, None, *grads)
@@ -52,7 +55,16 @@ class NativeBLSTM:
         why = supported(net)
         if why is not None:
             raise NbssError(f"NB-BLSTM native path: {why}")
-        self.net, self.lib = net, lib
+        # (a weak reference: models/arch/* caches the runner in a WeakKeyDictionary keyed by the module — a strong reference from the value would keep
+        #  every module that ever ran on the device, and its parameters, alive for the life of the process)
+        self._net, self.lib = weakref.ref(net), lib
+
+    @property
+    def net(self):
+        net = self._net()
+        if net is None:
+            raise NbssError("the module this native runner was built for has been freed")
+        return net
 
     def _p(self, t):
         return ops._ptr(self.lib, t)

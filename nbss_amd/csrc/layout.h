@@ -232,10 +232,16 @@ NBSS_HD size_t tc_part_bytes(const nbss_cfg& c) {
 NBSS_HD size_t ws_nops(const nbss_cfg& c) { return c.H == 96 ? 8 : 16; }
 // ... plus room for that path's re-laid weights (the LinearGroup pair at F = 272 is 10 MB in fp32), independent of the token count
 NBSS_HD size_t ws_wprep_bytes(const nbss_cfg& c) { return c.H == 96 ? 0 : (size_t)16 << 20; }
+// per-workgroup partial rows of the small (affine) parameter gradients: 576 floats per sequence / slab, plus the full-band block's fold scratch behind its
+// rows (full.hip: D [SQ][H] | dbs | ones | zeros = 968 floats at an offset of up to nwg * SQ + 64) — on a single-token grid (nwg = 1) that scratch
+// used to run into the wgrad partial tiles, whose writes zeroed four parameter gradients (round 5 review)
+NBSS_HD size_t ws_part_bytes(const nbss_cfg& c) {
+    const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
+    return ws_align((nwg * 576 + 64 + (size_t)c.SQ * c.H + c.SQ + 2 * c.H) * sizeof(float));
+}
 NBSS_HD size_t workspace_bytes(const nbss_cfg& c) {
     const size_t N = (size_t)c.B * c.F * c.T, esz = c.dtype == NBSS_BF16 ? 2 : 4;
-    const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
-    return ws_align(N * 2 * sizeof(float)) + ws_nops(c) * ws_align(N * c.FFN * esz) + ws_wprep_bytes(c) + ws_align(nwg * 576 * sizeof(float)) + ws_align(WGPART_BYTES) +
+    return ws_align(N * 2 * sizeof(float)) + ws_nops(c) * ws_align(N * c.FFN * esz) + ws_wprep_bytes(c) + ws_part_bytes(c) + ws_align(WGPART_BYTES) +
            ws_align(fc_part_bytes(c)) + ws_align(tc_part_bytes(c)) + 256;
 }
 // attention state saved by the forward pass for backward: O [N][H] (stream dtype) | log2-sum-exp [N][heads] fp32 | LayerNorm statistics [N][2] fp32
@@ -256,10 +262,7 @@ NBSS_HD size_t ws_part_offset(const nbss_cfg& c) {
 }
 
 // per-workgroup partial dW tiles of the wgrad kernels live behind those
-NBSS_HD size_t ws_wgpart_offset(const nbss_cfg& c) {
-    const size_t nwg = (size_t)c.B * (c.F > c.T ? c.F : c.T);
-    return ws_part_offset(c) + ws_align(nwg * 576 * sizeof(float));
-}
+NBSS_HD size_t ws_wgpart_offset(const nbss_cfg& c) { return ws_part_offset(c) + ws_part_bytes(c); }
 
 // the fused f-conv weight-gradient partial rows live behind the wgrad partial tiles
 NBSS_HD size_t ws_fcpart_offset(const nbss_cfg& c) { return ws_wgpart_offset(c) + ws_align(WGPART_BYTES); }

@@ -25,6 +25,13 @@
 #define TW_KC 64
 #define TW_H 96
 #define TW_THREADS 512
+#ifndef TW288_NTW
+#define TW288_NTW 2
+#endif
+// timing knock-outs (A/B flavours only, results wrong): bit 0 = no weight-gradient contraction, bit 1 = no tail tiles: what is left is the staging
+#ifndef TW_KO
+#define TW_KO 0
+#endif
 
 struct TailArgs {
     const bf16_t* A;      // [MA/24][Ntok][24]  pre-activation gradient (group-major)
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
             frag_load_tr(fa[0], buf + off_a(0), LDA);
             frag_load_tr(fb[0], buf + off_b(0), LDX);
 #pragma unroll
-            for (int i = 0; i < NSW * 2; ++i) {
+            for (int i = 0; i < ((TW_KO & 1) ? 1 : NSW * 2); ++i) {
                 const int s = i / 2, cur = i & 1;
                 if (i + 1 < NSW * 2) {
                     const int s1 = (i + 1) / 2, kh1 = (i + 1) % 2;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
             lds_barrier();
             if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
 #pragma unroll 1  // (two tiles inlined side by side were scheduled together: twice the live registers)
-            for (int tile = w; tile < TW_KC / 16; tile += NTW) tail_tile(buf, ch, tile);
+            for (int tile = w; tile < ((TW_KO & 2) ? 0 : TW_KC / 16); tile += NTW) tail_tile(buf, ch, tile);
             if (NBUF == 1) lds_barrier();
             else b ^= 1;
         }
@@ -287,7 +294,7 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
 #ifdef NBSS_TW288_NBUF1
             : MA == 288 ? tailw_go<288, 1, 2>(t, grid, st)
 #else
-            : MA == 288 ? tailw_go<288, 2, 2>(t, grid, st)  // both buffers + the 54 W^T fragments: 162 176 of 163 840 bytes
+            : MA == 288 ? tailw_go<288, 2, TW288_NTW>(t, grid, st)  // both buffers + the 54 W^T fragments: 162 176 of 163 840 bytes
 #endif
             : NBSS_EUNSUPPORTED;
     if (e) return e;

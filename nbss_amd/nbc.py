@@ -6,12 +6,14 @@ attention and a convolutional feed-forward with GroupNorm) on the HIP device, se
             -> out_proj + residual;  LayerNorm -> linear1 -> SiLU -> 3 x (grouped conv -> GroupNorm(8) -> SiLU) -> linear2 + residual
   decoder   ConvTranspose1d(k)                                          = a zero-padded tap-GEMM over the frames shifted by one, taps flipped
 
-Inference only: the reference trains NBC with dropout 0.1 inside the attention and the feed-forward (NBC.py:73-104,161-193), which these kernels do
-not draw; `models.arch.NBC.NBC.forward` takes this path for eval-mode / no-grad calls on a HIP tensor when NBSS_NBC_NATIVE=1 (opt-in until its first
-run on the device: round 4 ended before one), `tests/test_nbc_native.py` runs it on the emulator against the torch.nn module."""
+Inference and training: `models.arch.NBC.NBC.forward` takes this path by default for every call on a HIP tensor the kernels support (NBSS_NBC_NATIVE=0
+switches it off).  The reference trains NBC with dropout 0.1 inside the attention and the feed-forward (NBC.py:73-104,161-193): the attention dropout
+goes through keep-bits both passes read (`_keep_bits`), the element-wise dropouts are device tensors.  `tests/test_nbc_native.py` runs both paths on the
+emulator and on the device against the torch.nn module, `tests/test_nb_native_vs_reference.py` against numbers of the reference's own module."""
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -61,7 +63,16 @@ class NativeNBC:
         why = supported(net)
         if why is not None:
             raise NbssError(f"NBC native forward: {why}")
-        self.net, self.lib = net, lib
+        # (a weak reference: models/arch/* caches the runner in a WeakKeyDictionary keyed by the module — a strong reference from the value would keep
+        #  every module that ever ran on the device, and its parameters, alive for the life of the process)
+        self._net, self.lib = weakref.ref(net), lib
+
+    @property
+    def net(self):
+        net = self._net()
+        if net is None:
+            raise NbssError("the module this native runner was built for has been freed")
+        return net
 
     def _p(self, t: Optional[Tensor]):
         return ops._ptr(self.lib, t)
@@ -197,11 +208,12 @@ class _NBCTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, x, *params):
         out, saved = runner._forward_train(x)
-        ctx.runner, ctx.saved = runner, saved
+        ops.graph_guard_save(ctx, runner, saved, params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        ops.graph_guard_check(ctx, "NBC native training")
         grads = ctx.runner._backward_train(ctx.saved, dout.contiguous())
         ctx.saved = None
         return (None, None, *grads)
@@ -211,9 +223,14 @@ def _keep_bits(shape, p: float, dev) -> Tensor:
     """attention-dropout keep-bits for [nseq, heads, T, T] probabilities: int32 words [nseq, heads, T, ceil(T / 32)], bit (j & 31) of word j >> 5 = (i, j) kept"""
     nseq, heads, T, _ = shape
     MW = (T + 31) // 32
-    keep = torch.rand(nseq, heads, T, MW * 32, device=dev) >= p
-    w = (keep.view(nseq, heads, T, MW, 32).to(torch.int64) << torch.arange(32, device=dev, dtype=torch.int64)).sum(-1)
-    return (w - ((w >> 31) << 32)).to(torch.int32).contiguous()
+    out = torch.empty(nseq, heads, T, MW, dtype=torch.int32, device=dev)
+    wt = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=dev)
+    # one head at a time, bytes not int64 words: the transient is one float32 + one byte per probability of a head (the first version drew all heads at
+    # once and packed through two int64 copies: ~10 GB of transients per layer at B 4 x F 257 x 248 frames x 8 heads)
+    for h in range(heads):
+        keep = (torch.rand(nseq, T, MW, 4, 8, device=dev) >= p).to(torch.uint8)
+        out[:, h] = (keep * wt).sum(-1, dtype=torch.uint8).view(torch.int32).squeeze(-1)  # (little-endian: byte k of a word = bits 8k .. 8k + 7)
+    return out
 
 
 def forward_train(self, x: Tensor) -> Tensor:

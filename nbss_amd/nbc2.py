@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import weakref
+
 import torch
 from torch import Tensor
 
@@ -55,7 +57,16 @@ class NativeNBC2:
         why = supported(net)
         if why is not None:
             raise NbssError(f"NBC2 native forward: {why}")
-        self.net, self.lib = net, lib
+        # (a weak reference: models/arch/* caches the runner in a WeakKeyDictionary keyed by the module — a strong reference from the value would keep
+        #  every module that ever ran on the device, and its parameters, alive for the life of the process)
+        self._net, self.lib = weakref.ref(net), lib
+
+    @property
+    def net(self):
+        net = self._net()
+        if net is None:
+            raise NbssError("the module this native runner was built for has been freed")
+        return net
 
     def _p(self, t: Optional[Tensor]):
         return ops._ptr(self.lib, t)  # (checks that the tensor lives where the library computes: HIP device — or host for the test emulator)
@@ -142,11 +153,12 @@ class _NBC2TrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, x, *params):
         out, saved = runner._forward_train(x)
-        ctx.runner, ctx.saved = runner, saved
+        ops.graph_guard_save(ctx, runner, saved, params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        ops.graph_guard_check(ctx, "NBC2 native training")
         grads = ctx.runner._backward_train(ctx.saved, dout.contiguous())
         ctx.saved = None
         return (None, None, *grads)

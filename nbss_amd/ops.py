@@ -271,3 +271,22 @@ def selftest_mma(lib, dtype: int, kperm: int, A: Tensor, B: Tensor) -> Tensor:
     D = torch.empty(16, 16, dtype=torch.float32, device=A.device)
     lib.call("nbss_selftest_mma", dtype, kperm, _ptr(lib, A, torch.float32), _ptr(lib, B, torch.float32), _ptr(lib, D), _stream(lib, A))
     return D
+
+
+def graph_guard_save(ctx, runner, saved, params):
+    """state of a native autograd.Function between forward and backward: the runner, its module (kept alive while the graph is), the saved device
+    tensors and the version counters of the parameters backward will re-read from the live module"""
+    ctx.runner, ctx.net, ctx.saved, ctx.params = runner, runner.net, saved, params
+    ctx.versions = [p._version for p in params]
+
+
+def graph_guard_check(ctx, what: str):
+    """torch.nn raises when a tensor saved for backward was modified in place or the graph was already freed; the native paths re-read the module's
+    parameters in backward, so they check the same two conditions themselves"""
+    if ctx.saved is None:
+        raise RuntimeError(f"{what}: trying to backward through the graph a second time: the native path frees its saved state after the first backward "
+                           "(retain_graph is not supported)")
+    for p, v in zip(ctx.params, ctx.versions):
+        if p._version != v:
+            raise RuntimeError(f"{what}: a parameter needed for the gradient computation was modified in place between forward and backward "
+                               f"(shape {tuple(p.shape)}, version {p._version}, expected {v})")

@@ -21,6 +21,16 @@ REFERENCE = Path("/root/reference")
 os.environ.setdefault("NBSS_POISON_SCRATCH", "1")  # scratch buffers start as NaN bytes in every test (nbss_amd/ops.py: scratch)
 
 
+# the randomised shape tests draw the SAME examples in every run (round-5 review: an un-seeded draw hit a single-token defect in one run of three);
+# the defect classes they found are pinned as explicit @example cases next to each @given, tests/diag/sweep_small_grids.py walks the whole grid
+try:
+    from hypothesis import settings as _hyp_settings
+    _hyp_settings.register_profile("repro", derandomize=True, database=None, deadline=None, print_blob=True)
+    _hyp_settings.load_profile("repro")
+except ImportError:  # hypothesis is test-only
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running emulator case")

@@ -78,3 +78,19 @@ def test_simulation_on_device_feeds_training_step():
     assert x.is_cuda and x.shape == (2, 6, 8000) and torch.isfinite(x).all() and abs(float(x.abs().max()) - 0.9) < 0.2
     host = gs.SimulatedRoomDataModule(batch_size=[2, 2], num_samples=[4, 2, 2], audio_time_len=[1.0, 1.0, 1.0], device="cpu")
     assert host.Cs.shape == dm.Cs.shape
+    # numbers, not only shapes: the SAME sources, RIRs, SIR / SNR draws and sensor noises through the device pipeline (fp32, rocFFT) and through the
+    # host pipeline in fp64 — which the CPU tests above pin to scipy.signal.fftconvolve and the reference's numpy functions (mix.py:122-134,269-303,
+    # diffuse_noise.py:64-93)
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(3, 2, 8000, generator=g, dtype=torch.float64)
+    rir = host._rirs(3, g).double()
+    sir, snr = torch.tensor([-5.0, 0.0, 4.0], dtype=torch.float64), torch.tensor([3.0, 10.0, 20.0], dtype=torch.float64)
+    white = torch.randn(3, 6, 8000, generator=g, dtype=torch.float64)
+    Cs64 = gs.diffuse_mixing_matrices(host.pos_mics, 8000)[1]
+    assert float((dm.Cs.cpu().to(torch.complex128) - Cs64).abs().max()) < 1e-6  # the mixing matrices the device module built
+    want_mix, want_tgt, want_p = gs.mix_batch(src, rir, Cs64, sir, snr, None, white=white)
+    d = lambda t: t.float().to("cuda:0")  # noqa: E731
+    mix, tgt, p = gs.mix_batch(d(src), d(rir), dm.Cs, d(sir), d(snr), None, white=d(white))
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())  # noqa: E731
+    assert mix.is_cuda and rel(mix, want_mix) < 1e-4 and rel(tgt, want_tgt) < 1e-4, (rel(mix, want_mix), rel(tgt, want_tgt))
+    assert torch.allclose(p["snr"].double().cpu(), want_p["snr"], atol=1e-3) and torch.allclose(p["scale"].double().cpu(), want_p["scale"], rtol=1e-4)

@@ -1,7 +1,8 @@
 """The native narrow-band paths (nbss_amd/nbc2.py, nbc.py, blstm.py over the nbss_nb_* building blocks) against numbers produced by the REFERENCE's own
 modules (/root/reference/models/arch/{NBC2,NBC,blstm2_fc1}.py run in fp64 by tests/golden/make_golden.py nbnative -> tests/golden/nb_models_native.npz) at
 the smallest widths the kernels take: output and every parameter gradient of sum(y * r).  The other native tests compare with this repo's torch.nn modules
-(themselves pinned to the reference by tests/test_nb_models.py); this one has no such link in between.  Host emulator build of the kernel sources (CPU)."""
+(themselves pinned to the reference by tests/test_nb_models.py); this one has no such link in between.  Both backends: the host emulator build of the
+kernel sources (-m "not gpu") and libnbss_hip.so on the MI355X (-m gpu) read the same committed fixture."""
 from pathlib import Path
 
 import numpy as np
@@ -48,13 +49,15 @@ def _check(net, y, y_ref, grads, ytol, gtol, floor, every=None):
     assert seen == set(grads) and not bad, bad
 
 
-def test_native_nbc2_equals_the_reference(emu_lib):
+def test_native_nbc2_equals_the_reference(backend):
     from models.arch.NBC2 import NBC2
     from nbss_amd.nbc2 import NativeNBC2, supported
+    emu_lib, dev = backend.lib, backend.device
     x, y_ref, r, params, grads = _case("nbc2")
+    x, r = x.to(dev), r.to(dev)
     bk = {"n_heads": 2, "dropout": 0, "conv_kernel_size": 3, "n_conv_groups": 4, "norms": ("LN", "GBN", "GBN"),
           "group_batch_norm_kwargs": {"share_along_sequence_dim": False}}
-    net = _load(NBC2(dim_input=4, dim_output=4, n_layers=2, dim_hidden=48, dim_ffn=64, num_freqs=5, block_kwargs=bk), params).float().train()
+    net = _load(NBC2(dim_input=4, dim_output=4, n_layers=2, dim_hidden=48, dim_ffn=64, num_freqs=5, block_kwargs=bk), params).float().to(dev).train()
     assert supported(net) is None
     run = NativeNBC2(net, emu_lib)
     assert rel_l2(run.forward(x), y_ref) < 5e-6  # (measured: 2e-7; gradients 5e-7)
@@ -63,15 +66,17 @@ def test_native_nbc2_equals_the_reference(emu_lib):
     _check(net, y.detach(), y_ref, grads, 5e-6, 2e-5, 1e-7)
 
 
-def test_native_nbc_equals_the_reference(emu_lib):
+def test_native_nbc_equals_the_reference(backend):
     from models.arch.NBC import NBC
     from nbss_amd.nbc import NativeNBC, train_supported
+    emu_lib, dev = backend.lib, backend.device
     x, y_ref, r, params, grads = _case("nbc")
+    x, r = x.to(dev), r.to(dev)
     net = _load(NBC(dim_input=4, dim_output=4, n_layers=2, encoder_kernel_size=4, n_heads=2, hidden_size=48, ffn_size=64), params, skip=("rel_pos.pe",)).float()
     for m in net.modules():  # (the fixture is the reference in eval mode: its dropouts are inactive)
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    net.train()
+    net.to(dev).train()
     assert train_supported(net) is None
     run = NativeNBC(net, emu_lib)
     assert rel_l2(run.forward(x), y_ref) < 5e-6  # (measured: 4e-7; gradients 1.4e-6)
@@ -80,11 +85,13 @@ def test_native_nbc_equals_the_reference(emu_lib):
     _check(net, y.detach(), y_ref, grads, 5e-6, 2e-5, 1e-7)  # (floor: the key bias is gradient-free under the softmax)
 
 
-def test_native_blstm_equals_the_reference(emu_lib):
+def test_native_blstm_equals_the_reference(backend):
     from models.arch.blstm2_fc1 import BLSTM2_FC1
     from nbss_amd.blstm import NativeBLSTM, supported
+    emu_lib, dev = backend.lib, backend.device
     x, y_ref, r, params, grads = _case("blstm")
-    net = _load(BLSTM2_FC1(dim_input=4, dim_output=4, hidden_size=(128, 128)), params).float()
+    x, r = x.to(dev), r.to(dev)
+    net = _load(BLSTM2_FC1(dim_input=4, dim_output=4, hidden_size=(128, 128)), params).float().to(dev)
     assert supported(net) is None
     run = NativeBLSTM(net, emu_lib)
     assert rel_l2(run.forward(x), y_ref) < 5e-6  # (measured: 4e-7; gradients 4e-7)
