@@ -26,9 +26,12 @@
 #define TW_H 96
 #define TW_THREADS 512
 #ifndef TW288_NTW
-#define TW288_NTW 2
+#define TW288_NTW 4
 #endif
 // timing knock-outs (A/B flavours only, results wrong): bit 0 = no weight-gradient contraction, bit 1 = no tail tiles: what is left is the staging
+#ifndef TW_TAIL_UNROLL
+#define TW_TAIL_UNROLL 2
+#endif
 #ifndef TW_KO
 #define TW_KO 0
 #endif
@@ -180,18 +183,31 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
         }
     } else {
         // ================= tail waves: 16 tokens of the chunk each =================
-        auto tail_tile = [&](const bf16_t* buf, int ch, int tile) {
+        // The x / dy rows of a tile are requested ONE CHUNK AHEAD (round 6): as loads at the head of the tile's own math they were an exposed HBM round
+        // trip per chunk for dy (36 - 54 MFMAs do not cover it) — with the tail tiles knocked out the kernel ran 424 -> 200 us (in_proj) and 283 ->
+        // 153 us (W1), with the contraction waves knocked out 424 -> 408: the tail waves were the critical path of every chunk.
+        constexpr int TPW = TW_KC / 16 / NTW;  // tiles of a chunk per tail wave
+        auto tail_rows = [&](int ch, int tile, bool& tv, size_t& nrow) {
             const long nt0 = (long)ch * TW_KC + 16 * tile + l15;
-            const bool tv = nt0 < a.Ntok;
-            const size_t nrow = (size_t)(tv ? nt0 : a.Ntok - 1);  // clamped address, validity applied on use
-            RawC4<bf16_t> xr[BK_MT], dr[BK_MT];
-            rawc_load_row<bf16_t>(xr, a.x + nrow * TW_H);   // (L2: the staging has just fetched these rows)
+            tv = nt0 < a.Ntok;
+            nrow = (size_t)(tv ? nt0 : a.Ntok - 1);  // clamped address, validity applied on use
+        };
+        auto tail_load = [&](int ch, int tile, RawC4<bf16_t> (&xr)[BK_MT], RawC4<bf16_t> (&dr)[BK_MT]) {
+            bool tv;
+            size_t nrow;
+            tail_rows(ch, tile, tv, nrow);
+            rawc_load_row<bf16_t>(xr, a.x + nrow * TW_H);
             rawc_load_row<bf16_t>(dr, a.dy + nrow * TW_H);
+        };
+        auto tail_tile = [&](const bf16_t* buf, int ch, int tile, const RawC4<bf16_t> (&xr)[BK_MT], const RawC4<bf16_t> (&dr)[BK_MT]) {
+            bool tv;
+            size_t nrow;
+            tail_rows(ch, tile, tv, nrow);
             f32x4 du[BK_MT];
 #pragma unroll
             for (int mt = 0; mt < BK_MT; ++mt) du[mt] = F32X4_ZERO;
             const bf16_t* arow = buf + (size_t)(16 * tile + l15) * LDA + 8 * g4;  // B operand: the token's da row, natural K order
-#pragma unroll(KSW > 6 ? 1 : KSW)  // (9 k-steps unrolled: the scheduler hoists all 54 W^T fragment reads, 216 registers)
+#pragma unroll(KSW > 6 ? 1 : TW_TAIL_UNROLL)  // (9 k-steps unrolled: the scheduler hoists all 54 W^T fragment reads, 216 registers)
             for (int ks = 0; ks < KSW; ++ks) {
                 Frag<bf16_t> df;
                 frag_load(df, arow + 32 * ks);
@@ -204,13 +220,28 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
             }
             ln_bwd_row96_raw_na<bf16_t>(du, xr, dr, a.dx + nrow * TW_H, tv, lnp);
         };
+        RawC4<bf16_t> xn[TPW][BK_MT], dn[TPW][BK_MT];
+        if (ch < nchunks) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) tail_load(ch, w + i * NTW, xn[i], dn[i]);
+        }
         for (; ch < nchunks; ch += gridDim.x) {
             bf16_t* buf = base + (size_t)b * IMG;
             stash(buf);
             lds_barrier();
-            if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
-#pragma unroll 1  // (two tiles inlined side by side were scheduled together: twice the live registers)
-            for (int tile = w; tile < ((TW_KO & 2) ? 0 : TW_KC / 16); tile += NTW) tail_tile(buf, ch, tile);
+            const int nxt = ch + (int)gridDim.x;
+            if (nxt < nchunks) prefetch(nxt);
+            RawC4<bf16_t> xc[TPW][BK_MT], dc[TPW][BK_MT];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int mt = 0; mt < BK_MT; ++mt) { xc[i][mt] = xn[i][mt]; dc[i][mt] = dn[i][mt]; }
+            if (nxt < nchunks) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) tail_load(nxt, w + i * NTW, xn[i], dn[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < ((TW_KO & 2) ? 0 : TPW); ++i) tail_tile(buf, ch, w + i * NTW, xc[i], dc[i]);
             if (NBUF == 1) lds_barrier();
             else b ^= 1;
         }

@@ -11,7 +11,7 @@ for FL in ${1:-prod}; do
   for K in $2; do
     D=/tmp/kab_${FL}_${K}
     rm -rf $D
-    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $D -- python $GRAFT_REPO_ROOT/tools/run_one.py $K $B 4 > /dev/null 2>&1 )
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $D -- python $GRAFT_REPO_ROOT/tools/run_one.py $K $B ${KAB_ITERS:-8} > /dev/null 2>&1 )
     python - "$D" "$FL" "$K" "$MIN" <<'PY'
 import glob, sqlite3, sys
 root, fl, k, mn = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
