@@ -166,31 +166,118 @@ def _cpu_train_step_fn(B, use_reference):
 
 
 def cpu_baseline(seconds_budget=20.0):
-    """the reference's CPU training step timed on THIS host: batch 2, fp32, all cores, and at the reference's own
-    thread setting (models/utils/base_cli.py:7 pins OMP/MKL to 2 threads).  A reported baseline only; bounded sample."""
+    """the reference's CPU training step timed on THIS host: fp32, batch 2.  The thread count is the best of a short sweep over
+    {2 (the reference's own setting, models/utils/base_cli.py:7), 8, 32, all}: on a 128-thread host the all-threads run was SLOWER than two threads
+    (0.112 vs 0.311 utt/s, round 5: oversubscription of a step made of small ops).  A reported baseline only; bounded sample."""
     use_ref = Path("/root/reference/models/arch/SpatialNet.py").exists()
     threads = torch.get_num_threads()
+    sweep = {}
+    step1 = _cpu_train_step_fn(1, use_ref)
+    for n in sorted({2, 8, 32, threads}):
+        if n > threads:
+            continue
+        torch.set_num_threads(n)
+        step1()  # warm-up at this thread count
+        t1 = time.perf_counter()
+        step1()
+        sweep[n] = 1.0 / (time.perf_counter() - t1)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     B = 2
     step = _cpu_train_step_fn(B, use_ref)
     step()  # warm-up
     t0 = time.perf_counter()
     n = 0
-    while n < 1 or (time.perf_counter() - t0 < seconds_budget and n < 4):
+    while n < 1 or (time.perf_counter() - t0 < seconds_budget and n < 3):
         step()
         n += 1
     dt = time.perf_counter() - t0
-    torch.set_num_threads(2)
-    step1 = _cpu_train_step_fn(1, use_ref)
-    t1 = time.perf_counter()
-    step1()
-    dt2 = time.perf_counter() - t1
     torch.set_num_threads(threads)
     what = "the reference's own SpatialNet / STFT / Norm modules (/root/reference) + restated uPIT loss" if use_ref else \
            "the oracle (CPU restatement of the reference's training step; /root/reference is not on this box)"
-    return {"value": B * n / dt, "unit": "utterances/s", "cores": threads, "kind": "reference" if use_ref else "port",
-            "value_2_threads": 1.0 / dt2,
-            "sample": f"{n} fp32 training steps (STFT..clip+Adam) of {what} at batch {B}, 4-s 6-ch utterances, torch CPU {threads} threads "
-                      f"(os.cpu_count() = {os.cpu_count()}); value_2_threads: one step at batch 1 with 2 threads (base_cli.py:7 setting)"}
+    return {"value": B * n / dt, "unit": "utterances/s", "cores": best, "kind": "reference" if use_ref else "port",
+            "value_2_threads": sweep.get(2), "utt_per_s_by_threads": {str(k): round(v, 4) for k, v in sweep.items()},
+            "sample": f"{n} fp32 training steps (STFT..clip+Adam) of {what} at batch {B}, 4-s 6-ch utterances, torch CPU {best} threads = the best of a "
+                      f"one-step sweep at batch 1 over {sorted(sweep)} threads (os.cpu_count() = {os.cpu_count()}); value_2_threads: base_cli.py:7's setting"}
+
+
+def nb_arch_rates(dev, batch=4, steps=3):
+    """the three narrow-band archs behind NBSS.forward, native training step (forward + backward of every parameter, fp32
+    stream) at batch x 129 x 251, with a FLOP statement: forward FLOPs counted from the torch.nn modules' own shapes (every Linear / Conv1d /
+    ConvTranspose1d / LSTM call of one torch.nn forward, plus the attention contractions 4 T H per token and layer — 6 T H with NBC's relative-position
+    term), training = 3 x forward, against the exact-f32 MFMA peak these paths compute on (157.3 TFLOP/s)."""
+    import warnings
+    import torch.nn as nn
+    out = {}
+    F_, T_ = 129, 251
+
+    def fwd_flops(net, x, attn_layers, attn_h, attn_mult):
+        tot = [0.0]
+
+        def hook(m, inp, res):
+            if isinstance(m, nn.Linear):
+                tot[0] += 2.0 * res.numel() * m.in_features
+            elif isinstance(m, (nn.Conv1d, nn.ConvTranspose1d)):
+                tot[0] += 2.0 * res.numel() * m.kernel_size[0] * (m.in_channels // m.groups)
+            elif isinstance(m, nn.LSTM):
+                y = res[0]
+                nd = 2 if m.bidirectional else 1
+                isz = m.input_size
+                for _ in range(m.num_layers):
+                    tot[0] += 2.0 * (y.numel() / (nd * m.hidden_size)) * nd * 4 * m.hidden_size * (isz + m.hidden_size)
+                    isz = nd * m.hidden_size
+        hs = [m.register_forward_hook(hook) for m in net.modules() if isinstance(m, (nn.Linear, nn.Conv1d, nn.ConvTranspose1d, nn.LSTM))]
+        with torch.no_grad():
+            net(x)
+        for h in hs:
+            h.remove()
+        return tot[0] + attn_layers * attn_mult * T_ * attn_h * (x.shape[0] * F_ * T_)
+
+    def one(name, make, env, attn):
+        try:
+            torch.manual_seed(0)
+            net, cin = make()
+            net = net.to(dev).train()
+            x = torch.randn(batch, F_, T_, cin, device=dev)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                os.environ[env] = "0"
+                net.eval()
+                fl = fwd_flops(net, x, *attn)
+                net.train()
+                os.environ[env] = "1"
+
+                def step():
+                    net.zero_grad(set_to_none=True)
+                    net(x).square().mean().backward()
+                step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+            os.environ.pop(env, None)
+            out[name] = {"train_ms": round(dt * 1e3, 2), "batch": batch, "fwd_gflop": round(fl / 1e9, 1), "train_tflops": round(3 * fl / dt / 1e12, 2),
+                         "frac_of_f32_mfma_peak": round(3 * fl / dt / 157.3e12, 4)}
+        except Exception as e:  # reported, never fatal for the headline line
+            out[name] = {"error": str(e)[:200]}
+
+    def nbc2():
+        from models.arch.NBC2 import NBC2
+        return NBC2(dim_input=16, dim_output=6, n_layers=8, dim_hidden=96, dim_ffn=192, num_freqs=F_), 16
+
+    def nbc():
+        from models.arch.NBC import NBC
+        return NBC(dim_input=16, dim_output=4, n_layers=4, encoder_kernel_size=4, n_heads=8, hidden_size=192, ffn_size=384), 16
+
+    def blstm():
+        from models.arch.blstm2_fc1 import BLSTM2_FC1
+        return BLSTM2_FC1(dim_input=12, dim_output=4, hidden_size=(256, 128)), 12
+    one("NBC2", nbc2, "NBSS_NBC2_NATIVE", (8, 96, 4))
+    one("NBC", nbc, "NBSS_NBC_NATIVE", (4, 192, 6))
+    one("NB-BLSTM", blstm, "NBSS_BLSTM_NATIVE", (0, 0, 0))
+    return out
 
 
 def self_launch(args):
@@ -409,6 +496,7 @@ def main():
         base = None
         sweep = None
         large = None
+        nb = None
         if world == 1 and not args.no_cpu_baseline and roof is not None:
             # the same kernels with the walks IN ORDER (NBSS_SIDE_STREAM=0 is read once per process: a short child run): the live figures above
             # include whatever the gradient stream's launches cost the dominant kernel while they overlap it
@@ -421,6 +509,7 @@ def main():
                 roof["frac_in_order"] = io["frac"]
                 roof["avg_launch_us_in_order"] = io["avg_launch_us"]
                 roof["utt_per_s_in_order"] = round(child["value"], 1)
+                roof["kernel_ms_per_step_in_order"] = child["kernel_ms_per_step"]
             except Exception as e:  # reported, never fatal
                 roof["frac_in_order"] = None
                 roof["in_order_error"] = str(e)[:200]
@@ -444,6 +533,7 @@ def main():
             if large and "value" in large:  # ... and at twice the batch (one more ~0.3 s of steps)
                 l8 = large_train_rate(lib, dev, batch=8, steps=2)
                 large["batch8"] = {k: l8.get(k) for k in ("value", "ms_per_step", "error") if k in l8}
+            nb = nb_arch_rates(dev)
             base = cpu_baseline()
         line = {
             "metric": "utterances/sec (4 s, 6ch, 129 freqs) SpatialNet bf16 train at 1/2/4/8 MI355X",
@@ -453,7 +543,7 @@ def main():
             "config": {"workload": "SpatialNet-small 6ch->2spk, 4-s 8-kHz utterances (32000 samples), n_fft 256/hop 128 (F=129, T=251), 8 layers, "
                                    f"full train step (STFT..Adam), bf16 stream + fp32 master/stats, {B} utterances per GPU per step", "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "final_loss": final_loss},
-            "roofline": roof, "cpu_baseline": base, "utt_per_s_by_batch": sweep, "utt_per_s_large": large,
+            "roofline": roof, "cpu_baseline": base, "utt_per_s_by_batch": sweep, "utt_per_s_large": large, "nb_archs": nb,
             "rccl_world": worlds, "comm_ms_per_step": comm_ms,
             "kernel_ms_per_step": {k: round(v[0] / max(nprof, 1), 4) for k, v in prof.items() if v[1] > 0},
         }

@@ -13,6 +13,7 @@ from torch import Tensor
 from torch.nn import MultiheadAttention
 
 
+import os
 import warnings
 import weakref
 
@@ -172,6 +173,8 @@ class NBC2(nn.Module):
         if not x.is_cuda:
             return None, None
         B, F, T, _ = x.shape
+        if os.environ.get("NBSS_NBC2_NATIVE", "1") == "0":  # (the same switch NBC and NB-BLSTM have: A/B runs, FLOP counting on the torch.nn modules)
+            return None, "NBSS_NBC2_NATIVE=0"
         if x.dtype not in (torch.float32, torch.bfloat16):
             return None, f"input dtype {x.dtype}"
         nat = self._native()  # first: supported() also guards the attribute reads below (other norm types have no group_size)

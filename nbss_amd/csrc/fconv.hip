@@ -25,6 +25,7 @@
 #define FC_KS 2    // 15 pieces of 4 channels -> 2 k-steps of 8 pieces
 #define FC_MTF_MAX 10
 #define FC_MTF_BIG 17  // F <= 272
+#define FC_P16 (5 * FC_H * FC_CG)  // bf16 values per partial row of the fused conv weight gradient: [tap][group][input channel][12 outputs]
 
 template <class T> struct VecOf;
 template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
@@ -533,7 +534,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
     lds_barrier();
     PHASE(3);
 
-    constexpr int PROW = 3 * FC_H + FC_H * FC_CG * 5 + FC_H;  // floats per partial row (layout.h NBSS_FC_PROW)
+    constexpr int PROW = 4 * FC_H;  // floats per fp32 partial row: the three affine sums + the conv bias sums (layout.h NBSS_FC_PROW); the bf16 rows follow all of them
     if constexpr (WGF) {
         // ---- weight gradient of group w: dW[o][i][tap] = sum_{f,tt} dv[f][o] LN(x)[f + tap - 2][i], db[o] = sum dv[f][o] ----
         if (gwave) {
@@ -561,15 +562,26 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
                         wacc[tap] = mma(fa, fb, wacc[tap]);
                     }
                 }
-            // C tile: lane = input channel i (l15), rows = output channels 4 g4 + r; valid 12 x 12
-            float* prow = part + (size_t)blockIdx.x * PROW + 3 * FC_H;
+            // C tile: lane = input channel i (l15), rows = output channels 4 g4 + r; valid 12 x 12.  The workgroup's partial of the weight gradient leaves in
+            // bf16 as [tap][group][i][12 outputs] — a lane's four output channels are ONE 8-byte store and a wave's store instruction covers one contiguous
+            // 288-byte run (round 6; rounds 2-5: fp32 in dW's own [o][i][tap] order = twenty scattered 4-byte stores per lane, 68 of the launch's 335 us
+            // with the stores knocked out).  Only the per-slab partial is rounded (under the reference's autocast the weight gradient of a bf16 convolution
+            // IS a bf16 tensor); the sum over the B T slabs is fp32 (fconv_part_final_kernel).  The bias sums stay fp32, in the row's head.
+            bf16_t* prow16 = reinterpret_cast<bf16_t*>(part + (size_t)gridDim.x * PROW) + (size_t)blockIdx.x * FC_P16;
+            float* pb = part + (size_t)blockIdx.x * PROW + 3 * FC_H;
+#ifdef NBSS_FC_KO_PROW  // (timing knock-out, A/B flavour: no partial-row stores)
+            if (false) {
+#else
             if (l15 < FC_CG && g4 < 3) {
+#endif
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = w * FC_CG + 4 * g4 + r;
+                for (int tap = 0; tap < 5; ++tap) {
+                    const u32x2 v = {pack2bf(wacc[tap][0], wacc[tap][1]), pack2bf(wacc[tap][2], wacc[tap][3])};
+                    *reinterpret_cast<u32x2*>(prow16 + ((size_t)(tap * FC_G + w) * FC_CG + l15) * FC_CG + 4 * g4) = v;
+                }
+                if (l15 == 0) {
 #pragma unroll
-                    for (int tap = 0; tap < 5; ++tap) prow[((size_t)o * FC_CG + l15) * 5 + tap] = wacc[tap][r];
-                    if (l15 == 0) prow[FC_H * FC_CG * 5 + o] = bsum[r];
+                    for (int r = 0; r < 4; ++r) pb[w * FC_CG + 4 * g4 + r] = bsum[r];
                 }
             }
         }
@@ -730,6 +742,17 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
 #define FC_BWD_TT 1
 #endif
 
+// tconvffn_s.hip: fp32 slice sums of bf16 partial rows [nrows][p16] (fixed order; *nsl = slices written)
+int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl, hipStream_t st);
+// dW[o][i][tap] += the slices' sums of the [tap][group][i][12 outputs] rows, in slice order (one owner per element: bitwise repeatable)
+__global__ __launch_bounds__(256) void fconv_part_final_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ dW) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= FC_P16) return;
+    const float sum = fold_strided<16>(slices + e, (size_t)FC_P16, 0, nsl);
+    const int ol = e % FC_CG, i = (e / FC_CG) % FC_CG, g = (e / (FC_CG * FC_CG)) % FC_G, tap = e / (FC_CG * FC_CG * FC_G);
+    dW[((size_t)(g * FC_CG + ol) * FC_CG + i) * 5 + tap] += sum;
+}
+
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
                    void* ws, hipStream_t st, const Side* sd) {
     if (c.H != FC_H) return gb_fconv_bwd(c, P, G, layer, which, x, dy, dx, ws, st, sd);
@@ -762,15 +785,20 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     if (e) return e;
     const int nwg = c.dtype == NBSS_BF16 && !big ? c.B * cdiv(c.T, FC_BWD_TT) : c.B * c.T;
     AffSegs sg;
-    sg.n = fused ? 5 : 3;
     sg.off[0] = param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); sg.cnt[0] = FC_H;
     sg.off[1] = param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B); sg.cnt[1] = FC_H;
     sg.off[2] = param_off(c, layer, which ? P_FC2_PRELU : P_FC1_PRELU); sg.cnt[2] = FC_H;
-    sg.off[3] = param_off(c, layer, which ? P_FC2_W : P_FC1_W); sg.cnt[3] = FC_H * FC_CG * 5;  // partial rows carry dW / db in their own order
-    sg.off[4] = param_off(c, layer, which ? P_FC2_B : P_FC1_B); sg.cnt[4] = FC_H;
+    sg.n = fused ? 4 : 3;
+    sg.off[3] = param_off(c, layer, which ? P_FC2_B : P_FC1_B); sg.cnt[3] = FC_H;  // (fused: the fp32 rows carry the conv bias sums behind the affine sums)
     const hipStream_t gs = side_fork(sd, st);  // the folds and the weight-gradient problem only produce parameter gradients (side.h)
     if ((e = affine_reduce_launch(part, nwg, sg, G, gs))) return e;
-    if (fused) return NBSS_OK;
+    if (fused) {  // the bf16 rows of the conv weight gradient: slice sums in fp32 (the idle wgrad partial region is the scratch), then one owner per element
+        float* slices = (float*)((char*)ws + ws_wgpart_offset(c));
+        int nsl = 0;
+        if ((e = part16_slices_launch(part + (size_t)nwg * 4 * FC_H, nwg, slices, FC_P16, &nsl, gs))) return e;
+        NBSS_LAUNCH(fconv_part_final_kernel, dim3((FC_P16 + 255) / 256), dim3(256), 0, gs, (const float*)slices, nsl, G + param_off(c, layer, which ? P_FC2_W : P_FC1_W));
+        return NBSS_CHECK_LAUNCH();
+    }
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
     WgradArgs a;
     a.part = (float*)((char*)ws + ws_wgpart_offset(c));

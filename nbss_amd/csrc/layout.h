@@ -211,13 +211,15 @@ NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 // frequencies: the cross-band kernels keep the whole F axis of a slab on chip: 17 tiles of 16 (n_fft 512 -> F = 257; fp32 backward: F <= 160)
 #define NBSS_F_MAX 272
 #define NBSS_T_MAX 4096
-// fconv_bwd with the fused weight gradient (bf16, one frame per workgroup since round 5): one partial row per workgroup = the affine sums (3 H) + the
-// whole conv weight gradient [H][H / groups][ks] + its bias [H] as this workgroup's two frames see it; affine_reduce folds the rows
-#define NBSS_FC_PROW(c) (3 * (c).H + (c).H * ((c).H / (c).f_groups) * (c).f_ks + (c).H)
+// fconv_bwd with the fused weight gradient (bf16, one frame per workgroup since round 5): per workgroup one fp32 row = the affine sums (3 H) + the conv
+// bias sums (H) — affine_reduce folds those — and, behind ALL fp32 rows, one bf16 row = the whole conv weight gradient as this workgroup's frame sees it,
+// [tap][group][input channel][outputs of the group] (round 6: 13 KB per workgroup instead of 24.6 KB of fp32; fconv.hip: fconv_part_final_kernel)
+#define NBSS_FC_PROW(c) (4 * (c).H)
+#define NBSS_FC_P16(c) ((c).H * ((c).H / (c).f_groups) * (c).f_ks)
 #ifdef NBSS_FC_TT2  // (A/B flavour: round 4's two-frame slabs)
-NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * ((c.T + 1) / 2) * NBSS_FC_PROW(c) * sizeof(float); }
+NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * ((c.T + 1) / 2) * (NBSS_FC_PROW(c) * sizeof(float) + NBSS_FC_P16(c) * 2); }
 #else
-NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.T * NBSS_FC_PROW(c) * sizeof(float); }
+NBSS_HD size_t fc_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.T * (NBSS_FC_PROW(c) * sizeof(float) + NBSS_FC_P16(c) * 2); }
 #endif
 // T-ConvFFN backward from saved pre-activations (tconvffn_s.hip: tconvffn_bwd_v_kernel; bf16 stream, small geometry): per sequence one fp32
 // partial row (GroupNorm affine sums 2 FFN + the three conv bias sums 3 FFN + W2's bias sums H) and one bf16 row (the three conv weight

@@ -2159,6 +2159,13 @@ PHASE_READER(nbss_phase_read_tconvffn_bwd_v)
 size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV_PSTRIDE * sizeof(float) + TV_P16 * sizeof(bf16_t)); }
 // fold of the bf16 weight-gradient partial rows into G (fp32); offs = flat-gradient offsets of the three conv weights and of W2; `slices`: TV_RSL x TV_P16 floats of scratch
 // with_w2: the rows carry the dW2 block behind the three conv blocks (tconvffn_bwd_v_kernel) or not (tconvffn_bwd_q_kernel)
+// first stage alone, for other kernels' bf16 partial rows (fconv.hip)
+int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl_out, hipStream_t st) {
+    const int nsl = nrows < TV_RSL ? nrows : TV_RSL;
+    *nsl_out = nsl;
+    NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
+    return NBSS_CHECK_LAUNCH();
+}
 int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, bool with_w2, hipStream_t st) {
     const int nrows = c.B * c.F, nsl = nrows < TV_RSL ? nrows : TV_RSL, p16 = with_w2 ? TV_P16 : TQ_P16;
     NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
