@@ -308,7 +308,7 @@ NBSS_DEV void store4_nt(bf16_t* p, float a, float b, float c, float d) {
 #endif
 }
 NBSS_DEV void store16_nt(bf16_t* p, const u32x4& v) {  // one 16-byte streaming store
-#ifdef NBSS_EMU
+#if defined(NBSS_EMU) || defined(NBSS_NO_NT)  // (NBSS_NO_NT: A/B flavour, plain stores)
     *reinterpret_cast<u32x4*>(p) = v;
 #else
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));

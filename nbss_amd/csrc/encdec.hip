@@ -163,7 +163,10 @@ int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pa
                      hipStream_t st) {
     if (c.H != ENC_H) return gb_decoder_bwd(c, P, G, x, dout, dx, ws, st);
     const size_t N = (size_t)c.B * c.F * c.T;
-    const int CP = (c.C_out + 3) & ~3;
+    // the stream-dtype copy of dout for the weight gradient: rows padded to 8 channels in bf16 (zeros; mvalid keeps them out of dW) so that the problem
+    // takes wgrad.hip's transposing-read kernel (16-byte row pieces) — with 4-channel rows it fell to the generic kernel: 215 us per step at batch 32
+    // for a 4 x 96 weight (round 6)
+    const int CP = c.dtype == NBSS_BF16 ? (c.C_out + 7) & ~7 : (c.C_out + 3) & ~3;
     const int nstrips = c.B * c.F * cdiv(c.T, 16);
     dim3 grid(cdiv(nstrips, 4) < 2048 ? cdiv(nstrips, 4) : 2048), block(256);
     prof_begin(PK_DEC_B, st);
@@ -186,10 +189,34 @@ int decoder_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pa
 
 // encoder: the network input needs no gradient; only dW[o][i][tap] = sum_n dy[n][o] xin[n+tap-2][i] and db
 // ws: the backward workspace when the caller has one (nbss_spatialnet_bwd*): partial tiles + reduce instead of the atomicAdd flush
+// bf16 rows of C_in channels -> rows of CP (zero padding): 16-byte pieces for the transposing-read weight-gradient kernel
+__global__ __launch_bounds__(256) void pad_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, size_t n, int C, int CP) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * (size_t)CP; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / CP;
+        const int k = (int)(i - r * CP);
+        dst[i] = k < C ? src[r * C + k] : (bf16_t)0;
+    }
+}
+
 int encoder_bwd_impl(const nbss_cfg& c, float* G, const void* xin, const void* dy, void* ws, hipStream_t st) {
     WgradArgs a;
     if (ws) a.part = (float*)((char*)ws + ws_wgpart_offset(c));
     a.mvalid = 0; a.nvalid = 0;
+    if (ws && c.dtype == NBSS_BF16 && c.H == ENC_H && c.C_in % 8 != 0) {
+        // the network input has 2 C = 12 channels (24-byte rows): a zero-padded copy with 16 (the operand region of the workspace is idle here) takes the
+        // weight gradient to the transposing-read kernel, nvalid keeps the padding out of dW (round 6: 215 -> ~70 us per step at batch 32)
+        const size_t N = (size_t)c.B * c.F * c.T;
+        const int CP = (c.C_in + 7) & ~7;
+        bf16_t* xp = (bf16_t*)((char*)ws + ws_align(N * 2 * sizeof(float)));
+        NBSS_LAUNCH(pad_rows_kernel, dim3(2048), dim3(256), 0, st, (const bf16_t*)xin, xp, N, c.C_in, CP);
+        int e = NBSS_CHECK_LAUNCH();
+        if (e) return e;
+        a.Ntok = (int)N; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = c.enc_ks;
+        a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
+        a.A = dy; a.lda = c.H; a.MA = c.H; a.B = xp; a.ldb = CP; a.NB = CP; a.nvalid = c.C_in;
+        a.dW = G + param_off_enc_w(c); a.dbias = G + param_off_enc_b(c);
+        return wgrad_launch(a, c.dtype, st);
+    }
     a.Ntok = c.B * c.F * c.T; a.F = c.F; a.T = c.T; a.shift_stride = 1; a.shift_dim = 0; a.groups = 1; a.taps = c.enc_ks;
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     a.A = dy; a.lda = c.H; a.MA = c.H; a.B = xin; a.ldb = c.C_in; a.NB = c.C_in;

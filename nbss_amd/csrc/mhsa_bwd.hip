@@ -624,6 +624,9 @@ PHASE_READER(nbss_phase_read_mhsa_bwd)
 // The four heads of a sequence are four workgroups on the same XCD (x / dy rows come from its L2); the saved attention output, the
 // log2-sum-exp rows and this head's 24 weight fragments (staged in the LDS region that becomes the dS image) are read per head.
 // Padding frames (T not a multiple of 16): K rows are zero and lse = 1e30, so they contribute nothing anywhere.
+#ifndef MHB_KO
+#define MHB_KO 0   // timing knock-outs (A/B flavours, results wrong): 1 = no dqkv stores, 2 = every wave reads the sequence's first x / dy strip
+#endif
 #define MH_QC 64   // queries per dS chunk
 #define MH_RS 68   // dS image row stride (elements): rows 34 dwords apart — the 16 key rows of a b64 store hit 16 distinct bank pairs
 #define MH_TP 256
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(512, 4) void mhsa_bwd_h_kernel(nbss_cfg c, LayerPtr
                 xc[si][i] = *reinterpret_cast<const u32x4*>(xb + (tr * MB_H + cc * 8));
                 dc[si][i] = *reinterpret_cast<const u32x4*>(dyb + (tr * MB_H + cc * 8));
 #else  // fragments straight from global memory (lane = token l15, piece g4)
-                const int tc = tv[si] ? tt[si] : tlast;
+                const int tc = (MHB_KO & 2) ? l15 : tv[si] ? tt[si] : tlast;
                 frag_load(uf[si][i], xb + (tc * MB_H + i * 32 + 8 * g4));
                 frag_load(dr[si][i], dyb + (tc * MB_H + i * 32 + 8 * g4));
 #endif
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(512, 4) void mhsa_bwd_h_kernel(nbss_cfg c, LayerPtr
         PHASE(6);
         {   // the chunk's dQ rows are one 3 KB run of the group-major operand: 24 16-byte pieces per wave
             const int pc = w * 24 + lane, tq = ch * MH_QC + pc / 3;
-            if (lane < 24 && tq < T_) {
+            if (lane < 24 && tq < T_ && !(MHB_KO & 1 && nseq > 0)) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(dqs + pc * 8);
                 store16_nt(dq_seq + (dqkv_off(head, ch * MH_QC) + pc * 8), v);
             }
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(512, 4) void mhsa_bwd_h_kernel(nbss_cfg c, LayerPtr
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // 96 pieces per tensor: row pc / 3
             const int pc = i * 64 + lane, t = w * 32 + pc / 3;
-            if (pc < 96 && t < T_) {  // (padding keys only ever produced their own, discarded, rows)
+            if (pc < 96 && t < T_ && !(MHB_KO & 1 && nseq > 0)) {  // (padding keys only ever produced their own, discarded, rows)
                 const u32x4 vk = *reinterpret_cast<const u32x4*>(sK + pc * 8), vv = *reinterpret_cast<const u32x4*>(sV + pc * 8);
                 store16_nt(dq_seq + (dqkv_off(1 * MB_HEADS + head, w * 32) + pc * 8), vk);
                 store16_nt(dq_seq + (dqkv_off(2 * MB_HEADS + head, w * 32) + pc * 8), vv);
