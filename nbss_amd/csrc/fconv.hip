@@ -569,8 +569,8 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
             // IS a bf16 tensor); the sum over the B T slabs is fp32 (fconv_part_final_kernel).  The bias sums stay fp32, in the row's head.
             bf16_t* prow16 = reinterpret_cast<bf16_t*>(part + (size_t)gridDim.x * PROW) + (size_t)blockIdx.x * FC_P16;
             float* pb = part + (size_t)blockIdx.x * PROW + 3 * FC_H;
-#ifdef NBSS_FC_KO_PROW  // (timing knock-out, A/B flavour: no partial-row stores)
-            if (false) {
+#ifdef NBSS_FC_KO_PROW  // (timing knock-out, A/B flavour: no partial-row stores; the contraction stays: the compiler cannot see that `part` is never null)
+            if (part == nullptr) {
 #else
             if (l15 < FC_CG && g4 < 3) {
 #endif

@@ -395,7 +395,9 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
                 rawc_get(dcur[mt], dv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dyp[mt][r] = valid ? dv[r] * dsilu_f(acc[r] + bu[ch + r]) : 0.f;
+#ifndef FL_KO_OPS  // (timing knock-out, A/B flavour: no dy_pre operand)
                 if (valid) store4(dyp_out + n * FL_H + ch, dyp[mt][0], dyp[mt][1], dyp[mt][2], dyp[mt][3]);
+#endif
             }
             f32x4 dzt = F32X4_ZERO;
 #pragma unroll

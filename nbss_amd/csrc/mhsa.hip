@@ -289,7 +289,11 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
                     o1[r] *= inv;
                 }
                 frag_from_c2(of[si][hh], o0, o1);
+#ifdef MH_KO_SAVE  // (timing knock-out, A/B flavour: no saved attention output)
+                if (false) {
+#else
                 if (osave) {  // attention output before out_proj: the only extra activation backward needs
+#endif
                     const int t = (w * NSW + si) * 16 + l15;
                     if (t < T_) {
                         T* orow = osave + ((size_t)bf * T_ + t) * MH_H + (pass * HPP + hh) * MH_DH;

@@ -643,7 +643,11 @@ __global__ __launch_bounds__(512, 4) void mhsa_bwd_h_kernel(nbss_cfg c, LayerPtr
     typedef bf16_t T;
     NBSS_LDS(smem);
     // blocks b, b + 8, b + 16, b + 24 (same XCD, dispatched back to back) = the four heads of one sequence
+#ifdef MHB_FLAT_MAP  // (A/B flavour: four consecutive blocks = the four heads of a sequence, on four XCDs)
+    const int head = blockIdx.x & 3, bf = blockIdx.x >> 2;
+#else
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, head = bi & 3, bf = (bi >> 2) * 8 + xcd;
+#endif
     if (bf >= nseq) return;
     const int T_ = c.T, nst = FULL ? MB_NT : cdiv(T_, 16), nkp = FULL ? MB_NT / 2 : cdiv(nst, 2);
     T* Qr = reinterpret_cast<T*>(smem);

@@ -1771,7 +1771,14 @@ __global__ __launch_bounds__(256, 2) void tconvffn_bwd_q_kernel(nbss_cfg c, Laye
     PHASE_BEGIN(mbox + 4 * TS_CG);
     const TsLane L;
     const int w = wave_id_u(), tid = threadIdx.x;
-    const int row = blockIdx.x >> 2, gq = blockIdx.x & 3;  // the sequence, its group pair (conv groups 2 gq, 2 gq + 1)
+    // the sequence, its group pair (conv groups 2 gq, 2 gq + 1): four consecutive blocks = four XCDs.  Round 6, both measured and not kept:
+    //  * the four pairs of a sequence on ONE XCD (blocks b, b + 8, b + 16, b + 24, as mhsa_bwd_h maps its heads) so that the four readers of a sequence's
+    //    dy share an L2: SLOWER, the kernel 0.950 -> 0.973 of the previous build's time in the same call;
+    //  * a persistent grid (512 workgroups walking the sequences with a static stride, the conv weight-gradient tiles of four sequences accumulated in
+    //    20.7 KB of LDS, 1 152 partial rows instead of 4 128: the partial-row stores are 128 of this kernel's 1 028 us, knocked out): inside a sequence
+    //    loop the body no longer fits 256 registers — ~100 VGPRs go to scratch with every lane / wave / kernel-argument value made opaque per iteration
+    //    (217 without) — and the launch ran 1 890 us, at one or at thirty-two sequences per workgroup alike.
+    const int row = blockIdx.x >> 2, gq = blockIdx.x & 3;
     const size_t n0 = (size_t)row * T_, ntok = (size_t)c.B * c.F * T_;
     const bf16_t* dyb = dy + n0 * TS_H;
 
