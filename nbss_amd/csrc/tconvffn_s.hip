@@ -142,7 +142,9 @@ struct TsFwdW {  // packed fragment bases of one layer
     const bf16_t *W1, *C1, *C2, *C3, *W2;
 };
 
+#ifndef TS_SB
 #define TS_SB 2  // strips per block of a group phase (independent MFMA chains in flight)
+#endif
 
 // What a training-mode forward keeps for the backward pass (tconvffn_bwd_v_kernel below): the pre-activations a1 (W1 output), a2, a3
 // (conv1 / conv2 outputs; a3 = GroupNorm input) as group-major [G][N][24] bf16 tensors — what the reference's autocast graph holds as
