@@ -304,6 +304,7 @@ static SideState* side_state(hipStream_t st = nullptr) {
 int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* packed, const void* xin, void* acts, void* ws, float* out,
                         void* stream) {
     CHECK_CFG(cfg);
+    WalkFlipScope flip_scope(stream_bytes(*cfg));
     if (!params || !packed || !xin || !out || (!acts && !ws)) return NBSS_EINVAL;
     const nbss_cfg& c = *cfg;
     if (acts && c.T > NBSS_T_TRAIN_MAX) return NBSS_EUNSUPPORTED;  // long sequences: inference only
@@ -363,6 +364,7 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
     const nbss_cfg& c = *cfg;
     if (layer_lo < 0 || layer_hi > c.L || layer_lo >= layer_hi) return NBSS_EINVAL;
     if (layer_hi == c.L && !dout) return NBSS_EINVAL;
+    WalkFlipScope flip_scope(stream_bytes(*cfg));
     hipStream_t st = (hipStream_t)stream;
     const size_t sb = stream_bytes(c), wb = workspace_bytes(c);
     auto act = [&](int i) -> const void* { return (const char*)acts + (size_t)i * sb; };

@@ -100,7 +100,7 @@ NBSS_DEV void ln_halfrow_inplace(T* row, const float* __restrict__ gamma, const 
 template <class T, int TT, int GPW, int MTF, int HH>
 __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 ? 4 : 2) : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ cb, const float* __restrict__ slope,
-                                                        const T* __restrict__ Wp, const T* __restrict__ x, T* __restrict__ y) {
+                                                        const T* __restrict__ Wp, const T* __restrict__ x, T* __restrict__ y, int flip) {
     constexpr int FG = HH / FC_G;                 // channels per group
     constexpr int MTG = (FG + 15) / 16;           // output tiles per group
     constexpr int NP = 5 * (FG / 4);              // im2col pieces of 4 channels: (tap, channel quad)
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
     T* u = reinterpret_cast<T*>(smem);
     const int F = c.F, T_ = c.T;
     const int ntt = cdiv(T_, TT);
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
+    const int bid = flip_bid(flip);  // (launch.h: consecutive kernels of a walk traverse the utterances in opposite order)
+    const int b = bid / ntt, t0 = (bid % ntt) * TT;
     const int mtf = cdiv(F, 16), FP = mtf * 16 + 4;
     constexpr int HHP = HH + 8;              // padded (frequency, frame) row: 208 / 400 bytes — consecutive rows start on different LDS banks
     constexpr int ROW = TT * HHP;            // elements per frequency row in LDS
@@ -318,10 +319,11 @@ template <class T, int TT, int NW, bool WGF>
 __global__ __launch_bounds__(64 * NW, NW > 8 ? 3 : 2)  // (9 waves: one SIMD hosts three of them -> at most 168 VGPRs)
 void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb, const float* __restrict__ cb,
                       const float* __restrict__ slope, float* __restrict__ part, const T* __restrict__ Wp, const T* __restrict__ WpT,
-                      const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout) {
+                      const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ stats, T* __restrict__ dvout, int flip) {
     NBSS_LDS(smem);
     const int F = c.F, T_ = c.T, ntt = cdiv(T_, TT);
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
+    const int bid = flip_bid(flip);
+    const int b = bid / ntt, t0 = (bid % ntt) * TT;
     const int mtf = cdiv(F, 16), FP = mtf * 16 + 4, ntile = mtf * TT;
     constexpr int ROW = TT * FC_LD;  // elements per frequency row of an image
     T* u = reinterpret_cast<T*>(smem);          // [FP][TT][LD]  LN(x) (phases 0-1), then du (phases 2-3); image row f+2
@@ -567,8 +569,8 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
             // 288-byte run (round 6; rounds 2-5: fp32 in dW's own [o][i][tap] order = twenty scattered 4-byte stores per lane, 68 of the launch's 335 us
             // with the stores knocked out).  Only the per-slab partial is rounded (under the reference's autocast the weight gradient of a bf16 convolution
             // IS a bf16 tensor); the sum over the B T slabs is fp32 (fconv_part_final_kernel).  The bias sums stay fp32, in the row's head.
-            bf16_t* prow16 = reinterpret_cast<bf16_t*>(part + (size_t)gridDim.x * PROW) + (size_t)blockIdx.x * FC_P16;
-            float* pb = part + (size_t)blockIdx.x * PROW + 3 * FC_H;
+            bf16_t* prow16 = reinterpret_cast<bf16_t*>(part + (size_t)gridDim.x * PROW) + (size_t)bid * FC_P16;
+            float* pb = part + (size_t)bid * PROW + 3 * FC_H;
 #ifdef NBSS_FC_KO_PROW  // (timing knock-out, A/B flavour: no partial-row stores; the contraction stays: the compiler cannot see that `part` is never null)
             if (part == nullptr) {
 #else
@@ -706,7 +708,7 @@ void fconv_bwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __
         float v = aff[i];  // (PReLU slope sums: one contributor per channel)
         if (i < 2 * FC_H)
             for (int k = 0; k < NW; ++k) v += affw[k * 2 * FC_H + i];
-        part[(size_t)blockIdx.x * (WGF ? PROW : 3 * FC_H) + i] = v;
+        part[(size_t)bid * (WGF ? PROW : 3 * FC_H) + i] = v;
     }
     PHASE(7);
     PHASE_END();
@@ -728,7 +730,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
     ProfScope ps(PK_FCONV_B, st);
     NBSS_LAUNCH((fconv_bwd_kernel<T, TT, NW, WGF>), grid, block, lds, st, c, P + param_off(c, layer, lw), P + param_off(c, layer, lb),
                 P + param_off(c, layer, which ? P_FC2_B : P_FC1_B), P + param_off(c, layer, sl), part, pk + pack_off(c, layer, which ? K_FC2 : K_FC1),
-                pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv);
+                pk + pack_off(c, layer, which ? K_FC2_T : K_FC1_T), (const T*)x, (const T*)dy, (T*)dx, stats, (T*)dv, walk_flip_next());
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -796,7 +798,7 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
         float* slices = (float*)((char*)ws + ws_wgpart_offset(c));
         int nsl = 0;
         if ((e = part16_slices_launch(part + (size_t)nwg * 4 * FC_H, nwg, slices, FC_P16, &nsl, gs))) return e;
-        NBSS_LAUNCH(fconv_part_final_kernel, dim3((FC_P16 + 255) / 256), dim3(256), 0, gs, (const float*)slices, nsl, G + param_off(c, layer, which ? P_FC2_W : P_FC1_W));
+        NBSS_FOLD_LAUNCH(fconv_part_final_kernel, dim3((FC_P16 + 255) / 256), dim3(256), 0, gs, (const float*)slices, nsl, G + param_off(c, layer, which ? P_FC2_W : P_FC1_W));
         return NBSS_CHECK_LAUNCH();
     }
     // conv weight: dW[o][i][tap] = sum_n dv[n][o] LN(x)[n + (tap-2) T][i]   (shift along F = T rows), bias = colsum(dv)
@@ -825,7 +827,7 @@ static int fconv_fwd_t(const nbss_cfg& c, const float* P, const void* packed, in
     if (e) return e;
     dim3 grid(c.B * cdiv(c.T, TT)), block(64 * FC_G / GPW);
     ProfScope ps(PK_FCONV_F, st);
-    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW, MTF, HH>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y);
+    NBSS_LAUNCH((fconv_fwd_kernel<T, TT, GPW, MTF, HH>), grid, block, lds, st, c, lnw, lnb, cb, sl, Wp, (const T*)x, (T*)y, walk_flip_next());
     return NBSS_CHECK_LAUNCH();
 }
 

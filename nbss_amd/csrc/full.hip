@@ -74,14 +74,15 @@ void full_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __r
                                                        const float* __restrict__ bs, const float* __restrict__ bfull,
                                                        const float* __restrict__ bu, const T* __restrict__ Wsq,
                                                        const T* __restrict__ Wfull, const T* __restrict__ Wusq,
-                                                       const T* __restrict__ x, T* __restrict__ y) {
+                                                       const T* __restrict__ x, T* __restrict__ y, int flip) {
     NBSS_LDS(smem);
     const int F = c.F, T_ = c.T;
     const int mtf = cdiv(F, 16), ksf = cdiv(F, 32), FK = ksf * 32, FM = mtf * 16;
     T* s = reinterpret_cast<T*>(smem);             // [SQ][TT][FK]
     T* z = s + NSQ * TT * FK;                 // [FM][TT][SQ]
     const int ntt = cdiv(T_, TT);
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
+    const int bid = flip_bid(flip);  // (launch.h: consecutive kernels of a walk traverse the utterances in opposite order)
+    const int b = bid / ntt, t0 = (bid % ntt) * TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
     const int ntile = cdiv(F, 16 / TT);  // n-tiles of (16 / TT freqs x TT frames)
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
                                                        const T* __restrict__ WsqT, const T* __restrict__ WfullT, const T* __restrict__ WusqT,
                                                        const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                        float* __restrict__ stats, T* __restrict__ s_out, T* __restrict__ dz_out,
-                                                       T* __restrict__ z_out, T* __restrict__ dyp_out, T* __restrict__ dsp_out) {
+                                                       T* __restrict__ z_out, T* __restrict__ dyp_out, T* __restrict__ dsp_out, int flip) {
     NBSS_LDS(smem);
     const int F = c.F, T_ = c.T;
     const int mtf = cdiv(F, 16), ksf = cdiv(F, 32), FK = ksf * 32, FM = mtf * 16, FKP = FL_FKP(F);
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
     // sums gone as well (below) the kernel fits 128 VGPRs and TWO workgroups share a CU — its row loops are bound by exposed latency
     T* wl = reinterpret_cast<T*>(aff + FL_SQ * 17);                    // [FL_WFR][512]
     const int ntt = cdiv(T_, TT);
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x % ntt) * TT;
+    const int bid = flip_bid(flip);  // (launch.h: consecutive kernels of a walk traverse the utterances in opposite order)
+    const int b = bid / ntt, t0 = (bid % ntt) * TT;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id(), nw = nthr >> 6;
     const int ntile = cdiv(F, 16 / TT);
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
     for (int i = tid; i < FL_SQ; i += nthr) {
         float v = 0.f;
         for (int mt = 0; mt < mtf; ++mt) v += aff[i * 17 + mt];
-        part[(size_t)blockIdx.x * FL_SQ + i] = v;
+        part[(size_t)bid * FL_SQ + i] = v;
     }
     PHASE_END();
 }
@@ -572,7 +574,7 @@ static int full_bwd_tt(const nbss_cfg& c, const float* P, float* part, const voi
     ProfScope ps(PK_FULL_B, st);
     NBSS_LAUNCH((full_bwd_kernel<T, KSFM, TT>), grid, block, lds, st, c, lp, P, part, layer, pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL),
                 pk + pack_off(c, layer, K_USQ), pk + pack_off(c, layer, K_SQ_T), pk + pack_off(c, layer, K_FULL_T), pk + pack_off(c, layer, K_USQ_T),
-                (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4]);
+                (const T*)x, (const T*)dy, (T*)dx, stats, (T*)o[0], (T*)o[1], (T*)o[2], (T*)o[3], (T*)o[4], walk_flip_next());
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -618,7 +620,7 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     if (e) return e;
     // everything below only produces parameter gradients: gradient stream (side.h)
     const hipStream_t gs = side_fork(sd, st);
-    NBSS_LAUNCH(full_sq_prep_kernel, dim3(1), dim3(256), 0, gs, sqtmp);
+    NBSS_FOLD_LAUNCH(full_sq_prep_kernel, dim3(1), dim3(256), 0, gs, sqtmp);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     // squeeze bias gradient (fp32 sums of the kernel) -> tmp.dbs
     AffSegs sg;
@@ -649,7 +651,7 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.gamma = sqtmp + FL_SQ * FL_H + FL_SQ; a.beta = sqtmp + FL_SQ * FL_H + FL_SQ + FL_H;
     a.dW = sqtmp; a.dbias = nullptr;
     if ((e = wgrad_launch(a, c.dtype, gs))) return e;
-    NBSS_LAUNCH(full_sq_finalize_kernel, dim3(1), dim3(FL_H), 0, gs, (const float*)sqtmp, lp.p[P_SQ_W], lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
+    NBSS_FOLD_LAUNCH(full_sq_finalize_kernel, dim3(1), dim3(FL_H), 0, gs, (const float*)sqtmp, lp.p[P_SQ_W], lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 G + param_off(c, layer, P_SQ_W), G + param_off(c, layer, P_SQ_B), G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B));
     return NBSS_CHECK_LAUNCH();
 }
@@ -667,7 +669,7 @@ static int full_fwd_tt(const nbss_cfg& c, const float* P, const void* packed, in
     ProfScope ps(PK_FULL_F, st);
     NBSS_LAUNCH((full_fwd_kernel<T, KSFM, G::H, G::SQ, TT>), grid, block, lds, st, c, lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 lp.p[P_SQ_B], lp.p[P_FULL_B], lp.p[P_USQ_B],
-                pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y);
+                pk + pack_off(c, layer, K_SQ), pk + pack_off(c, layer, K_FULL), pk + pack_off(c, layer, K_USQ), (const T*)x, (T*)y, walk_flip_next());
     return NBSS_CHECK_LAUNCH();
 }
 

@@ -31,6 +31,9 @@
 #ifndef MH_BF16_NSW
 #define MH_BF16_NSW 2
 #endif
+#ifndef MH_BF16_HPP
+#define MH_BF16_HPP 4  // heads per pass of the bf16 kernel (A/B: 2 = two passes of a head pair, K / V images of 49 KB)
+#endif
 
 // LN of a 16-frame strip held as natural-order B fragments (lane: frame l&15, channels 32ks+8g+j)
 template <class T>
@@ -76,10 +79,10 @@ NBSS_DEV void v_frag_tr(Frag<float>&, const float*, int, int) {}
 
 // FULL: T in (240, 256]: every key tile exists, the tile tests fold at compile time (see mhsa_bwd.hip)
 template <class T, int HPP, bool FULL, int NSW>
-__global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+__global__ __launch_bounds__(64 * 16 / NSW, NSW == 4 ? 2 : 1) void mhsa_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ bin, const float* __restrict__ bout,
                                                        const T* __restrict__ Win, const T* __restrict__ Wout,
-                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave, float* __restrict__ lse, int bf0) {
+                                                       const T* __restrict__ x, T* __restrict__ y, T* __restrict__ osave, float* __restrict__ lse, int bf0, int flip) {
     NBSS_LDS(smem);
     T* Ks = reinterpret_cast<T*>(smem);              // [HPP][TP][DH]
     T* Vt = Ks + HPP * MH_TP * MH_DH;                // [HPP][DH][TP]
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
     T* wl = Vt + HPP * MH_TP * MH_DH + 32;           // [48][512]
     float* prm = reinterpret_cast<float*>(wl + (WLDS ? 48 * 512 : 0));  // [3H in_proj bias | H out_proj bias | 2H LN gamma, beta]
     const int T_ = c.T, nst = FULL ? MH_NT : cdiv(T_, 16);
-    const int bf = blockIdx.x + bf0;  // (bf0: first sequence of this launch — the walk's tail launch, side.h: SeqTail)
+    const int bf = flip_bid(flip) + bf0;  // (bf0: first sequence of this launch — the walk's tail launch, side.h: SeqTail; flip: launch.h)
     const int tid = threadIdx.x, lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
     const T* xb = x + (size_t)bf * T_ * MH_H;
     T* yb = y + (size_t)bf * T_ * MH_H;
@@ -306,6 +309,45 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
         }
 
         // ---- stage C: output projection (+bias, +residual) --------------------------------------
+        if constexpr (NSW > 2) {  // four strips per wave: one strip at a time (the residual rows of all four would be 96 registers)
+#pragma unroll 1
+            for (int si = 0; si < NSW; ++si) {
+                const int t = (w * NSW + si) * 16 + l15;
+                float rv[MH_H / 16][4];
+#pragma unroll
+                for (int mt = 0; mt < MH_H / 16; ++mt) {
+                    if (t < T_) load4((pass == 0 ? xb : yb) + (size_t)t * MH_H + 16 * mt + 4 * g4, rv[mt]);
+                    else rv[mt][0] = rv[mt][1] = rv[mt][2] = rv[mt][3] = 0.f;
+                }
+                Frag<T> ofs[HPP];
+#pragma unroll
+                for (int hh = 0; hh < HPP; ++hh) {
+                    ofs[hh] = of[0][hh];
+#pragma unroll
+                    for (int k = 1; k < NSW; ++k)
+                        if (si == k) ofs[hh] = of[k][hh];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MH_H / 16; ++mt) {
+                    const int ch = 16 * mt + 4 * g4;
+                    f32x4 acc = F32X4_ZERO;
+#pragma unroll
+                    for (int hh = 0; hh < HPP; ++hh) {
+                        Frag<T> a;
+                        if (WLDS) frag_load(a, wl + ((size_t)24 + mt * MH_HEADS + hh) * 512 + lane * 8);
+                        else wfrag_load(a, Wout, mt, MH_HEADS, pass * HPP + hh);
+                        acc = mma(a, ofs[hh], acc);
+                    }
+                    float bo[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (pass == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bo[r] = WLDS ? prm[3 * MH_H + ch + r] : bout[ch + r];
+                    }
+                    if (t < T_)
+                        store4(yb + (size_t)t * MH_H + ch, rv[mt][0] + bo[0] + acc[0], rv[mt][1] + bo[1] + acc[1], rv[mt][2] + bo[2] + acc[2], rv[mt][3] + bo[3] + acc[3]);
+                }
+            }
+        } else {
         // the residual rows are requested up front (one wait instead of one per output tile)
         float rv[NSW][MH_H / 16][4];
 #pragma unroll
@@ -342,6 +384,7 @@ __global__ __launch_bounds__(64 * 16 / NSW) void mhsa_fwd_kernel(nbss_cfg c, con
                            rv[si][mt][3] + bo[3] + acc[3]);
             }
         }
+        }
     }
 }
 
@@ -355,16 +398,17 @@ static int mhsa_fwd_t(const nbss_cfg& c, const float* P, const void* packed, int
     if (e) return e;
     const int nseq = c.B * c.F, ntail = tl ? tl->n : 0;
     dim3 grid(nseq - ntail), block(64 * 16 / NSW);
+    const int flip = walk_flip_next();  // (one direction for the main and the tail launch)
     ProfScope ps(PK_MHSA_F, st);
     float* lse = osave ? (float*)((char*)osave + mhsa_lse_offset(c)) : nullptr;
     NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL, NSW>), grid, block, lds, st, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                 P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
-                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, lse, 0);
+                pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, lse, 0, flip);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     if (ntail > 0)  // the last, nearly empty round of sequences: on the walk's second stream, overlapping the next row kernel's full rounds
         NBSS_LAUNCH((mhsa_fwd_kernel<T, HPP, FULL, NSW>), dim3(ntail), block, lds, tl->ts, c, P + param_off(c, layer, P_MH_LN_W), P + param_off(c, layer, P_MH_LN_B),
                     P + param_off(c, layer, P_INP_B), P + param_off(c, layer, P_OUTP_B), pk + pack_off(c, layer, K_INP),
-                    pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, lse, nseq - ntail);
+                    pk + pack_off(c, layer, K_OUTP), (const T*)x, (T*)y, (T*)osave, lse, nseq - ntail, flip);
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -690,5 +734,5 @@ int mhsa_fwd_impl(const nbss_cfg& c, const float* P, const void* packed, int lay
     // T > 256: `osave` is the K | V scratch of the two-launch long-sequence path (nothing is saved for backward)
     if (c.T > MH_TP) return c.dtype == NBSS_BF16 ? mhsa_fwd_long_t<bf16_t, GeoS, 128>(c, P, packed, layer, x, y, osave, st) : mhsa_fwd_long_t<float, GeoS, 128>(c, P, packed, layer, x, y, osave, st);
     if (c.dtype != NBSS_BF16) return mhsa_fwd_t<float, 2, false, 2>(c, P, packed, layer, x, y, osave, st, nullptr);
-    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, 4, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st, tl) : mhsa_fwd_t<bf16_t, 4, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st, tl);
+    return cdiv(c.T, 16) == MH_NT ? mhsa_fwd_t<bf16_t, MH_BF16_HPP, true, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st, tl) : mhsa_fwd_t<bf16_t, MH_BF16_HPP, false, MH_BF16_NSW>(c, P, packed, layer, x, y, osave, st, tl);
 }

@@ -639,16 +639,17 @@ NBSS_DEV void frag_pack_c2(Frag<bf16_t>& f, const f32x4& lo, const f32x4& hi) { 
 template <bool FULL>
 __global__ __launch_bounds__(512, 4) void mhsa_bwd_h_kernel(nbss_cfg c, LayerPtrs lp, int nseq, const bf16_t* __restrict__ Win, const bf16_t* __restrict__ WoutT,
                                                             const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ osave,
-                                                            const float* __restrict__ lse, const float* __restrict__ stats, bf16_t* __restrict__ dqkv) {
+                                                            const float* __restrict__ lse, const float* __restrict__ stats, bf16_t* __restrict__ dqkv, int flip) {
     typedef bf16_t T;
     NBSS_LDS(smem);
     // blocks b, b + 8, b + 16, b + 24 (same XCD, dispatched back to back) = the four heads of one sequence
 #ifdef MHB_FLAT_MAP  // (A/B flavour: four consecutive blocks = the four heads of a sequence, on four XCDs)
-    const int head = blockIdx.x & 3, bf = blockIdx.x >> 2;
+    const int head = blockIdx.x & 3, bf0 = blockIdx.x >> 2;
 #else
-    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, head = bi & 3, bf = (bi >> 2) * 8 + xcd;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, head = bi & 3, bf0 = (bi >> 2) * 8 + xcd;
 #endif
-    if (bf >= nseq) return;
+    if (bf0 >= nseq) return;
+    const int bf = flip ? nseq - 1 - bf0 : bf0;  // (launch.h: consecutive kernels of a walk traverse the utterances in opposite order)
     const int T_ = c.T, nst = FULL ? MB_NT : cdiv(T_, 16), nkp = FULL ? MB_NT / 2 : cdiv(nst, 2);
     T* Qr = reinterpret_cast<T*>(smem);
     T* Kr = Qr + MH_TP * MB_DH;
@@ -1038,7 +1039,7 @@ static int mhsa_bwd_h_t(const nbss_cfg& c, const float* P, const void* packed, i
     const int nseq = c.B * c.F;
     dim3 grid(cdiv(nseq, 8) * 8 * MB_HEADS), block(512);
     NBSS_LAUNCH((mhsa_bwd_h_kernel<FULL>), grid, block, lds, st, c, lp, nseq, pk + pack_off(c, layer, K_INP), pk + pack_off(c, layer, K_OUTP_T), (const bf16_t*)x,
-                (const bf16_t*)dy, (const bf16_t*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)), stats, (bf16_t*)dqkv);
+                (const bf16_t*)dy, (const bf16_t*)osave, (const float*)((const char*)osave + mhsa_lse_offset(c)), stats, (bf16_t*)dqkv, walk_flip_next());
     return NBSS_CHECK_LAUNCH();
 }
 

@@ -47,6 +47,7 @@ struct TailArgs {
     const bf16_t* WT;     // packed W^T fragments [6][MA/32][64][8] (K_TF_W1_TN / K_INP_TN: rows = H, K = MA natural)
     float* part;          // [grid][ntot][256] partial dW tiles | [grid][ntot][16] bias sums (WGPART region)
     int Ntok;
+    int flip;             // launch.h: walk the chunks from the last one down (the data-gradient kernel before this one ran the other way)
 };
 
 // Wave specialisation: waves 4-7 hold ALL dW accumulators (NTOT / 4 tiles each), waves 0-3 run the tail.  The two roles are two
@@ -80,8 +81,9 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     // staging: slot u < UA is a da piece for every thread, the rest x pieces (a few lanes of the last slot of each kind idle)
     u32x4 preA[UA], preX[UX];
     float pmu[UX], prs[UX];
+    auto phys = [&](int ch) -> int { return a.flip ? nchunks - 1 - ch : ch; };  // logical -> token chunk
     auto prefetch = [&](int ch) {
-        const long n0 = (long)ch * TW_KC;
+        const long n0 = (long)phys(ch) * TW_KC;
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             const int v = tid + u * TW_THREADS, r = v / PA, col = (v % PA) * 8;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
         // 153 us (W1), with the contraction waves knocked out 424 -> 408: the tail waves were the critical path of every chunk.
         constexpr int TPW = TW_KC / 16 / NTW;  // tiles of a chunk per tail wave
         auto tail_rows = [&](int ch, int tile, bool& tv, size_t& nrow) {
-            const long nt0 = (long)ch * TW_KC + 16 * tile + l15;
+            const long nt0 = (long)phys(ch) * TW_KC + 16 * tile + l15;
             tv = nt0 < a.Ntok;
             nrow = (size_t)(tv ? nt0 : a.Ntok - 1);  // clamped address, validity applied on use
         };
@@ -316,6 +318,7 @@ static int tailw_go(const TailArgs& t, int grid, hipStream_t st) {
 int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes, const float* W, float* dW, float* dbias, float* dgamma, float* dbeta,
                  hipStream_t st, const Side* sd, hipStream_t* gs_out) {
     TailArgs t = t0;
+    t.flip = walk_flip_next();
     const int nchunks = cdiv(t.Ntok, TW_KC);
     const int grid = nchunks < 256 ? nchunks : 256;
     const int ntot = (MA / 16) * (TW_H / 16);
@@ -331,9 +334,9 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
     if (e) return e;
     const hipStream_t gs = side_fork(sd, st);
     if (gs_out) *gs_out = gs;
-    NBSS_LAUNCH(tailw_finalize_kernel, dim3(4 * ntot), dim3(64 * TW_RSL), 2 * TW_RSL * 64 * sizeof(float), gs, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias);
+    NBSS_FOLD_LAUNCH(tailw_finalize_kernel, dim3(4 * ntot), dim3(64 * TW_RSL), 2 * TW_RSL * 64 * sizeof(float), gs, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
-    NBSS_LAUNCH(tailw_affine_kernel, dim3(1), dim3(2 * TW_H), 0, gs, (const float*)wgpart, MA / 16, dgamma, dbeta);
+    NBSS_FOLD_LAUNCH(tailw_affine_kernel, dim3(1), dim3(2 * TW_H), 0, gs, (const float*)wgpart, MA / 16, dgamma, dbeta);
     return NBSS_CHECK_LAUNCH();
 }
 

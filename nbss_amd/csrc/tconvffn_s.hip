@@ -159,7 +159,7 @@ struct TsSave {
 // SAVE: training-mode forward (sv is filled); inference launches the SAVE = false instance (no stores, no extra packing)
 template <bool SAVE>
 __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPtrs lp, TsFwdW W, const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                             TsSave sv, int bf0) {
+                                                             TsSave sv, int bf0, int flip) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32;
     bf16_t* img = reinterpret_cast<bf16_t*>(smem);  // [NT + TS_PAD][TS_RS]
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
     load_wfrags<5>(wc3, W.C3, w, L.lane);
     // One workgroup per sequence.  (A persistent grid of 256 workgroups looping over sequences was measured SLOWER, 675 vs 524 us
     // per launch at batch 31: all CUs then march through the HBM-latency and the VALU-bound phases in lock step.)
-    const int bf = blockIdx.x + bf0;  // (bf0: first sequence of this launch — side.h: SeqTail)
+    const int bf = flip_bid(flip) + bf0;  // (bf0: first sequence of this launch — side.h: SeqTail; flip: launch.h)
     const size_t n0 = (size_t)bf * T_, ntok = (size_t)c.B * c.F * T_;
     {
     const bf16_t* xb = x + (size_t)bf * T_ * TS_H;
@@ -487,19 +487,20 @@ int tconvffn_fwd_s_impl(const nbss_cfg& c, const float* P, const void* packed, i
                 pk + pack_off(c, layer, K_TS_W2)};
     const int nseq = c.B * c.F, ntail = tl ? tl->n : 0;  // (tail launch: see mhsa_fwd_t)
     dim3 grid(nseq - ntail), block(512);
+    const int flip = walk_flip_next();  // (one direction for the main and the tail launch)
     ProfScope ps(PK_TCF_F, st);
     int e;
     if (tsave) {
         if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<true>, lds))) return e;
-        NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave), 0);
+        NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave), 0, flip);
         if (ntail > 0 && !(e = NBSS_CHECK_LAUNCH()))
-            NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, dim3(ntail), block, lds, tl->ts, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave), nseq - ntail);
+            NBSS_LAUNCH(tconvffn_fwd_s_kernel<true>, dim3(ntail), block, lds, tl->ts, c, lp, W, (const bf16_t*)x, (bf16_t*)y, ts_save_ptrs(c, tsave), nseq - ntail, flip);
     } else {
         TsSave none = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if ((e = NBSS_SET_MAX_LDS(tconvffn_fwd_s_kernel<false>, lds))) return e;
-        NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none, 0);
+        NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, grid, block, lds, st, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none, 0, flip);
         if (ntail > 0 && !(e = NBSS_CHECK_LAUNCH()))
-            NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, dim3(ntail), block, lds, tl->ts, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none, nseq - ntail);
+            NBSS_LAUNCH(tconvffn_fwd_s_kernel<false>, dim3(ntail), block, lds, tl->ts, c, lp, W, (const bf16_t*)x, (bf16_t*)y, none, nseq - ntail, flip);
     }
     if (e) return e;
     return NBSS_CHECK_LAUNCH();
@@ -1760,7 +1761,7 @@ __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPt
 // barrier waits overlap the other's math.  The strip phase takes two strips per wave; dy is read by four workgroups per sequence (L2).  No room for the
 // dy image beside two resident workgroups: this variant emits the h5 operand and the W2 weight gradient is wgrad.hip's, as in round 4.
 __global__ __launch_bounds__(256, 2) void tconvffn_bwd_q_kernel(nbss_cfg c, LayerPtrs lp, TvW W, TvIn sv, const bf16_t* __restrict__ dy, float* __restrict__ part,
-                                                                bf16_t* __restrict__ part16, bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1) {
+                                                                bf16_t* __restrict__ part16, bf16_t* __restrict__ op_h5, bf16_t* __restrict__ op_da1, int flip) {
     NBSS_LDS(smem);
     const int T_ = c.T, NS = (T_ + 31) >> 5, NT = NS * 32, NSL = NS >> 1, TS = 32 * NSL;
     bf16_t* S = reinterpret_cast<bf16_t*>(smem);         // [NT + TB_PAD][TQ_RS]  the gradient chain, in place
@@ -1780,7 +1781,7 @@ __global__ __launch_bounds__(256, 2) void tconvffn_bwd_q_kernel(nbss_cfg c, Laye
     //    20.7 KB of LDS, 1 152 partial rows instead of 4 128: the partial-row stores are 128 of this kernel's 1 028 us, knocked out): inside a sequence
     //    loop the body no longer fits 256 registers — ~100 VGPRs go to scratch with every lane / wave / kernel-argument value made opaque per iteration
     //    (217 without) — and the launch ran 1 890 us, at one or at thirty-two sequences per workgroup alike.
-    const int row = blockIdx.x >> 2, gq = blockIdx.x & 3;
+    const int row0 = blockIdx.x >> 2, gq = blockIdx.x & 3, row = flip ? (int)(gridDim.x >> 2) - 1 - row0 : row0;  // (flip: launch.h)
     const size_t n0 = (size_t)row * T_, ntok = (size_t)c.B * c.F * T_;
     const bf16_t* dyb = dy + n0 * TS_H;
 
@@ -2175,15 +2176,15 @@ size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV
 int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl_out, hipStream_t st) {
     const int nsl = nrows < TV_RSL ? nrows : TV_RSL;
     *nsl_out = nsl;
-    NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
+    NBSS_FOLD_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
     return NBSS_CHECK_LAUNCH();
 }
 int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, bool with_w2, hipStream_t st) {
     const int nrows = c.B * c.F, nsl = nrows < TV_RSL ? nrows : TV_RSL, p16 = with_w2 ? TV_P16 : TQ_P16;
-    NBSS_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
+    NBSS_FOLD_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;
-    NBSS_LAUNCH(tconv_part_reduce2_kernel, dim3((p16 + 255) / 256), dim3(256), 0, st, (const float*)slices, nsl, G, offs[0], offs[1], offs[2], offs[3], p16);
+    NBSS_FOLD_LAUNCH(tconv_part_reduce2_kernel, dim3((p16 + 255) / 256), dim3(256), 0, st, (const float*)slices, nsl, G, offs[0], offs[1], offs[2], offs[3], p16);
     return NBSS_CHECK_LAUNCH();
 }
 size_t tconvffn_v_slices_bytes() { return (size_t)TV_RSL * TV_P16 * sizeof(float); }
@@ -2220,7 +2221,8 @@ int tconvffn_bwd_q_launch(const nbss_cfg& c, const LayerPtrs& lp, float* part, c
     TvIn in = {s.a1, s.a2, s.a3, s.gn};
     int e = NBSS_SET_MAX_LDS(tconvffn_bwd_q_kernel, lds);
     if (e) return e;
-    NBSS_LAUNCH(tconvffn_bwd_q_kernel, dim3(4 * c.B * c.F), dim3(256), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_h5, (bf16_t*)op_da1);
+    NBSS_LAUNCH(tconvffn_bwd_q_kernel, dim3(4 * c.B * c.F), dim3(256), lds, st, c, lp, W, in, (const bf16_t*)dy, part, part16, (bf16_t*)op_h5, (bf16_t*)op_da1,
+                walk_flip_next());
     return NBSS_CHECK_LAUNCH();
 }
 float* tconvffn_save_ln_stats(const nbss_cfg& c, void* tsave) { return ts_save_ptrs(c, tsave).ln; }

@@ -2,6 +2,15 @@
 #include "launch.h"
 #include "blocks.h"
 #include <string.h>
+#include <cstdlib>
+
+// launch.h: the traversal direction of the walks' main-stream kernels
+thread_local WalkFlip g_walk_flip = {0, 0u};
+WalkFlipScope::WalkFlipScope(size_t stream_bytes) {
+    static const int knob = [] { const char* v = getenv("NBSS_FLIP"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();  // A/B knob: 0 off, 1 on at every size
+    prev = g_walk_flip.on;
+    g_walk_flip.on = knob >= 0 ? knob : (stream_bytes >= ((size_t)64 << 20) ? 1 : 0);
+}
 
 int memset_async_impl(void* p, size_t bytes, hipStream_t st) {
 #ifdef NBSS_EMU
@@ -64,9 +73,9 @@ int affine_reduce_launch(const float* part, int nwg, const AffSegs& segs, float*
     for (int i = 0; i < segs.n; ++i) naff += segs.cnt[i];
     const int nsl = nwg < AFF_SLICES ? nwg : AFF_SLICES;
     if (nsl < 1) return NBSS_OK;
-    NBSS_LAUNCH(affine_slices_kernel, dim3((naff + 127) / 128, nsl), dim3(128), 0, st, const_cast<float*>(part), nwg, naff);
+    NBSS_FOLD_LAUNCH(affine_slices_kernel, dim3((naff + 127) / 128, nsl), dim3(128), 0, st, const_cast<float*>(part), nwg, naff);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;
-    NBSS_LAUNCH(affine_final_kernel, dim3((naff + 127) / 128), dim3(128), 0, st, part, nwg, naff, nsl, segs, G);
+    NBSS_FOLD_LAUNCH(affine_final_kernel, dim3((naff + 127) / 128), dim3(128), 0, st, part, nwg, naff, nsl, segs, G);
     return NBSS_CHECK_LAUNCH();
 }

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(64 * WG_RSL) void wgrad_reduce_kernel(WgradArgs a, 
 }
 
 static int wgrad_reduce_go(const WgradArgs& a, int ntot, int xb, int ybl, int nt_major, hipStream_t st) {
-    NBSS_LAUNCH(wgrad_reduce_kernel, dim3(4 * ntot, 1, ybl), dim3(64 * WG_RSL), WG_RSL * 80 * sizeof(float), st, a, xb, nt_major);
+    NBSS_FOLD_LAUNCH(wgrad_reduce_kernel, dim3(4 * ntot, 1, ybl), dim3(64 * WG_RSL), WG_RSL * 80 * sizeof(float), st, a, xb, nt_major);
     return NBSS_CHECK_LAUNCH();
 }
 
