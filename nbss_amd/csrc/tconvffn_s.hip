@@ -80,6 +80,9 @@ NBSS_DEV void p6_gstore(bf16_t* __restrict__ g, const P6& p, bool ok, bool nt) {
     return;
 #endif
     if (!ok) return;
+#ifdef NBSS_TS_NT0  // (A/B flavour: plain stores)
+    nt = false;
+#endif
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         u32x2 v = {p.d[2 * q], p.d[2 * q + 1]};
@@ -88,6 +91,24 @@ NBSS_DEV void p6_gstore(bf16_t* __restrict__ g, const P6& p, bool ok, bool nt) {
         else
 #endif
             *reinterpret_cast<u32x2*>(g + 8 * q) = v;
+    }
+}
+// whole rows of a group's [tokens][24] bf16 slice: LDS rows (stride RS elements) -> the group-major global tensor, 16 bytes per lane, consecutive lanes =
+// consecutive addresses (three pieces per token)
+template <int NPMAX, int RS>
+NBSS_DEV void rows_gstore_t(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 0; k < (NPMAX + 63) / 64; ++k) {
+        const int i = lane + 64 * k, tok = i / 3, part = i - 3 * tok;
+        if (i < 3 * nrows && tok < nvalid) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + (size_t)tok * RS + 8 * part);
+#ifndef NBSS_EMU
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part));
+#else
+            *reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part) = v;
+#endif
+        }
     }
 }
 NBSS_DEV FragH frag_const_one() {  // K slot 0 = 1.0, the rest 0: the B side of a bias slot
@@ -249,6 +270,9 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
         }
         bf16_t* orow = img + (size_t)(3 + t) * TS_RS + 4 * L.h;
         const uint32_t vm = lane_mask(tv);
+        P6 hprev;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) hprev.d[i] = 0u;
 #pragma unroll 2
         for (int g = 0; g < TS_G; ++g) {
             FragH w1[7];
@@ -258,6 +282,7 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
             for (int ks = 1; ks < 7; ++ks) a1 = mma32(w1[ks], u[ks], a1);
             P6 h1;
             silu_pack(a1, vm, h1);
+#ifdef NBSS_TS_LANE_SAVE  // (A/B flavour: rounds 3-5's lane-wise saves)
             p6_store(orow + g * TS_CG, h1);
             if (SAVE) {
                 P6 pa;
@@ -265,7 +290,36 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                 for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a1[2 * i], a1[2 * i + 1]);
                 p6_gstore(sv.a1 + ((size_t)g * ntok + n0 + t) * TS_CG + 4 * L.h, pa, tv, true);
             }
+#else
+            if (SAVE) {
+                // The saved pre-activation leaves as WHOLE ROWS (round 6): staged in the image where h1 of the same group goes — the wave's own 32 rows,
+                // nobody else touches them before the barrier —, read back one group later as 16-byte pieces in address order and only then replaced
+                // by h1.  (Lane-wise: three 8-byte stores per lane, each instruction covering 16 of every 48 bytes of a 1.5 KB span.  Measured in one call: the
+                // kernel 708 -> 689 us, the step +0.4 % at batch 32 and +1.5 % at batch 8; with the three saves knocked out it runs 548 us — the rest is their bytes.)
+                P6 pa;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a1[2 * i], a1[2 * i + 1]);
+                p6_store(orow + g * TS_CG, pa);
+                if (g > 0) {
+                    wave_lds_sync();
+                    rows_gstore_t<96, TS_RS>(sv.a1 + ((size_t)(g - 1) * ntok + n0 + 32 * w) * TS_CG, img + (size_t)(3 + 32 * w) * TS_RS + (g - 1) * TS_CG, 32, T_ - 32 * w);
+                    wave_lds_sync();
+                    p6_store(orow + (g - 1) * TS_CG, hprev);
+                }
+                hprev = h1;
+            } else {
+                p6_store(orow + g * TS_CG, h1);
+            }
+#endif
         }
+#ifndef NBSS_TS_LANE_SAVE
+        if (SAVE) {
+            wave_lds_sync();
+            rows_gstore_t<96, TS_RS>(sv.a1 + ((size_t)(TS_G - 1) * ntok + n0 + 32 * w) * TS_CG, img + (size_t)(3 + 32 * w) * TS_RS + (TS_G - 1) * TS_CG, 32, T_ - 32 * w);
+            wave_lds_sync();
+            p6_store(orow + (TS_G - 1) * TS_CG, hprev);
+        }
+#endif
     }
     PHASE(0);
     lds_barrier();
@@ -282,7 +336,8 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
     // ---- group phases: wave g owns channels 24g..24g+23 of every row ------------------------------------------------------------
     const int g = w, cbase = g * TS_CG;
     bf16_t* col = img + cbase;  // &img[0][24 g]
-    const size_t gsave = ((size_t)g * ntok + n0) * TS_CG + 4 * L.h;  // this lane's piece of token 0 in a saved [G][N][24] tensor
+    const size_t gsave0 = ((size_t)g * ntok + n0) * TS_CG, gsave = gsave0 + 4 * L.h;  // token 0 of this group in a saved [G][N][24] tensor (+ this lane's piece)
+    bf16_t* scr = wl + (size_t)NV2 * 8 + (size_t)w * (32 * TS_CG);  // [32][24] per wave, behind the 39 W2 fragments
     // conv1: h1 (rows 3 + t) -> h2 = SiLU(.) (rows 2 + t)
 #pragma unroll 1
     for (int s0 = 0; s0 < NS; s0 += TS_SB) {
@@ -301,7 +356,15 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                     P6 pa;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) pa.d[i] = pack2bf(a2[2 * i], a2[2 * i + 1]);
+#ifdef NBSS_TS_LANE_SAVE
                     p6_gstore(sv.a2 + gsave + (size_t)(32 * (s0 + k) + L.n) * TS_CG, pa, 32 * (s0 + k) + L.n < T_, true);
+#else
+                    // whole rows through the wave's scratch strip (the window's 17 KB behind the W2 fragments: W1 is dead since the barrier)
+                    p6_store(scr + L.n * TS_CG + 4 * L.h, pa);
+                    wave_lds_sync();
+                    rows_gstore_t<96, TS_CG>(sv.a2 + gsave0 + (size_t)32 * (s0 + k) * TS_CG, scr, 32, T_ - 32 * (s0 + k));
+                    wave_lds_sync();
+#endif
                 }
             }
     }
@@ -335,10 +398,19 @@ __global__ __launch_bounds__(512) void tconvffn_fwd_s_kernel(nbss_cfg c, LayerPt
                     s2 += v0 * v0 + v1 * v1;
                 }
                 p6_store(col + (size_t)(1 + 32 * (s0 + k) + L.n) * TS_RS + 4 * L.h, a3p);
+#ifdef NBSS_TS_LANE_SAVE
                 if (SAVE) p6_gstore(sv.a3 + gsave + (size_t)(32 * (s0 + k) + L.n) * TS_CG, a3p, 32 * (s0 + k) + L.n < T_, true);
+#endif
             }
     }
     if (L.lane < 6) *reinterpret_cast<u32x2*>(col + (size_t)(1 + NT) * TS_RS + 4 * L.lane) = (u32x2){0u, 0u};
+#ifndef NBSS_TS_LANE_SAVE
+    if (SAVE) {  // a3 sits in the image (rows 1 + t of the group's column) until GroupNorm rewrites it: the whole column slice leaves in address order
+        wave_lds_sync();
+        rows_gstore_t<3 * 256, TS_RS>(sv.a3 + gsave0, col + (size_t)TS_RS, NT, T_);
+        wave_lds_sync();
+    }
+#endif
     s1 = wave_sum64(s1);
     s2 = wave_sum64(s2);
     const float cnt = (float)(TS_CG * T_);
@@ -564,22 +636,6 @@ NBSS_DEV void p6_gload(const bf16_t* __restrict__ g, P6& p) {
 // ONE contiguous run (48 bytes per frame), read back by the wave that has just written the rows (same wave: LDS executes in order).
 // The lane-wise form (p6_gstore: three 8-byte stores per lane, each instruction covering 16 of every 48 bytes of a 1.5 KB span) cost a
 // quarter of the kernel: knocked out, tconvffn_bwd went from 12.8 to 10.3 ms per step.
-template <int NPMAX, int RS>
-NBSS_DEV void rows_gstore_t(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int k = 0; k < (NPMAX + 63) / 64; ++k) {
-        const int i = lane + 64 * k, tok = i / 3, part = i - 3 * tok;
-        if (i < 3 * nrows && tok < nvalid) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(lsrc + (size_t)tok * RS + 8 * part);
-#ifndef NBSS_EMU
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part));
-#else
-            *reinterpret_cast<u32x4*>(gdst + (size_t)tok * TS_CG + 8 * part) = v;
-#endif
-        }
-    }
-}
 template <int NPMAX>
 NBSS_DEV void rows_gstore(bf16_t* __restrict__ gdst, const bf16_t* lsrc, int nrows, int nvalid) { rows_gstore_t<NPMAX, TB_RS>(gdst, lsrc, nrows, nvalid); }
 
@@ -1948,6 +2004,9 @@ __global__ __launch_bounds__(256, 2) void tconvffn_bwd_q_kernel(nbss_cfg c, Laye
                     p6_pack(hv, vm, ph);
                     p6_pack(dv, vm, pd);
                     p6_store(r, pd);
+                    // (lane-wise on purpose.  Round 6: with these stores knocked out the kernel runs 1 113 -> 995 us, but as whole rows through a per-wave
+                    //  staging strip — 16-byte pieces in address order, the form the forward kernel's saves and the da1 operand use — it was no faster:
+                    //  1 072 -> 1 089 us in the same call.  The cost is the operand's bytes, not the form of its stores.)
                     p6_gstore(op_h5 + gsv + (size_t)t * TS_CG, ph, tv, true);
                 }
         }
