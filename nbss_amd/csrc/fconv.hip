@@ -98,7 +98,9 @@ NBSS_DEV void ln_halfrow_inplace(T* row, const float* __restrict__ gamma, const 
 // MTF = frequency tiles the accumulators are sized for: 10 (F <= 160, the 8-kHz geometry) or 17 (F <= 272: 16 kHz, n_fft 512 -> 257 bins)
 // HH = dim_hidden (geom.h): 96 (12 channels per conv group, one 16-row output tile) or 192 (24 channels, two tiles)
 template <class T, int TT, int GPW, int MTF, int HH>
-__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 ? 4 : 2) : 1) void fconv_fwd_kernel(nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
+// (launch bounds: threads, waves per SIMD — four = two 8-wave workgroups per CU, at most 128 VGPRs; -DNBSS_FCONV_DMA: A/B flavour, rounds 4-5's prologue)
+__global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 ? 4 : 2) : 1) void fconv_fwd_kernel(
+                                                        nbss_cfg c, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                         const float* __restrict__ cb, const float* __restrict__ slope,
                                                         const T* __restrict__ Wp, const T* __restrict__ x, T* __restrict__ y, int flip) {
     constexpr int FG = HH / FC_G;                 // channels per group
@@ -120,12 +122,41 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
     const int lane = lane_id(), l15 = lane & 15, g4 = lane >> 4, w = wave_id();
 
     // ---- phase 1: stage x (raw) into LDS rows f+2, zero halo / tail rows -------------------
-#ifdef NBSS_FCONV_NO_DMA  // (A/B flavour)
-    constexpr bool DMA = false;
+#ifdef NBSS_FCONV_DMA
+    constexpr bool DMA = sizeof(T) == 2, REGX = false;
 #else
-    constexpr bool DMA = sizeof(T) == 2;
+    constexpr bool DMA = false, REGX = sizeof(T) == 2;
 #endif
-    if constexpr (DMA) {
+    // bf16 stream (round 6): the slab's rows come in through REGISTERS — every thread requests its 16-byte pieces up front (one round trip), copies
+    // them into the image, and KEEPS them: they are the residual of phase 4.  With the LDS-DMA prologue (no register stop) the image was normalised in
+    // place and the residual re-read from global memory — the kernel fetched 2.26 x the slab (PMC, round 5), on a kernel that runs at the HBM rate.
+    // (six rounds of the workgroup's threads = 3 072 of the 3 096 pieces of a 129-bin slab; the few pieces beyond them take the old path: copied in a
+    //  load -> store loop and re-read in phase 4 — registers for the largest slab the instance admits would be 8 - 13 rounds, over the 128-VGPR budget)
+    constexpr int NTHR = 64 * FC_G / GPW, NXR = REGX ? 6 : 1;
+    u32x4 xr[NXR];
+    if constexpr (REGX) {
+#pragma unroll
+        for (int k = 0; k < NXR; ++k) {
+            const int i = tid + k * NTHR, ic = i < F * VPR ? i : 0, f = ic / VPR, off = (ic % VPR) * VN, tt = off / HH;
+            if (i < F * VPR && t0 + tt < T_) xr[k] = *reinterpret_cast<const u32x4*>(x + (((size_t)b * F + f) * T_ + t0 + tt) * HH + (off - tt * HH));
+            else xr[k] = (u32x4){0u, 0u, 0u, 0u};  // (frames behind the end of the sequence: zero rows)
+        }
+        for (int i = tid; i < (FP - F) * VPR; i += nthr) {  // halo rows (f = -2, -1) and the rows behind the last frequency
+            const int k = i / VPR, rr = k < 2 ? k : F + k, off = (i % VPR) * VN, tt = off / HH;
+            vec_zero(u + (size_t)rr * ROW + tt * HHP + (off - tt * HH));
+        }
+#pragma unroll
+        for (int k = 0; k < NXR; ++k) {
+            const int i = tid + k * NTHR, f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
+            if (i < F * VPR) *reinterpret_cast<u32x4*>(u + (size_t)(f + 2) * ROW + tt * HHP + (off - tt * HH)) = xr[k];
+        }
+        for (int i = tid + NXR * NTHR; i < F * VPR; i += NTHR) {
+            const int f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
+            T* d = u + (size_t)(f + 2) * ROW + tt * HHP + (off - tt * HH);
+            if (t0 + tt < T_) vec_copy(d, x + (((size_t)b * F + f) * T_ + t0) * HH + off);
+            else vec_zero(d);
+        }
+    } else if constexpr (DMA) {
         // bf16 stream: the slab comes in as one burst of global -> LDS copies (16-byte pieces, no register stop; the copy loop below is a chain
         // of load -> store round trips, seven per thread).  Piece q: row q / CPR (= f TT + tt), 16-byte column q % CPR (the last one is padding).
         constexpr int CPR = HHP / 8, DPR = HH / 8;
@@ -238,7 +269,33 @@ __global__ __launch_bounds__(64 * FC_G / GPW, GPW == 1 ? (MTF <= 10 && HH == 96 
     lds_barrier();
 
     // ---- phase 4: residual add + coalesced store -------------------------------------------------
-    if constexpr (DMA) {  // (VN == 8) the residual rows of up to eight iterations are requested together: one round trip per batch instead of one per row
+    if constexpr (REGX) {
+#pragma unroll
+        for (int k = 0; k < NXR; ++k) {
+            const int i = tid + k * NTHR, f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
+            if (i >= F * VPR || t0 + tt >= T_) continue;
+            const size_t go = (((size_t)b * F + f) * T_ + t0) * HH + off;
+            float yv[8], o[8];
+            load8(u + (size_t)f * ROW + tt * HHP + (off - tt * HH), yv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] = bf2f((bf16_t)(xr[k][j] & 0xFFFF)) + yv[2 * j];
+                o[2 * j + 1] = bf2f((bf16_t)(xr[k][j] >> 16)) + yv[2 * j + 1];
+            }
+            store8(reinterpret_cast<bf16_t*>(y) + go, o);
+        }
+        for (int i = tid + NXR * NTHR; i < F * VPR; i += NTHR) {
+            const int f = i / VPR, off = (i % VPR) * VN, tt = off / HH;
+            if (t0 + tt >= T_) continue;
+            const size_t go = (((size_t)b * F + f) * T_ + t0) * HH + off;
+            float xv[8], yv[8], o[8];
+            load8(x + go, xv);
+            load8(u + (size_t)f * ROW + tt * HHP + (off - tt * HH), yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = xv[j] + yv[j];
+            store8(reinterpret_cast<bf16_t*>(y) + go, o);
+        }
+    } else if constexpr (DMA) {  // (VN == 8) the residual rows of up to eight iterations are requested together: one round trip per batch instead of one per row
         constexpr int NB4 = 8;
         for (int i0 = tid; i0 < F * VPR; i0 += NB4 * nthr) {
             u32x4 xr4[NB4];
