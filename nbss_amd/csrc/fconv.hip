@@ -15,6 +15,8 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "fold.h"
+#include "foldk.h"
 #include "geom.h"
 #include "side.h"
 #include <cstdlib>
@@ -801,15 +803,13 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
 #define FC_BWD_TT 1
 #endif
 
+#define TV_RSL_MAX 64  // (tconvffn_s.hip: TV_RSL, the most slices part16_slices_launch writes)
 // tconvffn_s.hip: fp32 slice sums of bf16 partial rows [nrows][p16] (fixed order; *nsl = slices written)
 int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl, hipStream_t st);
 // dW[o][i][tap] += the slices' sums of the [tap][group][i][12 outputs] rows, in slice order (one owner per element: bitwise repeatable)
+static_assert(FC_H == FK_H && FC_CG == FK_FCG && FC_G == FK_FG && FC_P16 == FK_FC_P16, "foldk.h");
 __global__ __launch_bounds__(256) void fconv_part_final_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ dW) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= FC_P16) return;
-    const float sum = fold_strided<16>(slices + e, (size_t)FC_P16, 0, nsl);
-    const int ol = e % FC_CG, i = (e / FC_CG) % FC_CG, g = (e / (FC_CG * FC_CG)) % FC_G, tap = e / (FC_CG * FC_CG * FC_G);
-    dW[((size_t)(g * FC_CG + ol) * FC_CG + i) * 5 + tap] += sum;
+    fk_fconv_final(slices, nsl, dW, (int)blockIdx.x);  // (the body lives in foldk.h: fold.hip's table kernel runs it too)
 }
 
 int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, int which, const void* x, const void* dy, void* dx,
@@ -850,11 +850,27 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     sg.n = fused ? 4 : 3;
     sg.off[3] = param_off(c, layer, which ? P_FC2_B : P_FC1_B); sg.cnt[3] = FC_H;  // (fused: the fp32 rows carry the conv bias sums behind the affine sums)
     const hipStream_t gs = side_fork(sd, st);  // the folds and the weight-gradient problem only produce parameter gradients (side.h)
+    FoldScope fs(gs, (char*)ws + ws_wgpart_offset(c), WGPART_BYTES, N);  // (fold.h: the sub-block's folds leave as one launch per stage)
     if ((e = affine_reduce_launch(part, nwg, sg, G, gs))) return e;
     if (fused) {  // the bf16 rows of the conv weight gradient: slice sums in fp32 (the idle wgrad partial region is the scratch), then one owner per element
         float* slices = (float*)((char*)ws + ws_wgpart_offset(c));
+        if (g_fold) {
+            int err;
+            void* sl = g_fold->alloc((size_t)TV_RSL_MAX * FC_P16 * sizeof(float), &err);
+            if (err || !sl) return err ? err : NBSS_EUNSUPPORTED;
+            slices = (float*)sl;
+        }
         int nsl = 0;
         if ((e = part16_slices_launch(part + (size_t)nwg * 4 * FC_H, nwg, slices, FC_P16, &nsl, gs))) return e;
+        if (g_fold) {
+            FoldItem it;
+            it.kind = FK_FCONV_FINAL;
+            it.gx = (FC_P16 + 255) / 256; it.gy = 1; it.nblk = it.gx;
+            it.u.p16.part16 = nullptr; it.u.p16.nrows = nwg; it.u.p16.p16 = FC_P16; it.u.p16.nsl = nsl; it.u.p16.slices = slices;
+            it.u.p16.G = G + param_off(c, layer, which ? P_FC2_W : P_FC1_W);
+            if ((e = g_fold->add(2, it))) return e;
+            return fs.end();
+        }
         NBSS_FOLD_LAUNCH(fconv_part_final_kernel, dim3((FC_P16 + 255) / 256), dim3(256), 0, gs, (const float*)slices, nsl, G + param_off(c, layer, which ? P_FC2_W : P_FC1_W));
         return NBSS_CHECK_LAUNCH();
     }
@@ -866,7 +882,8 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     a.A = dv; a.lda = FC_H; a.MA = FC_H; a.B = x; a.ldb = FC_H; a.NB = FC_H;
     a.stats = stats; a.gamma = P + param_off(c, layer, which ? P_FC2_LN_W : P_FC1_LN_W); a.beta = P + param_off(c, layer, which ? P_FC2_LN_B : P_FC1_LN_B);
     a.dW = G + param_off(c, layer, which ? P_FC2_W : P_FC1_W); a.dbias = G + param_off(c, layer, which ? P_FC2_B : P_FC1_B);
-    return wgrad_launch(a, c.dtype, gs);
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
+    return fs.end();
 }
 
 template <class T, int TT, int GPW, int MTF, int HH>

@@ -15,6 +15,8 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "fold.h"
+#include "foldk.h"
 #include "geom.h"
 #include "side.h"
 
@@ -518,21 +520,10 @@ __global__ void full_sq_prep_kernel(float* __restrict__ tmp) {
 }
 // dWs[o][i] += D[o][i] gamma[i] + dbs[o] beta[i];  dbs[o] += dbs;  dgamma[i] += sum_o Ws[o][i] D[o][i];  dbeta[i] += sum_o Ws[o][i] dbs[o]
 // (du = Ws^T ds_pre contracted with xhat resp. 1 over all tokens, reordered: the LayerNorm affine gradients cost no per-token work)
+static_assert(FL_H == FK_H && FL_SQ == FK_SQ, "foldk.h");
 __global__ void full_sq_finalize_kernel(const float* __restrict__ tmp, const float* __restrict__ Ws, const float* __restrict__ gamma, const float* __restrict__ beta,
                                         float* __restrict__ dWs, float* __restrict__ dbs, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int i = threadIdx.x;
-    if (i >= FL_H) return;
-    float dg = 0.f, db = 0.f;
-#pragma unroll
-    for (int o = 0; o < FL_SQ; ++o) {
-        const float D = tmp[o * FL_H + i], b = tmp[FL_SQ * FL_H + o], w = Ws[o * FL_H + i];
-        dWs[o * FL_H + i] += D * gamma[i] + b * beta[i];
-        dg += w * D;
-        db += w * b;
-    }
-    dgamma[i] += dg;
-    dbeta[i] += db;
-    if (i < FL_SQ) dbs[i] += tmp[FL_SQ * FL_H + i];
+    fk_full_sq_final(tmp, Ws, gamma, beta, dWs, dbs, dgamma, dbeta);  // (the body lives in foldk.h: fold.hip's table kernel runs it too)
 }
 
 // frames per slab: the largest of 8 / 4 / 2 that still gives (nearly) every CU a workgroup.  The LinearGroup passes cost the same per slab whatever its
@@ -620,6 +611,7 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     if (e) return e;
     // everything below only produces parameter gradients: gradient stream (side.h)
     const hipStream_t gs = side_fork(sd, st);
+    FoldScope fs(gs, (char*)ws + ws_wgpart_offset(c), WGPART_BYTES, N);  // (fold.h: the sub-block's seven fold launches leave as three, one per stage)
     NBSS_FOLD_LAUNCH(full_sq_prep_kernel, dim3(1), dim3(256), 0, gs, sqtmp);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     // squeeze bias gradient (fp32 sums of the kernel) -> tmp.dbs
@@ -651,6 +643,16 @@ int full_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.gamma = sqtmp + FL_SQ * FL_H + FL_SQ; a.beta = sqtmp + FL_SQ * FL_H + FL_SQ + FL_H;
     a.dW = sqtmp; a.dbias = nullptr;
     if ((e = wgrad_launch(a, c.dtype, gs))) return e;
+    if (g_fold) {  // third stage: reads the squeeze problem's second pass (stage 1) and the bias fold (stage 2)
+        FoldItem it;
+        it.kind = FK_FULL_SQ;
+        it.gx = 1; it.gy = 1; it.nblk = 1;
+        it.u.sq.tmp = sqtmp; it.u.sq.Ws = lp.p[P_SQ_W]; it.u.sq.gamma = lp.p[P_FULL_LN_W]; it.u.sq.beta = lp.p[P_FULL_LN_B];
+        it.u.sq.dWs = G + param_off(c, layer, P_SQ_W); it.u.sq.dbs = G + param_off(c, layer, P_SQ_B);
+        it.u.sq.dgamma = G + param_off(c, layer, P_FULL_LN_W); it.u.sq.dbeta = G + param_off(c, layer, P_FULL_LN_B);
+        if ((e = g_fold->add(3, it))) return e;
+        return fs.end();
+    }
     NBSS_FOLD_LAUNCH(full_sq_finalize_kernel, dim3(1), dim3(FL_H), 0, gs, (const float*)sqtmp, lp.p[P_SQ_W], lp.p[P_FULL_LN_W], lp.p[P_FULL_LN_B],
                 G + param_off(c, layer, P_SQ_W), G + param_off(c, layer, P_SQ_B), G + param_off(c, layer, P_FULL_LN_W), G + param_off(c, layer, P_FULL_LN_B));
     return NBSS_CHECK_LAUNCH();

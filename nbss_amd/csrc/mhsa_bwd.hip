@@ -16,6 +16,7 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "fold.h"
 #include "side.h"
 #include <cstdlib>
 
@@ -1063,6 +1064,7 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
 #endif
     int e;
     hipStream_t gs = st;  // parameter-gradient launches (side.h)
+    FoldScope fs(st, (char*)ws + ws_wgpart_offset(c), WGPART_BYTES, N);  // (fold.h: the sub-block's folds leave as one launch per stage, on the gradient stream)
     {
     ProfScope ps(PK_MHSA_B, st);  // ONE profiler interval per nbss_mhsa_bwd call: data-gradient kernel (+ fused tail / in_proj wgrad kernel)
     e = c.dtype != NBSS_BF16 ? mhsa_bwd_t<float, false, false>(c, P, part, packed, layer, x, dy, osave, dx, stats, dqkv, st)
@@ -1093,11 +1095,12 @@ int mhsa_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packe
     a.stats = nullptr; a.gamma = nullptr; a.beta = nullptr;
     a.dW = G + param_off(c, layer, P_OUTP_W); a.dbias = G + param_off(c, layer, P_OUTP_B);
     if ((e = wgrad_launch(a, c.dtype, gs))) return e;
-    if (xt) return NBSS_OK;
+    if (xt) return fs.end();
     // in_proj: dWin[3H][H] = dqkv^T LN(x) ; dbin = colsum(dqkv)
     a.A = dqkv; a.lda = 3 * MB_H; a.MA = 3 * MB_H; a.B = x; a.ldb = MB_H; a.NB = MB_H;
     if (c.dtype == NBSS_BF16) { a.a_gw = MB_DH; a.a_gs = (int)(N * MB_DH); }  // group-major dqkv
     a.stats = stats; a.gamma = lp.p[P_MH_LN_W]; a.beta = lp.p[P_MH_LN_B];
     a.dW = G + param_off(c, layer, P_INP_W); a.dbias = G + param_off(c, layer, P_INP_B);
-    return wgrad_launch(a, c.dtype, gs);
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
+    return fs.end();
 }

@@ -20,6 +20,8 @@
 #include "prof.h"
 #include "blocks.h"
 #include "wgrad.h"
+#include "fold.h"
+#include "foldk.h"
 #include "side.h"
 
 #define TW_KC 64
@@ -259,47 +261,18 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
 // gradients.  (256-thread blocks: see wgrad_reduce_kernel.)
 // W = the fp32 master weight [MA][96].  Tile tl = nt * MTA + mt; block (tl, r), lane: row 16 mt + 4 (lane >> 4) + r, column 16 nt + (lane & 15).
 #define TW_RSL 4
+static_assert(TW_RSL == FK_RSL && TW_H == FK_H, "foldk.h");
+// (the bodies live in foldk.h: fold.hip's table kernel runs them too)
 __global__ __launch_bounds__(64 * TW_RSL) void tailw_finalize_kernel(float* __restrict__ part, int xb, int MTA, const float* __restrict__ W,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
                                                                      float* __restrict__ dbias) {
     NBSS_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);  // [slice][64] D | [slice][64] bias sums (per thread: its row's)
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, r = blockIdx.x & 3, l15 = lane & 15, g4 = lane >> 4;
-    const int nsl = xb < TW_RSL ? xb : TW_RSL;
-    const int ntot = gridDim.x >> 2, tl = blockIdx.x >> 2, nt = tl / MTA, mt = tl % MTA;
-    const int x0 = sl < nsl ? (int)((long)xb * sl / nsl) : 0, x1 = sl < nsl ? (int)((long)xb * (sl + 1) / nsl) : 0;
-    const float* pt = part + (size_t)tl * 256 + r * 64 + lane;
-    const float* pb = part + (size_t)xb * ntot * 256 + (size_t)mt * 16 + 4 * g4 + r;  // bias sums of tile (nt = 0, mt): rows 4 g4 + r
-    const size_t xs = (size_t)ntot * 256, bs = (size_t)ntot * 16;
-    red[sl * 64 + lane] = fold_strided<16>(pt, xs, x0, x1);
-    red[(TW_RSL + sl) * 64 + lane] = fold_strided<16>(pb, bs, x0, x1);
-    __syncthreads();  // (also: every slice has read workgroup 0's values of this block, whose slot receives the column sums below)
-    if (sl) return;
-    const float D = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
-    const float bsum = (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]);
-    const int o = mt * 16 + 4 * g4 + r, i = nt * 16 + l15;
-    const float w = W[(size_t)o * TW_H + i];
-    dW[(size_t)o * TW_H + i] += D * gamma[i] + bsum * beta[i];
-    if (nt == 0 && l15 == 0) dbias[o] += bsum;
-    // column sums over the block's four rows (the lane groups)
-    float tg = w * D, tb = w * bsum;
-    tg += __shfl_xor(tg, 16); tg += __shfl_xor(tg, 32);
-    tb += __shfl_xor(tb, 16); tb += __shfl_xor(tb, 32);
-    if (g4 == 0) {
-        part[(size_t)tl * 256 + r * 64 + l15] = tg;
-        part[(size_t)tl * 256 + r * 64 + 16 + l15] = tb;
-    }
+    fk_tailw_finalize(part, xb, MTA, (int)(gridDim.x >> 2), W, gamma, beta, dW, dbias, (int)blockIdx.x, reinterpret_cast<float*>(smem));
 }
 // dgamma[i] += the column sums tailw_finalize_kernel left, over the MTA tiles of column tile i / 16 and their four blocks in (tile, r) order; dbeta
 // likewise (threads 96 ..)
 __global__ __launch_bounds__(192) void tailw_affine_kernel(const float* __restrict__ part, int MTA, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int k = threadIdx.x / TW_H, i = threadIdx.x % TW_H, nt = i >> 4, j = i & 15;
-    float s = 0.f;
-    for (int mt = 0; mt < MTA; ++mt) {
-        const float* p = part + (size_t)(nt * MTA + mt) * 256 + 16 * k + j;
-        s += (p[0] + p[64]) + (p[128] + p[192]);
-    }
-    (k ? dbeta : dgamma)[i] += s;
+    fk_tailw_affine(part, MTA, dgamma, dbeta);
 }
 
 template <int MA, int NBUF, int NTW>
@@ -323,6 +296,18 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
     const int grid = nchunks < 256 ? nchunks : 256;
     const int ntot = (MA / 16) * (TW_H / 16);
     if ((size_t)grid * ntot * 272 * sizeof(float) > wgpart_bytes) return NBSS_EUNSUPPORTED;
+    bool batched = false;
+    if (g_fold) {  // inside a FoldScope (fold.h): the partial tiles come from the scope's pool, the two second passes join its first and second stage
+        int err;
+        void* p = g_fold->alloc((size_t)grid * ntot * 272 * sizeof(float), &err);
+        if (err) return err;
+        if (p) {
+            wgpart = (float*)p;
+            batched = true;
+        } else if ((err = g_fold->flush())) {
+            return err;
+        }
+    }
     t.part = wgpart;
     int e = MA == 192 ? tailw_go<192, 2, 4>(t, grid, st)
 #ifdef NBSS_TW288_NBUF1
@@ -334,6 +319,18 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
     if (e) return e;
     const hipStream_t gs = side_fork(sd, st);
     if (gs_out) *gs_out = gs;
+    if (batched) {
+        g_fold->st = gs;
+        FoldItem it;
+        it.kind = FK_TAILW_FIN;
+        it.gx = 4 * ntot; it.gy = 1; it.nblk = it.gx;
+        it.u.tw.part = wgpart; it.u.tw.xb = grid; it.u.tw.MTA = MA / 16; it.u.tw.ntot = ntot; it.u.tw.W = W; it.u.tw.gamma = t.gamma; it.u.tw.beta = t.beta;
+        it.u.tw.dW = dW; it.u.tw.dbias = dbias; it.u.tw.dgamma = dgamma; it.u.tw.dbeta = dbeta;
+        if ((e = g_fold->add(1, it))) return e;
+        it.kind = FK_TAILW_AFF;
+        it.gx = 1; it.nblk = 1;
+        return g_fold->add(2, it);
+    }
     NBSS_FOLD_LAUNCH(tailw_finalize_kernel, dim3(4 * ntot), dim3(64 * TW_RSL), 2 * TW_RSL * 64 * sizeof(float), gs, wgpart, grid, MA / 16, W, t.gamma, t.beta, dW, dbias);
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     NBSS_FOLD_LAUNCH(tailw_affine_kernel, dim3(1), dim3(2 * TW_H), 0, gs, (const float*)wgpart, MA / 16, dgamma, dbeta);

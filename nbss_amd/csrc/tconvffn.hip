@@ -15,6 +15,7 @@
 #include "prof.h"
 #include "wgrad.h"
 #include "blocks.h"
+#include "fold.h"
 #include "side.h"
 #include <cstdlib>
 
@@ -1149,6 +1150,7 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     const bool q = tcf_use_q();
     int e;
     hipStream_t gs = st;  // parameter-gradient launches (side.h): everything behind the tail kernel
+    FoldScope fs(st, wgpart, WGPART_BYTES, N);  // (fold.h: the sub-block's seven fold launches leave as two, one per stage, on the gradient stream)
     {
         ProfScope ps(PK_TCF_B, st);  // both kernels of the sub-block: ONE profiler interval per nbss_tconvffn_bwd call
         if ((e = q ? tconvffn_bwd_q_launch(c, lp, part, packed, layer, dy, tsave, op_h5, op_da1, st) : tconvffn_bwd_v_launch(c, lp, part, packed, layer, dy, tsave, op_da1, st)))
@@ -1166,7 +1168,7 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     const long long woffs[4] = {param_off(c, layer, convW[0]), param_off(c, layer, convW[1]), param_off(c, layer, convW[2]), param_off(c, layer, P_TF_W2)};
     // (the slice sums of the fold live in the wgrad partial-tile region, idle between this sub-block's wgrad launches: 64 x 59 904 floats = 15.3 MB)
     if ((e = tconvffn_v_reduce16(c, part + (size_t)c.B * c.F * (5 * TF_FFN + (q ? 0 : TF_H)), wgpart, G, woffs, !q, gs))) return e;
-    if (!q) return NBSS_OK;
+    if (!q) return fs.end();
     // W2: dW2[H][FFN] = dy^T h5 ; db2 = colsum(dy)
     WgradArgs a;
     a.part = wgpart;
@@ -1176,7 +1178,8 @@ static int tconvffn_bwd_saved(const nbss_cfg& c, const float* P, float* G, const
     a.A = dy; a.lda = TF_H; a.MA = TF_H; a.B = op_h5; a.ldb = TF_FFN; a.NB = TF_FFN; a.groups = 1; a.taps = 1;
     a.b_gw = TF_CG; a.b_gs = (int)(N * TF_CG);
     a.dW = G + param_off(c, layer, P_TF_W2); a.dbias = G + param_off(c, layer, P_TF_B2);
-    return wgrad_launch(a, c.dtype, gs);
+    if ((e = wgrad_launch(a, c.dtype, gs))) return e;
+    return fs.end();
 }
 
 int tconvffn_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* packed, int layer, const void* x, const void* dy, const void* tsave,

@@ -18,6 +18,8 @@
 #include "launch.h"
 #include "layout.h"
 #include "prof.h"
+#include "fold.h"
+#include "foldk.h"
 
 #define TS_H 96
 #define TS_FFN 192
@@ -1307,44 +1309,14 @@ NBSS_DEV void tv_flush(bf16_t* __restrict__ w16, float* __restrict__ brow, int g
 // four rows in flight per thread) into slices[y][e] (fp32); (2) one thread per element sums the slices and adds the result to the parameter's own
 // [out][in][tap] order in G.  (The first version — 4-byte loads, two rows in flight, 1.3 M atomicAdds — took 130 us for 0.34 GB.)
 #define TV_RSL 64
+static_assert(TS_H == FK_H && TS_FFN == FK_FFN && TS_CG == FK_TCG && TV_CONVW == FK_TCONVW, "foldk.h");
+// (the bodies live in foldk.h: fold.hip's table kernel runs them too)
 __global__ __launch_bounds__(256) void tconv_part_reduce1_kernel(const bf16_t* __restrict__ part16, int nrows, float* __restrict__ slices, int P16) {
-    const int e8 = blockIdx.x * 256 + threadIdx.x;  // group of 8 elements
-    if (e8 >= P16 / 8) return;
-    const int r0 = (int)((long)nrows * blockIdx.y / gridDim.y), r1 = (int)((long)nrows * (blockIdx.y + 1) / gridDim.y);
-    const u32x4* p = reinterpret_cast<const u32x4*>(part16) + e8;
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    auto add = [&](const u32x4& u) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[2 * k] += __builtin_bit_cast(float, u[k] << 16);
-            acc[2 * k + 1] += __builtin_bit_cast(float, u[k] & 0xFFFF0000u);
-        }
-    };
-    int r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        const u32x4 a = p[(size_t)r * (P16 / 8)], b = p[(size_t)(r + 1) * (P16 / 8)], c = p[(size_t)(r + 2) * (P16 / 8)], d = p[(size_t)(r + 3) * (P16 / 8)];
-        add(a); add(b); add(c); add(d);
-    }
-    for (; r < r1; ++r) add(p[(size_t)r * (P16 / 8)]);
-    float* out = slices + (size_t)blockIdx.y * P16 + (size_t)e8 * 8;
-    store4(out, acc[0], acc[1], acc[2], acc[3]);
-    store4(out + 4, acc[4], acc[5], acc[6], acc[7]);
+    fk_p16_slices(part16, nrows, slices, P16, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 __global__ __launch_bounds__(256) void tconv_part_reduce2_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ G, long long off0, long long off1, long long off2,
                                                                  long long off3, int P16) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= P16) return;
-    const float sum = fold_strided<16>(slices + e, (size_t)P16, 0, nsl);
-    if (e >= 3 * TV_CONVW) {  // dW2 partial: [FFN channel][H output] -> the parameter's [H][FFN]
-        const int q = e - 3 * TV_CONVW, ch = q / TS_H, o = q - ch * TS_H;
-        G[off3 + (size_t)o * TS_FFN + ch] += sum;
-        return;
-    }
-    const int k = e / TV_CONVW, q = e - k * TV_CONVW, grp = q / (3 * TS_CG * TS_CG), tap = (q / (TS_CG * TS_CG)) % 3, i = (q / TS_CG) % TS_CG, o = grp * TS_CG + q % TS_CG;
-    float* g = G + (k == 0 ? off0 : k == 1 ? off1 : off2);
-    g[((size_t)o * TS_CG + i) * 3 + tap] += sum;  // (stream order: nothing else writes these gradients between the two launches)
+    fk_tconv_final(slices, nsl, G, off0, off1, off2, off3, P16, (int)blockIdx.x);
 }
 
 __global__ __launch_bounds__(512) void tconvffn_bwd_v_kernel(nbss_cfg c, LayerPtrs lp, TvW W, TvIn sv, const bf16_t* __restrict__ dy, float* __restrict__ part,
@@ -2235,11 +2207,37 @@ size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV
 int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl_out, hipStream_t st) {
     const int nsl = nrows < TV_RSL ? nrows : TV_RSL;
     *nsl_out = nsl;
+    if (g_fold) {  // inside a FoldScope (fold.h; `slices` is the caller's allocation from the scope's pool): first stage
+        g_fold->st = st;
+        FoldItem it;
+        it.kind = FK_P16_SLICES;
+        it.gx = (p16 / 8 + 255) / 256; it.gy = nsl; it.nblk = it.gx * it.gy;
+        it.u.p16.part16 = part16; it.u.p16.nrows = nrows; it.u.p16.p16 = p16; it.u.p16.nsl = nsl; it.u.p16.slices = slices; it.u.p16.G = nullptr;
+        return g_fold->add(1, it);
+    }
     NBSS_FOLD_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
     return NBSS_CHECK_LAUNCH();
 }
 int tconvffn_v_reduce16(const nbss_cfg& c, const void* part16, float* slices, float* G, const long long* offs, bool with_w2, hipStream_t st) {
     const int nrows = c.B * c.F, nsl = nrows < TV_RSL ? nrows : TV_RSL, p16 = with_w2 ? TV_P16 : TQ_P16;
+    if (g_fold) {  // inside a FoldScope (fold.h): the slice sums come from the scope's pool, the two passes join its first and second stage
+        int err;
+        void* sl = g_fold->alloc((size_t)nsl * p16 * sizeof(float), &err);
+        if (err) return err;
+        if (sl) {
+            g_fold->st = st;
+            FoldItem it;
+            it.kind = FK_P16_SLICES;
+            it.gx = (p16 / 8 + 255) / 256; it.gy = nsl; it.nblk = it.gx * it.gy;
+            it.u.p16.part16 = part16; it.u.p16.nrows = nrows; it.u.p16.p16 = p16; it.u.p16.nsl = nsl; it.u.p16.slices = (float*)sl; it.u.p16.G = G;
+            for (int k = 0; k < 4; ++k) it.u.p16.off[k] = offs[k];
+            if ((err = g_fold->add(1, it))) return err;
+            it.kind = FK_TCONV_FINAL;
+            it.gx = (p16 + 255) / 256; it.gy = 1; it.nblk = it.gx;
+            return g_fold->add(2, it);
+        }
+        if ((err = g_fold->flush())) return err;
+    }
     NBSS_FOLD_LAUNCH(tconv_part_reduce1_kernel, dim3((p16 / 8 + 255) / 256, nsl), dim3(256), 0, st, (const bf16_t*)part16, nrows, slices, p16);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;

@@ -1,6 +1,8 @@
 // util.hip — small stream-ordered helpers used by the host-side sequencing code.
 #include "launch.h"
 #include "blocks.h"
+#include "fold.h"
+#include "foldk.h"
 #include <string.h>
 #include <cstdlib>
 
@@ -27,41 +29,13 @@ int memset_async_impl(void* p, size_t bytes, hipStream_t st) {
 // slices' sums in slice order and adds the result to G with a plain read-modify-write (one owner per element; gradient launches of one parameter
 // are stream-ordered).  The very first version walked all ~1000 workgroups in 2-5 blocks and cost 49 us per call (2 ms per training step).
 #define AFF_SLICES 64
-// first row of slice y: nwg y / nsl without a division (nsl is AFF_SLICES, or nwg itself when there are fewer rows than slices)
-NBSS_DEV int aff_row0(int nwg, int nsl, int y) { return nsl == AFF_SLICES ? (int)(((unsigned)nwg * (unsigned)y) >> 6) : y; }
+static_assert(AFF_SLICES == FK_AFF_SLICES, "foldk.h");
+// (the bodies live in foldk.h: fold.hip's table kernel runs them too)
 __global__ void affine_slices_kernel(float* __restrict__ part, int nwg, int naff) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= naff) return;
-    const int w0 = aff_row0(nwg, gridDim.y, blockIdx.y), w1 = aff_row0(nwg, gridDim.y, blockIdx.y + 1);
-    const float s = fold_strided<16>(part + e, (size_t)naff, w0, w1);
-    part[(size_t)w0 * naff + e] = s;
+    fk_affine_slices(part, nwg, naff, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)blockIdx.y, (int)gridDim.y);
 }
 __global__ void affine_final_kernel(const float* __restrict__ part, int nwg, int naff, int nsl, AffSegs segs, float* __restrict__ G) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= naff) return;
-    float s16[16], v16[16];  // sixteen loads in flight; the order of the adds is fixed
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s16[k] = 0.f;
-    for (int y = 0; y < nsl; y += 16) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v16[k] = y + k < nsl ? part[(size_t)aff_row0(nwg, nsl, y + k) * naff + e] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s16[k] += v16[k];
-    }
-#pragma unroll
-    for (int h = 8; h >= 1; h >>= 1) {
-#pragma unroll
-        for (int k = 0; k < h; ++k) s16[k] += s16[k + h];
-    }
-    const float s = s16[0];
-    int r = e;
-    for (int i = 0; i < segs.n; ++i) {
-        if (r < segs.cnt[i]) {
-            G[segs.off[i] + r] += s;
-            return;
-        }
-        r -= segs.cnt[i];
-    }
+    fk_affine_final(part, nwg, naff, nsl, segs, G, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // (Tried, round 5: both passes in ONE launch — the block of an element range that draws the last ticket of a counter adds the slice sums.  The
@@ -73,6 +47,18 @@ int affine_reduce_launch(const float* part, int nwg, const AffSegs& segs, float*
     for (int i = 0; i < segs.n; ++i) naff += segs.cnt[i];
     const int nsl = nwg < AFF_SLICES ? nwg : AFF_SLICES;
     if (nsl < 1) return NBSS_OK;
+    if (g_fold) {  // inside a FoldScope (fold.h): the two passes join the scope's first and second stage
+        g_fold->st = st;
+        FoldItem it;
+        it.kind = FK_AFF_SLICES;
+        it.gx = (naff + 255) / 256; it.gy = nsl; it.nblk = it.gx * it.gy;
+        it.u.af.part = const_cast<float*>(part); it.u.af.nwg = nwg; it.u.af.naff = naff; it.u.af.nsl = nsl; it.u.af.segs = segs; it.u.af.G = G;
+        int e = g_fold->add(1, it);
+        if (e) return e;
+        it.kind = FK_AFF_FINAL;
+        it.gy = 1; it.nblk = it.gx;
+        return g_fold->add(2, it);
+    }
     NBSS_FOLD_LAUNCH(affine_slices_kernel, dim3((naff + 127) / 128, nsl), dim3(128), 0, st, const_cast<float*>(part), nwg, naff);
     int e = NBSS_CHECK_LAUNCH();
     if (e) return e;

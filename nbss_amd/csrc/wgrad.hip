@@ -24,6 +24,8 @@
 #include "launch.h"
 #include "layout.h"
 #include "wgrad.h"
+#include "fold.h"
+#include "foldk.h"
 #include <cstdlib>
 #include "prof.h"
 
@@ -551,54 +553,38 @@ __global__ __launch_bounds__(WG_THREADS, NS > 14 ? 1 : 2) void wgrad_tr3_kernel(
 // the gradient stream beside the main stream's one-workgroup-per-CU kernels, and a 1024-thread block (one block per whole tile, the first version of
 // this fold) waits for a CU to drain (measured: step 663.9 -> 651.4 utt/s).  (Round 4's fold: 8 blocks per tile, each ending in an atomicAdd per element.)
 #define WG_RSL 4
+static_assert(WG_RSL == FK_RSL, "foldk.h");
+// (the body lives in foldk.h: fold.hip's table kernel runs it too)
 __global__ __launch_bounds__(64 * WG_RSL) void wgrad_reduce_kernel(WgradArgs a, int xb, int nt_major) {
     NBSS_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);  // [slice][64] sums | [slice][16] bias sums
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6, r = blockIdx.x & 3, l15 = lane & 15, g4 = lane >> 4;
-    const int nsl = xb < WG_RSL ? xb : WG_RSL;  // slices that have x-blocks
-    const int mg = a.MA / a.groups, ng = a.NB / a.groups;
-    const int mv = a.mvalid ? a.mvalid : mg, nv = a.nvalid ? a.nvalid : ng;
-    const int mtiles = cdiv(mg, 16), nexp = a.taps * ng, ntiles = cdiv(nexp, 16);
-    const int tpg = mtiles * ntiles;
-    const bool per_group = gridDim.z > 1;
-    const int ntot = (per_group ? 1 : a.groups) * tpg;
-    const int tl = blockIdx.x >> 2, y = blockIdx.z;
-    const int x0 = sl < nsl ? (int)((long)xb * sl / nsl) : 0, x1 = sl < nsl ? (int)((long)xb * (sl + 1) / nsl) : 0;
-    const float* pt = a.part + ((size_t)y * xb * ntot + tl) * 256 + r * 64 + lane;
-    const size_t xs = (size_t)ntot * 256;
-    red[sl * 64 + lane] = fold_strided<16>(pt, xs, x0, x1);
-    int g, mt, nt;
-    if (nt_major) {  // wgrad_tr3_kernel: tl = nt * nfirst + g * mtiles + mt
-        const int nfirst = ntot / ntiles, gm = tl % nfirst;
-        nt = tl / nfirst; g = gm / mtiles; mt = gm % mtiles;
-    } else {
-        const int rem = tl % tpg;
-        g = tl / tpg; mt = rem / ntiles; nt = rem % ntiles;
-    }
-    if (per_group) g += y;
-    const bool bias = a.dbias && nt == 0 && r == 0;  // the tile's 16 bias sums: the r = 0 block
-    if (bias && lane < 16) {
-        const float* pbias = a.part + (size_t)gridDim.z * xb * ntot * 256 + ((size_t)y * xb * ntot + tl) * 16 + lane;
-        red[WG_RSL * 64 + sl * 16 + lane] = fold_strided<16>(pbias, (size_t)ntot * 16, x0, x1);
-    }
-    __syncthreads();
-    if (sl) return;
-    const float sum = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
-    const int q = nt * 16 + l15;
-    if (q < nexp) {
-        const int tap = q / ng, i = q % ng, m = mt * 16 + 4 * g4 + r;
-        if (m < mv && i < nv) a.dW[((size_t)(g * mv + m) * nv + i) * a.taps + tap] += sum;
-    }
-    if (bias && lane < 16) {
-        const float b = (red[WG_RSL * 64 + lane] + red[WG_RSL * 64 + 16 + lane]) + (red[WG_RSL * 64 + 32 + lane] + red[WG_RSL * 64 + 48 + lane]);
-        const int m = mt * 16 + lane;
-        if (m < mv) a.dbias[(size_t)g * mv + m] += b;
-    }
+    fk_wgrad_reduce(a, xb, nt_major, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.z, reinterpret_cast<float*>(smem));
 }
 
-static int wgrad_reduce_go(const WgradArgs& a, int ntot, int xb, int ybl, int nt_major, hipStream_t st) {
+// batched: the partial tiles came from the enclosing FoldScope's pool (fold_part) — the pass joins the scope's first stage
+static int wgrad_reduce_go(const WgradArgs& a, int ntot, int xb, int ybl, int nt_major, hipStream_t st, bool batched = false) {
+    if (batched && g_fold) {
+        g_fold->st = st;
+        FoldItem it;
+        it.kind = FK_WGRAD_REDUCE;
+        it.gx = 4 * ntot; it.gy = ybl; it.nblk = it.gx * it.gy;
+        it.u.wr.a = a; it.u.wr.xb = xb; it.u.wr.nt_major = nt_major;
+        return g_fold->add(1, it);
+    }
     NBSS_FOLD_LAUNCH(wgrad_reduce_kernel, dim3(4 * ntot, 1, ybl), dim3(64 * WG_RSL), WG_RSL * 80 * sizeof(float), st, a, xb, nt_major);
     return NBSS_CHECK_LAUNCH();
+}
+// Inside a FoldScope (fold.h) the partial tiles of a launch come from the scope's pool — they have to outlive the launches that follow, whose partial
+// tiles would otherwise land on the same bytes — and the second pass is batched.  A request the pool cannot hold goes out alone, after everything pending.
+static int fold_part(WgradArgs& a, size_t need, bool* batched) {
+    *batched = false;
+    if (!g_fold || !a.part) return NBSS_OK;
+    int err;
+    void* p = g_fold->alloc(need, &err);
+    if (err) return err;
+    if (!p) return g_fold->flush();
+    a.part = (float*)p;
+    *batched = true;
+    return NBSS_OK;
 }
 
 // second pass alone, for kernels that write partial tiles in wgrad_tr3_kernel's layout themselves (wgrad_g.hip)
@@ -646,10 +632,13 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
         if (nvec <= W3_MAXV * WG_THREADS && lds3 <= 158 * 1024 && (size_t)xb * ntot3 * 272 * sizeof(float) <= WGPART_BYTES) {
             ProfScope ps(PK_WGRAD, st);
             int e3;
+            WgradArgs a27 = a;
+            bool batched;
+            if ((e3 = fold_part(a27, (size_t)xb * ntot3 * 272 * sizeof(float), &batched))) return e3;
             if ((e3 = NBSS_SET_MAX_LDS((wgrad_tr3_kernel<32, 27>), lds3))) return e3;
-            NBSS_LAUNCH((wgrad_tr3_kernel<32, 27>), dim3(xb, 1), dim3(WG_THREADS), lds3, st, a);
+            NBSS_LAUNCH((wgrad_tr3_kernel<32, 27>), dim3(xb, 1), dim3(WG_THREADS), lds3, st, a27);
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
-            return wgrad_reduce_go(a, ntot3, xb, 1, 1, st);
+            return wgrad_reduce_go(a27, ntot3, xb, 1, 1, st, batched);
         }
     }
     if (nz == 1 && sizeof(T) == 2 && ncA % 8 == 0 && ncB % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0) {
@@ -678,6 +667,8 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
             WgradArgs a3 = a;
             if ((size_t)ybl * xb * ntot3 * 272 * sizeof(float) > WGPART_BYTES) a3.part = nullptr;
             int e3;
+            bool batched;
+            if ((e3 = fold_part(a3, (size_t)ybl * xb * ntot3 * 272 * sizeof(float), &batched))) return e3;
             const int need = cdiv(ntot3, WG_WAVES);  // tile slots per wave
 #define W3_GO(KC, NS)                                                                             \
     do {                                                                                          \
@@ -695,7 +686,7 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
 #undef W3_GO
             if ((e3 = NBSS_CHECK_LAUNCH())) return e3;
             if (a3.part && !WG_PROBE_HOST(a3, 1)) {
-                return wgrad_reduce_go(a3, ntot3, xb, ybl, 1, st);
+                return wgrad_reduce_go(a3, ntot3, xb, ybl, 1, st, batched);
             }
             return NBSS_OK;
         }
@@ -718,6 +709,8 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
     ak.part = nullptr;
 #endif
     if (nz > 1 || (size_t)ybl * xbl * ntot_k * 272 * sizeof(float) > WGPART_BYTES) ak.part = nullptr;  // (column-tile ranges / huge grids: atomic flush)
+    bool batched;
+    if ((e = fold_part(ak, (size_t)ybl * xbl * ntot_k * 272 * sizeof(float), &batched))) return e;
 #define WK_GO(CW, TPW)                                                             \
     do {                                                                           \
         if ((e = NBSS_SET_MAX_LDS((wgrad_kernel<T, CW, TPW>), lds))) return e;     \
@@ -730,7 +723,7 @@ static int wgrad_launch_t(const WgradArgs& a_in, hipStream_t st) {
 #undef WK_GO
     if ((e = NBSS_CHECK_LAUNCH())) return e;
     if (ak.part) {
-        return wgrad_reduce_go(ak, ntot_k, xbl, ybl, 0, st);
+        return wgrad_reduce_go(ak, ntot_k, xbl, ybl, 0, st, batched);
     }
     return NBSS_OK;
 }
