@@ -205,7 +205,11 @@ NBSS_HD int64_t pack_total(const nbss_cfg& c) {
 // wgrad partial tiles: up to 512 workgroups x 112 tiles x (256 accumulators + 16 bias sums) floats
 #define WGPART_BYTES ((size_t)512 * 112 * 272 * sizeof(float))
 // backward workspace (caller-provided): per-token LN statistics + the widest set of wgrad operands
-NBSS_HD size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
+#ifndef NBSS_WS_PAD
+#define NBSS_WS_PAD 0  // (A/B flavour: extra bytes behind every aligned region.  At batch 32 all regions start at multiples of 2 KB; 1 280 or 4 352 bytes of padding
+                       //  changed nothing — 727 / 728 / 727 utt/s in one call: the batch-31 / 32 / 33 steps of 738 / 730 / 718 are round counts, not address aliasing)
+#endif
+NBSS_HD size_t ws_align(size_t b) { return ((b + 255) & ~(size_t)255) + NBSS_WS_PAD; }
 // sequence lengths: backward keeps a whole sequence per workgroup (LDS), forward has chunked variants beyond that
 #define NBSS_T_TRAIN_MAX 256
 // frequencies: the cross-band kernels keep the whole F axis of a slab on chip: 17 tiles of 16 (n_fft 512 -> F = 257; fp32 backward: F <= 160)
