@@ -57,7 +57,9 @@ struct TailArgs {
 // affine sums on the other — have disjoint live ranges; as one loop with `if (w < 4)` inside, both sets stayed live and 65-146 VGPRs spilled.
 // NTW = tail waves: 4 (one 16-token tile of the chunk each, 4 accumulator waves) or 2 (two tiles each, 6 accumulator waves: in_proj's
 // 108 tiles are 18 per wave then instead of 27, which did not fit the register file)
-template <int MA, int NBUF, int NTW>
+// PD = chunks requested ahead (register sets of the staging): 1; 2 was built for W1 (223 + 24 VGPRs, 6 of them spilled) and measured SLOWER in round 6,
+// 281 -> 345 us per launch: the set that rotates into the stash set has to have arrived right behind the barrier, one more wait in the chunk's critical path
+template <int MA, int NBUF, int NTW, int PD>
 __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     constexpr int LDA = MA + 16;                    // image row strides == 16 (mod 32) elements: wgrad.hip tr_ld()
     constexpr int LDX = 112;                        // 96 + 16
@@ -81,45 +83,48 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
 
     const int nchunks = cdiv(a.Ntok, TW_KC);
     // staging: slot u < UA is a da piece for every thread, the rest x pieces (a few lanes of the last slot of each kind idle)
-    u32x4 preA[UA], preX[UX];
-    float pmu[UX], prs[UX];
+    struct Pre {
+        u32x4 A[UA], X[UX];
+        float mu[UX], rs[UX];
+    };
+    Pre ps0, ps1;  // (ps1: PD == 2 only)
     auto phys = [&](int ch) -> int { return a.flip ? nchunks - 1 - ch : ch; };  // logical -> token chunk
-    auto prefetch = [&](int ch) {
+    auto prefetch = [&](Pre& q, int ch) {
         const long n0 = (long)phys(ch) * TW_KC;
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             const int v = tid + u * TW_THREADS, r = v / PA, col = (v % PA) * 8;
-            preA[u] = (u32x4){0, 0, 0, 0};
-            if (v < NVA && n0 + r < a.Ntok) preA[u] = *reinterpret_cast<const u32x4*>(a.A + ((size_t)(col / 24) * a.Ntok + n0 + r) * 24 + col % 24);
+            q.A[u] = (u32x4){0, 0, 0, 0};
+            if (v < NVA && n0 + r < a.Ntok) q.A[u] = *reinterpret_cast<const u32x4*>(a.A + ((size_t)(col / 24) * a.Ntok + n0 + r) * 24 + col % 24);
         }
 #pragma unroll
         for (int u = 0; u < UX; ++u) {
             const int v = tid + u * TW_THREADS, r = v / (TW_H / 8), col = (v % (TW_H / 8)) * 8;
-            preX[u] = (u32x4){0, 0, 0, 0};
-            pmu[u] = 0.f; prs[u] = 0.f;
+            q.X[u] = (u32x4){0, 0, 0, 0};
+            q.mu[u] = 0.f; q.rs[u] = 0.f;
             if (v < NVX && n0 + r < a.Ntok) {
-                preX[u] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(n0 + r) * TW_H + col);
-                pmu[u] = a.stats[2 * (n0 + r)];
-                prs[u] = a.stats[2 * (n0 + r) + 1];
+                q.X[u] = *reinterpret_cast<const u32x4*>(a.x + (size_t)(n0 + r) * TW_H + col);
+                q.mu[u] = a.stats[2 * (n0 + r)];
+                q.rs[u] = a.stats[2 * (n0 + r) + 1];
             }
         }
     };
-    auto stash = [&](bf16_t* buf) {
+    auto stash = [&](const Pre& q, bf16_t* buf) {
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             const int v = tid + u * TW_THREADS, r = v / PA, col = (v % PA) * 8;
-            if (v < NVA) *reinterpret_cast<u32x4*>(buf + r * LDA + col) = preA[u];
+            if (v < NVA) *reinterpret_cast<u32x4*>(buf + r * LDA + col) = q.A[u];
         }
 #pragma unroll
         for (int u = 0; u < UX; ++u) {
             const int v = tid + u * TW_THREADS, r = v / (TW_H / 8), col = (v % (TW_H / 8)) * 8;
             if (v < NVX) {  // xhat on the fly (rows past Ntok: rstd = 0, they stay 0)
-                u32x4 xq = preX[u];
+                u32x4 xq = q.X[u];
                 float f[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { f[2 * i] = bf2f((bf16_t)(xq[i] & 0xFFFF)); f[2 * i + 1] = bf2f((bf16_t)(xq[i] >> 16)); }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = (f[e] - pmu[u]) * prs[u];
+                for (int e = 0; e < 8; ++e) f[e] = (f[e] - q.mu[u]) * q.rs[u];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xq[i] = pack2bf(f[2 * i], f[2 * i + 1]);
                 *reinterpret_cast<u32x4*>(buf + IMGA + r * LDX + col) = xq;
@@ -128,7 +133,20 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
     };
 
     int ch = blockIdx.x;
-    if (ch < nchunks) prefetch(ch);
+    const int gstep = (int)gridDim.x;
+    // behind the barrier of chunk `ch`: request the next chunk(s).  PD == 2: the set that arrived (requested a whole chunk ago) moves into the stash set,
+    // its registers take the request for the chunk after the next — two chunks in flight through one loop body (two inlined bodies, one per set,
+    // spilled 176 registers)
+    auto advance = [&]() {
+        if (PD == 2) {
+            ps0 = ps1;
+            if (ch + 2 * gstep < nchunks) prefetch(ps1, ch + 2 * gstep);
+        } else if (ch + gstep < nchunks) {
+            prefetch(ps0, ch + gstep);
+        }
+    };
+    if (ch < nchunks) prefetch(ps0, ch);
+    if (PD == 2 && ch + gstep < nchunks) prefetch(ps1, ch + gstep);
     lds_barrier();  // zero fill, fragments, gamma / beta
     int b = 0;
     if (w >= NTW) {
@@ -146,11 +164,11 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
         const int la = toff * LDA + tcol, lb = IMGA + toff * LDX + tcol;
         auto off_a = [&](int s) { const int tl = NWW * s + w4; return la + (tl < NTOT ? tl % MTA : 0) * 16; };  // slots past the last tile
         auto off_b = [&](int s) { const int tl = NWW * s + w4; return lb + (tl < NTOT ? tl / MTA : 0) * 16; };  // re-contract tile 0: never flushed
-        for (; ch < nchunks; ch += gridDim.x) {
+        for (; ch < nchunks; ch += gstep) {
             bf16_t* buf = base + (size_t)b * IMG;
-            stash(buf);
+            stash(ps0, buf);
             lds_barrier();
-            if (ch + (int)gridDim.x < nchunks) prefetch(ch + gridDim.x);
+            advance();
             // software pipeline over the NSW x 2 (tile, k-half) steps: the operands of step i+1 are requested before step i's MFMA
             Frag<bf16_t> fa[2], fb[2];
             frag_load_tr(fa[0], buf + off_a(0), LDA);
@@ -229,12 +247,12 @@ __global__ __launch_bounds__(TW_THREADS, 2) void tailw_kernel(TailArgs a) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) tail_load(ch, w + i * NTW, xn[i], dn[i]);
         }
-        for (; ch < nchunks; ch += gridDim.x) {
+        for (; ch < nchunks; ch += gstep) {
             bf16_t* buf = base + (size_t)b * IMG;
-            stash(buf);
+            stash(ps0, buf);
             lds_barrier();
-            const int nxt = ch + (int)gridDim.x;
-            if (nxt < nchunks) prefetch(nxt);
+            const int nxt = ch + gstep;
+            advance();
             RawC4<bf16_t> xc[TPW][BK_MT], dc[TPW][BK_MT];
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
@@ -275,14 +293,14 @@ __global__ __launch_bounds__(192) void tailw_affine_kernel(const float* __restri
     fk_tailw_affine(part, MTA, dgamma, dbeta);
 }
 
-template <int MA, int NBUF, int NTW>
+template <int MA, int NBUF, int NTW, int PD>
 static int tailw_go(const TailArgs& t, int grid, hipStream_t st) {
     constexpr int LDA = MA + 16;
     const size_t lds = (size_t)NBUF * TW_KC * (LDA + 112) * sizeof(bf16_t) + (size_t)6 * (MA / 32) * 512 * sizeof(bf16_t) + TW_H * sizeof(float);
     if (lds > 160 * 1024) return NBSS_EUNSUPPORTED;
-    int e = NBSS_SET_MAX_LDS((tailw_kernel<MA, NBUF, NTW>), lds);
+    int e = NBSS_SET_MAX_LDS((tailw_kernel<MA, NBUF, NTW, PD>), lds);
     if (e) return e;
-    NBSS_LAUNCH((tailw_kernel<MA, NBUF, NTW>), dim3(grid), dim3(TW_THREADS), lds, st, t);
+    NBSS_LAUNCH((tailw_kernel<MA, NBUF, NTW, PD>), dim3(grid), dim3(TW_THREADS), lds, st, t);
     return NBSS_CHECK_LAUNCH();
 }
 
@@ -309,11 +327,14 @@ int tailw_launch(int MA, const TailArgs& t0, float* wgpart, size_t wgpart_bytes,
         }
     }
     t.part = wgpart;
-    int e = MA == 192 ? tailw_go<192, 2, 4>(t, grid, st)
+#ifndef TW192_PD
+#define TW192_PD 1  // (A/B: 2 = two chunks in flight for W1 — measured 281 -> 345 us per launch, see the kernel's note)
+#endif
+    int e = MA == 192 ? tailw_go<192, 2, 4, TW192_PD>(t, grid, st)
 #ifdef NBSS_TW288_NBUF1
-            : MA == 288 ? tailw_go<288, 1, 2>(t, grid, st)
+            : MA == 288 ? tailw_go<288, 1, 2, 1>(t, grid, st)
 #else
-            : MA == 288 ? tailw_go<288, 2, TW288_NTW>(t, grid, st)  // both buffers + the 54 W^T fragments: 162 176 of 163 840 bytes
+            : MA == 288 ? tailw_go<288, 2, TW288_NTW, 1>(t, grid, st)  // both buffers + the 54 W^T fragments: 162 176 of 163 840 bytes
 #endif
             : NBSS_EUNSUPPORTED;
     if (e) return e;
