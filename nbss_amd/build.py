@@ -29,6 +29,17 @@ EMU_LIB = EMUDIR / "libnbss_emu.so"
 # a heavily cancelling sum) lands at 1.58x the reference's own bf16 error instead of 1.45x (other FMA contractions, same algorithm), above the 1.5x bar,
 # and the bar is not what gets moved.
 PER_FILE_FLAGS = {k: ["-fno-slp-vectorize"] for k in ("mhsa", "mhsa_bwd")}
+# The machine scheduler's strategy, per file (round 6; `-mllvm -amdgpu-sched-strategy=...` changes the order of the same instructions, not the arithmetic).
+# Measured per kernel in one call with the whole library built under each strategy (us per launch at batch 32, default -> strategy):
+#   iterative-minreg   full_bwd 526-535 -> 485, mhsa_bwd_h 795 -> 767      (but fconv_bwd 312 -> 464, tconvffn_bwd_q 1 092 -> 1 167, tconvffn_fwd 614 -> 640)
+#   iterative-maxocc   full_bwd -> 495, mhsa_bwd_h -> 771                   (fconv_fwd 141 -> 153)
+#   max-ilp            tailw<288> 336 -> 317, tailw<192> 277 -> 269, tconvffn_fwd 614 -> 604   (fconv_bwd 308 -> 434, mhsa_bwd_h -> 871, tconvffn_bwd_q +28)
+#   max-memory-clause  tailw<288> -> 323; mhsa_bwd_h -> 914
+# tconvffn_s.hip holds a kernel that gains (forward) and one that loses (backward) under max-ilp: it keeps the default.
+_SCHED = lambda s: ["-mllvm", f"-amdgpu-sched-strategy={s}"]
+PER_FILE_FLAGS["full"] = _SCHED("iterative-minreg")
+PER_FILE_FLAGS["mhsa_bwd"] = PER_FILE_FLAGS["mhsa_bwd"] + _SCHED("iterative-minreg")
+PER_FILE_FLAGS["tailw"] = _SCHED("max-ilp")
 
 
 def _sources():
