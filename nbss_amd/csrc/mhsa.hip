@@ -215,6 +215,11 @@ __global__ __launch_bounds__(64 * 16 / NSW, NSW == 4 ? 2 : 1) void mhsa_fwd_kern
         lds_barrier();
 
         // ---- stage B: attention per (strip, head); outputs stay in registers as B fragments ---
+        // (Per pair the ISA is phased: 16 + 16 MFMAs, then 64 v_exp_f32 in a row.  Round 6 built the software-pipelined form — the O^T MFMAs of pair i-1
+        //  issued between the exponentials of pair i, two per eight, pinned with an empty asm on the running sum + sched_barrier (without them the
+        //  instruction selector emits all exponentials behind the last MFMA) — and measured it equal: 622 / 622 vs 616 / 628 us per launch, the step
+        //  711-715 both ways.  With two waves per SIMD the other wave already fills the matrix pipe during this wave's softmax; s_setprio around the
+        //  MFMA bursts changed nothing either: 620-631 vs 626-632 us.)
         Frag<T> of[NSW][HPP];
 #pragma unroll
         for (int si = 0; si < NSW; ++si) {
