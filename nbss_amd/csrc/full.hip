@@ -361,7 +361,9 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
             const int f = (16 / TT) * nt + (l15 / TT);
             return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
         };
-        constexpr bool PF = false;  // (see the note at the kernel's launch bounds)
+        // (round 6, under the file's iterative-minreg schedule: 469 / 475 -> 460 / 466 us per launch with the prefetch in THIS pass — twelve registers;
+        //  in p5, twenty-four registers and 55 instead of 28 spilled: 561 us)
+        constexpr bool PF = true;
         RawC4<T> dnext[BK_MT];
         if (PF && w < ntile) rawc_load_row<T>(dnext, dy + row_of(w) * FL_H);
         for (int nt = w; nt < ntile; nt += nw) {
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(FL_THREADS, sizeof(T) == 2 && TT == 8 ? 4 : 2) void
             const int f = (16 / TT) * nt + (l15 / TT);
             return ((size_t)b * F + (f < F ? f : F - 1)) * T_ + tcl;
         };
-        constexpr bool PF = false;
+        constexpr bool PF = false;  // (see p3)
         RawC4<T> xnext[BK_MT], dnext[BK_MT];
         if (PF && w < ntile) {
             rawc_load_row<T>(xnext, x + row_of(w) * FL_H);
