@@ -38,6 +38,8 @@ struct FoldTable {
     FoldItem it[FOLD_MAX_ITEMS];
 };
 
+static_assert(sizeof(FoldTable) <= 4096, "the table travels as a by-value kernel argument");
+
 struct FoldBatch {
     hipStream_t st;
     char* pool;
