@@ -805,7 +805,7 @@ static int fconv_bwd_t(const nbss_cfg& c, const float* P, float* part, const voi
 
 #define TV_RSL_MAX 64  // (tconvffn_s.hip: TV_RSL, the most slices part16_slices_launch writes)
 // tconvffn_s.hip: fp32 slice sums of bf16 partial rows [nrows][p16] (fixed order; *nsl = slices written)
-int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl, hipStream_t st);
+int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl, hipStream_t st, bool batch);
 // dW[o][i][tap] += the slices' sums of the [tap][group][i][12 outputs] rows, in slice order (one owner per element: bitwise repeatable)
 static_assert(FC_H == FK_H && FC_CG == FK_FCG && FC_G == FK_FG && FC_P16 == FK_FC_P16, "foldk.h");
 __global__ __launch_bounds__(256) void fconv_part_final_kernel(const float* __restrict__ slices, int nsl, float* __restrict__ dW) {
@@ -854,15 +854,21 @@ int fconv_bwd_impl(const nbss_cfg& c, const float* P, float* G, const void* pack
     if ((e = affine_reduce_launch(part, nwg, sg, G, gs))) return e;
     if (fused) {  // the bf16 rows of the conv weight gradient: slice sums in fp32 (the idle wgrad partial region is the scratch), then one owner per element
         float* slices = (float*)((char*)ws + ws_wgpart_offset(c));
+        bool batch = false;
         if (g_fold) {
             int err;
             void* sl = g_fold->alloc((size_t)TV_RSL_MAX * FC_P16 * sizeof(float), &err);
-            if (err || !sl) return err ? err : NBSS_EUNSUPPORTED;
-            slices = (float*)sl;
+            if (err) return err;
+            if (sl) {
+                slices = (float*)sl;
+                batch = true;
+            } else if ((err = g_fold->flush())) {  // (larger than the pool: on its own, behind everything pending)
+                return err;
+            }
         }
         int nsl = 0;
-        if ((e = part16_slices_launch(part + (size_t)nwg * 4 * FC_H, nwg, slices, FC_P16, &nsl, gs))) return e;
-        if (g_fold) {
+        if ((e = part16_slices_launch(part + (size_t)nwg * 4 * FC_H, nwg, slices, FC_P16, &nsl, gs, batch))) return e;
+        if (batch) {
             FoldItem it;
             it.kind = FK_FCONV_FINAL;
             it.gx = (FC_P16 + 255) / 256; it.gy = 1; it.nblk = it.gx;

@@ -75,6 +75,9 @@ void* FoldBatch::alloc(size_t bytes, int* err) {
 }
 
 FoldScope::FoldScope(hipStream_t st, void* pool, size_t pool_bytes, size_t ntokens) : prev(g_fold), open(false) {
+    // NBSS_FOLD_POOL=<bytes>: test knob — a pool smaller than the sub-block's partial tiles exercises the flush-when-full and the larger-than-the-pool paths
+    static const long cap = [] { const char* v = getenv("NBSS_FOLD_POOL"); return v ? atol(v) : 0L; }();
+    if (cap > 0 && (size_t)cap < pool_bytes) pool_bytes = (size_t)cap;
     fb.st = st;
     fb.pool = (char*)pool;
     fb.pool_bytes = pool_bytes;

@@ -2204,10 +2204,10 @@ size_t tconvffn_v_part_bytes(const nbss_cfg& c) { return (size_t)c.B * c.F * (TV
 // fold of the bf16 weight-gradient partial rows into G (fp32); offs = flat-gradient offsets of the three conv weights and of W2; `slices`: TV_RSL x TV_P16 floats of scratch
 // with_w2: the rows carry the dW2 block behind the three conv blocks (tconvffn_bwd_v_kernel) or not (tconvffn_bwd_q_kernel)
 // first stage alone, for other kernels' bf16 partial rows (fconv.hip)
-int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl_out, hipStream_t st) {
+int part16_slices_launch(const void* part16, int nrows, float* slices, int p16, int* nsl_out, hipStream_t st, bool batch) {
     const int nsl = nrows < TV_RSL ? nrows : TV_RSL;
     *nsl_out = nsl;
-    if (g_fold) {  // inside a FoldScope (fold.h; `slices` is the caller's allocation from the scope's pool): first stage
+    if (g_fold && batch) {  // inside a FoldScope (fold.h; `slices` is the caller's allocation from the scope's pool): first stage
         g_fold->st = st;
         FoldItem it;
         it.kind = FK_P16_SLICES;

@@ -12,9 +12,11 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(flag: str, tmp: Path) -> dict:
-    out = tmp / f"fold_{flag}.pt"
+def _run(flag: str, tmp: Path, pool: str = "") -> dict:
+    out = tmp / f"fold_{flag}_{pool}.pt"
     env = dict(os.environ, NBSS_FOLD_BATCH=flag, HIPEMU_ORDER="fwd")
+    if pool:
+        env["NBSS_FOLD_POOL"] = pool
     subprocess.run([sys.executable, str(ROOT / "tests" / "emu_schedule_worker.py"), str(out)], check=True, env=env, cwd=str(ROOT), timeout=1500)
     return torch.load(out)
 
@@ -23,12 +25,15 @@ def test_batched_folds_equal_single_launches_bitwise(tmp_path):
     from nbss_amd.build import build_emu
     build_emu()  # once, before the workers race to build it
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(2) as ex:
-        single, batched = ex.map(lambda f: _run(f, tmp_path), ("0", "1"))
+    # pools of 400 KB / 100 KB: the scopes run full in mid sub-block (flush, then reuse of the pool) resp. meet requests larger than the pool (those
+    # folds leave alone, behind everything pending) — the partial tiles of the worker's shapes are 40 - 320 KB per launch
+    with ThreadPoolExecutor(4) as ex:
+        single, batched, tight, tiny = ex.map(lambda a: _run(a[0], tmp_path, a[1]), (("0", ""), ("1", ""), ("1", "400000"), ("1", "100000")))
     grads = [k for k in single if k.endswith("_G")]
     assert len(grads) >= 10 and all(float(single[k].abs().max()) > 0 for k in grads)
-    bad = [(k, int((single[k] != batched[k]).sum())) for k in single if not torch.equal(single[k], batched[k])]
-    assert not bad, bad
+    for name, got in (("batched", batched), ("pool 400 KB", tight), ("pool 100 KB", tiny)):
+        bad = [(k, int((single[k] != got[k]).sum())) for k in single if not torch.equal(single[k], got[k])]
+        assert not bad, (name, bad)
 
 
 def _device_worker(out: str):
