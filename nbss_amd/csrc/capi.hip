@@ -317,6 +317,10 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
     auto buf = [&](int i) -> void* { return acts ? (void*)((char*)acts + (size_t)i * sb) : (void*)(pp + (size_t)(i & 1) * sb); };
     int e = encoder_fwd_impl(c, params, packed, xin, buf(0), st);
     if (e) return e;
+#ifndef NBSS_TAIL_ROUNDS
+#define NBSS_TAIL_ROUNDS 40  // tail launches for grids below this many rounds (rounds 4-5: 8; round 6, same call: batch 16 — 8 rounds + 16 sequences —
+                             // 701 / 705 -> 715 / 716 utt/s with its tail launches, batch 32 739 / 731 -> 739 / 739)
+#endif
     // tail launches of the bf16 row kernels (side.h: SeqTail): when the last round of sequences is at most half full
     SeqTail tl = {0, st};
 #ifndef NBSS_EMU
@@ -331,7 +335,7 @@ int nbss_spatialnet_fwd(const nbss_cfg* cfg, const float* params, const void* pa
         // measured (same box, NBSS_SEQ_TAIL=0 / 1): batch 2 (1 round + 2 sequences) 297 -> 302 utt/s, batch 8 (4 + 8) 512 -> 516, batch 32 (16 + 32)
         // 624 -> 623: the tail launch pays while the rounds are few
         static const bool off = [] { const char* v = getenv("NBSS_SEQ_TAIL"); return v && v[0] == '0'; }();  // A/B knob
-        if (!off && c.dtype == NBSS_BF16 && c.H == 96 && c.T <= NBSS_T_TRAIN_MAX && nseq > ncu && nseq < 8 * ncu && rem > 0 && 2 * rem <= ncu) tl.n = rem;
+        if (!off && c.dtype == NBSS_BF16 && c.H == 96 && c.T <= NBSS_T_TRAIN_MAX && nseq > ncu && nseq < NBSS_TAIL_ROUNDS * ncu && rem > 0 && 2 * rem <= ncu) tl.n = rem;
     }
     const SeqTail* tlp = tl.n > 0 ? &tl : nullptr;
     for (int l = 0; l < c.L; ++l) {
