@@ -386,7 +386,12 @@ int nbss_spatialnet_bwd_range(const nbss_cfg* cfg, const float* params, float* g
     Side side;
     if (ss) {
         side = ss->sd;
-        if (c.B * c.F < 8 * ss->ncu) side.gs = ss->gs_low;
+#ifndef NBSS_GSLOW_ROUNDS
+#define NBSS_GSLOW_ROUNDS 0  // the lowest-priority gradient stream for grids below this many rounds of row-kernel workgroups: none any more (rounds 4-5: 8 — then
+                            // +1 % at batch 2 / 8; round 6, same call, 8 -> 0: batch 2 373.5 / 375.6 -> 378.3 / 378.0 utt/s, batch 8 630.6 / 629.8 -> 632.6 / 634.4;
+                            // 8 -> 40: batch 16 and 32 unchanged)
+#endif
+        if (c.B * c.F < NBSS_GSLOW_ROUNDS * ss->ncu) side.gs = ss->gs_low;
     }
     const Side* sd = ss ? &side : nullptr;
     bool rec[BWD_KINDS] = {false, false, false, false, false};
